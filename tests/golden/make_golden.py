@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Run in the build container only (it needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference (``/root/reference/ava/models/vae.py``) is imported with empty
+stand-in modules for ``h5py`` and ``affinewarp`` (neither is on the arithmetic
+path of ``VAE``; they are only imported by ``vae_dataset.py`` / ``models/utils.py``).
+Weights, inputs and the two normal draws of ``rsample`` come from the integer-hash
+recipe in ``ava_amd.synthetic``; the normal draws are
+injected by replacing
+``torch.distributions.lowrank_multivariate_normal._standard_normal``.
+
+Only *data* (inputs are re-derivable from the recipe; expected outputs are
+stored) is written: small ``.npz`` files, no reference source.
+"""
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+for _m in ("h5py", "affinewarp", "affinewarp.crossval"):
+    sys.modules[_m] = types.ModuleType(_m)
+sys.modules["affinewarp"].PiecewiseWarping = object
+sys.modules["affinewarp.crossval"].paramsearch = None
+sys.path.insert(0, "/root/reference")
+
+import torch.distributions.lowrank_multivariate_normal as lrmvn   # noqa: E402
+from ava.models.vae import VAE as RefVAE, X_DIM, X_SHAPE          # noqa: E402
+
+# our recipe lives in the product package (pure numpy, no device code)
+sys.path.insert(0, ROOT)
+import importlib.util                                             # noqa: E402
+_spec = importlib.util.spec_from_file_location(
+    "ava_amd", os.path.join(ROOT, "ava_amd", "__init__.py"),
+    submodule_search_locations=[os.path.join(ROOT, "autoencoded-vocal-analysis_amd")])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["ava_amd"] = _mod
+_spec.loader.exec_module(_mod)
+from ava_amd import synthetic as syn                              # noqa: E402
+from ava_amd.layout import param_specs                            # noqa: E402
+
+torch.set_num_threads(8)
+_QUEUE = []
+_orig_std_normal = lrmvn._standard_normal
+
+
+def _injected(shape, dtype, device):
+    t = _QUEUE.pop(0)
+    assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+    return t.to(dtype=dtype, device=device)
+
+
+lrmvn._standard_normal = _injected
+
+
+def push_noise(eps_w, eps_d):
+    _QUEUE.append(torch.from_numpy(np.ascontiguousarray(eps_w)))
+    _QUEUE.append(torch.from_numpy(np.ascontiguousarray(eps_d)))
+
+
+def build_ref(z_dim, save_dir=""):
+    m = RefVAE(save_dir=save_dir, z_dim=z_dim, device_name="cpu")
+    fp = syn.fixture_parameters(z_dim)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            p.copy_(torch.from_numpy(fp[name]))
+    return m
+
+
+def sample_idx(numel, h, k=16):
+    return np.minimum((syn.u01(k, 5000 + h) * numel).astype(np.int64), numel - 1)
+
+
+def bn_hooks(m, store):
+    hs = []
+    for i in range(1, 15):
+        name = "bn%d" % i
+
+        def hook(mod, inp, out, name=name):
+            x = inp[0].detach().double()
+            store[name + ".mean"] = x.mean(dim=(0, 2, 3)).numpy()
+            store[name + ".var"] = x.var(dim=(0, 2, 3), unbiased=False).numpy()
+        hs.append(getattr(m, name).register_forward_hook(hook))
+    return hs
+
+
+def running_stats(m, out, prefix):
+    for i in range(1, 15):
+        bn = getattr(m, "bn%d" % i)
+        out["%sbn%d.running_mean" % (prefix, i)] = bn.running_mean.numpy().copy()
+        out["%sbn%d.running_var" % (prefix, i)] = bn.running_var.numpy().copy()
+        out["%sbn%d.num_batches_tracked" % (prefix, i)] = bn.num_batches_tracked.numpy().copy()
+
+
+def grads_summary(m, out, prefix):
+    for h, (name, p) in enumerate(m.named_parameters()):
+        g = p.grad.detach().double().numpy().ravel()
+        out["%sgradnorm.%s" % (prefix, name)] = np.sqrt((g * g).sum())
+        out["%sgrad.%s" % (prefix, name)] = p.grad.detach().numpy().ravel()[sample_idx(g.size, h)]
+
+
+def params_summary(m, out, prefix):
+    for h, (name, p) in enumerate(m.named_parameters()):
+        a = p.detach().numpy().ravel()
+        out["%ssum.%s" % (prefix, name)] = a.astype(np.float64).sum()
+        out["%sval.%s" % (prefix, name)] = a[sample_idx(a.size, h)]
+
+
+def forward_backward_case(B, z_dim, steps):
+    """Train-mode forward/backward/Adam on fixed (x, eps) for ``steps`` steps,
+    then an eval-mode forward."""
+    out = {}
+    m = build_ref(z_dim)
+    m.train()
+    x = torch.from_numpy(syn.spectrograms(B))
+    eps_w, eps_d = syn.noise(B, z_dim)
+    for step in range(1, steps + 1):
+        pre = "s%d." % step
+        if step == 1:
+            # probing pass on a throw-away copy: intermediates the forward() API hides
+            probe = build_ref(z_dim)
+            probe.train()
+            store = {}
+            hs = bn_hooks(probe, store)
+            push_noise(eps_w, eps_d)
+            mu, u, d = probe.encode(x)
+            dist = lrmvn.LowRankMultivariateNormal(mu, u, d)
+            zs = dist.rsample()
+            xr = probe.decode(zs)
+            for h_ in hs:
+                h_.remove()
+            out.update({pre + k: v for k, v in store.items()})
+            out[pre + "mu"] = mu.detach().numpy()[:2]
+            out[pre + "u"] = u.detach().numpy()[:2, :, 0]
+            out[pre + "d"] = d.detach().numpy()[:2]
+            out[pre + "z"] = zs.detach().numpy()[:2]
+            pix = sample_idx(B * X_DIM, 999, 64)
+            out[pre + "xrec_idx"] = pix
+            out[pre + "xrec"] = xr.detach().numpy().ravel()[pix]
+            out[pre + "sum_z2"] = float((zs.detach().double() ** 2).sum())
+            out[pre + "sse"] = float(((x.view(B, -1).double() - xr.detach().double()) ** 2).sum())
+            out[pre + "sum_h"] = float(dist.entropy().detach().double().sum())
+            del probe
+        m.optimizer.zero_grad()
+        push_noise(eps_w, eps_d)
+        loss = m.forward(x)
+        out[pre + "loss"] = float(loss.item())
+        loss.backward()
+        if step == 1:
+            grads_summary(m, out, pre)
+            running_stats(m, out, pre)
+        m.optimizer.step()
+        params_summary(m, out, pre)
+        if step in (1, steps):
+            st = m.optimizer.state_dict()["state"]
+            for h, (name, p) in enumerate(m.named_parameters()):
+                idx = sample_idx(p.numel(), h)
+                out["%sexp_avg.%s" % (pre, name)] = st[h]["exp_avg"].numpy().ravel()[idx]
+                out["%sexp_avg_sq.%s" % (pre, name)] = st[h]["exp_avg_sq"].numpy().ravel()[idx]
+            out[pre + "adam_step"] = float(st[0]["step"])
+    running_stats(m, out, "final.")
+    # eval-mode forward (running-stat path, vae.py:376-382)
+    m.eval()
+    with torch.no_grad():
+        push_noise(eps_w, eps_d)
+        out["eval.loss"] = float(m.forward(x).item())
+        mu, u, d = m.encode(x)
+        out["eval.mu"] = mu.numpy()[:2]
+        out["eval.d"] = d.numpy()[:2]
+    return out, m
+
+
+def eval_fresh_case(B, z_dim):
+    m = build_ref(z_dim)
+    m.eval()
+    x = torch.from_numpy(syn.spectrograms(B))
+    eps_w, eps_d = syn.noise(B, z_dim)
+    with torch.no_grad():
+        push_noise(eps_w, eps_d)
+        return {"eval_fresh.loss": float(m.forward(x).item())}
+
+
+def get_latent_case(z_dim=32, B=8, nb=2):
+    """get_latent on a fresh (train-mode!) module, vae.py:519-547."""
+    m = build_ref(z_dim)
+    ds = syn.SyntheticSpecDataset(B * nb)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False)
+    lat = m.get_latent(loader)
+    out = {"latent": lat}
+    running_stats(m, out, "after.")
+    return out
+
+
+def ddp_case(z_dim=32, B=8, shards=2):
+    """Each shard run separately from identical weights; grads summed."""
+    out = {}
+    x = syn.spectrograms(B * shards)
+    eps_w, eps_d = syn.noise(B * shards, z_dim)
+    total = None
+    for r in range(shards):
+        m = build_ref(z_dim)
+        m.train()
+        sl = slice(r * B, (r + 1) * B)
+        push_noise(eps_w[sl], eps_d[sl])
+        loss = m.forward(torch.from_numpy(x[sl]))
+        loss.backward()
+        out["shard%d.loss" % r] = float(loss.item())
+        g = [p.grad.detach().double().numpy().ravel() for p in m.parameters()]
+        total = g if total is None else [a + b for a, b in zip(total, g)]
+    for h, (s, g) in enumerate(zip(param_specs(z_dim), total)):
+        out["gradnorm." + s.name] = np.sqrt((g * g).sum())
+        out["grad." + s.name] = g[sample_idx(g.size, h)]
+    return out
+
+
+def harness_case(z_dim=32, B=8, nb=2):
+    """train_epoch / test_epoch / train_loop / checkpoint manifest (vae.py:330-472)."""
+    out = {}
+    tmp = tempfile.mkdtemp()
+    m = build_ref(z_dim, save_dir=tmp)
+    ds = syn.SyntheticSpecDataset(B * nb)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False)
+    loaders = {"train": loader, "test": loader}
+
+    def queue_epoch(tag):
+        for k in range(nb):
+            ew, ed = syn.noise(B, z_dim, 2002 + 10 * k + tag, 3003 + 10 * k + tag)
+            push_noise(ew, ed)
+    # train_loop(epochs=2, test_freq=1, save_freq=1, vis_freq=None)
+    queue_epoch(0); queue_epoch(100); queue_epoch(1); queue_epoch(101)
+    m.train_loop(loaders, epochs=2, test_freq=1, save_freq=1, vis_freq=None)
+    assert not _QUEUE
+    out["train_loss"] = np.array([m.loss["train"][0], m.loss["train"][1]])
+    out["test_loss"] = np.array([m.loss["test"][0], m.loss["test"][1]])
+    out["epoch"] = m.epoch
+    files = sorted(os.listdir(tmp))
+    ck = torch.load(os.path.join(tmp, "checkpoint_001.tar"), weights_only=True)
+    manifest = {"files": files, "keys": list(ck.keys()), "layers": {}, "epoch": ck["epoch"],
+                "z_dim": ck["z_dim"], "lr": ck["lr"], "loss_keys": {k: sorted(v.keys()) for k, v in ck["loss"].items()}}
+    for k, v in ck.items():
+        if isinstance(v, dict) and k not in ("optimizer_state", "loss"):
+            manifest["layers"][k] = {kk: [list(vv.shape), str(vv.dtype)] for kk, vv in v.items()}
+    pg = ck["optimizer_state"]["param_groups"]
+    manifest["param_groups"] = [{k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in g.items()} for g in pg]
+    st = ck["optimizer_state"]["state"]
+    manifest["opt_state"] = {str(i): {kk: [list(vv.shape), str(vv.dtype)] for kk, vv in st[i].items()} for i in sorted(st)}
+    with open(os.path.join(HERE, "checkpoint_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    return out
+
+
+def main():
+    for B, z, steps in ((8, 32, 3), (8, 64, 1), (64, 32, 1)):
+        out, _ = forward_backward_case(B, z, steps)
+        if (B, z) == (8, 32):
+            out.update(eval_fresh_case(B, z))
+        np.savez_compressed(os.path.join(HERE, "step_B%d_z%d.npz" % (B, z)), **out)
+        print("B=%d z=%d loss=%r" % (B, z, out["s1.loss"]))
+    np.savez_compressed(os.path.join(HERE, "get_latent.npz"), **get_latent_case())
+    np.savez_compressed(os.path.join(HERE, "ddp2.npz"), **ddp_case())
+    np.savez_compressed(os.path.join(HERE, "harness.npz"), **harness_case())
+    assert not _QUEUE
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,280 @@
+// BatchNorm2d statistics / finalisation (forward and backward) and the NHWC <-> NCHW-flatten
+// hand-offs between the convolutional and fully connected parts of the VAE.
+//
+// Replaces ATen's batch_norm / batch_norm_backward (nn.BatchNorm2d, ava/models/vae.py:135-141,
+// 162-168) -- the *apply* part of BatchNorm lives in the prologue of the consuming convolution
+// (conv.hip), the per-channel sums in the epilogue of the producing kernel; what remains here are
+// the tiny per-channel reductions between them.  Per-workgroup partial sums are fp32, everything
+// across workgroups is accumulated in fp64 in a fixed order (deterministic, and as accurate as the
+// reference's CPU kernels, which accumulate float tensors in double).
+#include "common.h"
+
+#define BN_EPS 1e-5
+#define BN_MOMENTUM 0.1
+
+// ---- statistics of a raw tensor x[n][C] (used for bn1, whose input has no producer kernel) --------
+template <int C>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t n,
+                                                       float* __restrict__ partials) {
+  __shared__ float red[4][2 * C];
+  float s1[C], s2[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) s1[c] = s2[c] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (C == 1) {
+    const int64_t n4 = n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 v = x4[i];
+      s1[0] += (v.x + v.y) + (v.z + v.w);
+      s2[0] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      for (int64_t i = n4 * 4; i < n; ++i) { s1[0] += x[i]; s2[0] += x[i] * x[i]; }
+  } else {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float v = x[p * C + c];
+        s1[c] += v;
+        s2[c] = fmaf(v, v, s2[c]);
+      }
+    }
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float r1 = wave_sum(s1[c]), r2 = wave_sum(s2[c]);
+    if (l == 0) { red[w][c] = r1; red[w][C + c] = r2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C)
+    partials[(size_t)blockIdx.x * 2 * C + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// column sums of partials[nparts][ncols] in fp64; result in sums[ncols] (shared memory, double)
+__device__ void column_sums(const float* __restrict__ partials, int nparts, int ncols, double* sums /*[ncols]*/,
+                            double* scratch /*[1024]*/) {
+  const int t = threadIdx.x;
+  const int groups = 1024 / ncols;
+  const int col = t % ncols, grp = t / ncols;
+  double s = 0.0;
+  if (grp < groups)
+    for (int r = grp; r < nparts; r += groups) s += (double)partials[(size_t)r * ncols + col];
+  scratch[t] = grp < groups ? s : 0.0;
+  __syncthreads();
+  if (t < ncols) {
+    double tot = 0.0;
+    for (int gI = 0; gI < groups; ++gI) tot += scratch[gI * ncols + t];
+    sums[t] = tot;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double n,
+                                                           int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* running_mean,
+                                                           float* running_var, int64_t* num_batches, int train,
+                                                           float* mean_o, float* invstd_o, float* scale_o,
+                                                           float* shift_o) {
+  __shared__ double sums[64];
+  __shared__ double scratch[1024];
+  if (train) column_sums(partials, nparts, 2 * C, sums, scratch);
+  const int c = threadIdx.x;
+  if (c < C) {
+    double mean, var;
+    if (train) {
+      mean = sums[c] / n;
+      var = sums[C + c] / n - mean * mean;      // biased variance
+      if (var < 0.0) var = 0.0;
+      if (running_mean != nullptr) {
+        const double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+        running_mean[c] = (float)((1.0 - BN_MOMENTUM) * (double)running_mean[c] + BN_MOMENTUM * mean);
+        running_var[c] = (float)((1.0 - BN_MOMENTUM) * (double)running_var[c] + BN_MOMENTUM * unb);
+      }
+    } else {
+      mean = (double)running_mean[c];
+      var = (double)running_var[c];
+    }
+    const float meanf = (float)mean;
+    const float invstd = (float)(1.0 / sqrt(var + BN_EPS));
+    const float sc = gamma[c] * invstd;
+    mean_o[c] = meanf;
+    invstd_o[c] = invstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - meanf * sc;
+  }
+  if (train && threadIdx.x == 0 && num_batches != nullptr) *num_batches += 1;
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __restrict__ partials, int nparts,
+                                                               double n, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, float* dgamma,
+                                                               float* dbeta, float* A, float* Bc, float* Cc) {
+  __shared__ double sums[64];
+  __shared__ double scratch[1024];
+  column_sums(partials, nparts, 2 * C, sums, scratch);
+  const int c = threadIdx.x;
+  if (c < C) {
+    const double dB = sums[c];            // sum g
+    const double dG = sums[C + c];        // sum g * xhat
+    const double is = (double)invstd[c], gm = (double)gamma[c], mu = (double)mean[c];
+    const double a = gm * is;
+    const double b = -gm * is * is * dG / n;
+    dgamma[c] = (float)dG;
+    dbeta[c] = (float)dB;
+    A[c] = (float)a;
+    Bc[c] = (float)b;
+    Cc[c] = (float)(-a * dB / n - b * mu);
+  }
+}
+
+// ---- NCHW-flatten <-> NHWC hand-offs (per sample: 32 channels x 256 pixels) --------------------------
+// f8 [B][32*256] (c*256+p) -> out [B][256][32], plus per-channel {sum, sum^2} partials for bn8
+__global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 float* __restrict__ partials, int B) {
+  __shared__ float tile[32][257];
+  __shared__ float red[8][64];
+  const int t = threadIdx.x;
+  float s1 = 0.f, s2 = 0.f;                 // thread -> channel t&31, 8 threads per channel
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) tile[i >> 8][i & 255] = in[(size_t)b * 8192 + i];
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) {
+      const int p = i >> 5, c = i & 31;
+      const float v = tile[c][p];
+      out[(size_t)b * 8192 + i] = v;
+      s1 += v;                              // c == t&31 for every i of this thread
+      s2 = fmaf(v, v, s2);
+    }
+  }
+  red[t >> 5][t & 31] = s1;
+  red[t >> 5][32 + (t & 31)] = s2;
+  __syncthreads();
+  if (t < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][t];
+    partials[(size_t)blockIdx.x * 64 + t] = s;
+  }
+}
+
+// y7 [B][256][32] -> out [B][32*256]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B) {
+  __shared__ float tile[32][257];
+  const int t = threadIdx.x;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) tile[i & 31][i >> 5] = in[(size_t)b * 8192 + i];
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) out[(size_t)b * 8192 + i] = tile[i >> 8][i & 255];
+  }
+}
+
+// dU7 (NHWC) = (y7 > 0) ? dy7 (NCHW-flatten, from fc1's backward) : 0       (ReLU of vae.py:223)
+__global__ __launch_bounds__(256) void relu_mask_to_nhwc_kernel(const float* __restrict__ dy_nchw,
+                                                                const float* __restrict__ y_nhwc,
+                                                                float* __restrict__ du_nhwc, int B) {
+  __shared__ float tile[32][257];
+  const int t = threadIdx.x;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) tile[i >> 8][i & 255] = dy_nchw[(size_t)b * 8192 + i];
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) {
+      const float y = y_nhwc[(size_t)b * 8192 + i];
+      du_nhwc[(size_t)b * 8192 + i] = y > 0.f ? tile[i & 31][i >> 5] : 0.f;
+    }
+  }
+}
+
+// dF8 (NCHW-flatten) = (f8 > 0) ? A[c]*g + Bc[c]*f8 + Cc[c] : 0 ; g = dXhat8 (NHWC)   (bn8 backward + ReLU of fc8)
+__global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* __restrict__ g_nhwc,
+                                                                   const float* __restrict__ f8_nchw,
+                                                                   const float* __restrict__ A,
+                                                                   const float* __restrict__ Bc,
+                                                                   const float* __restrict__ Cc,
+                                                                   float* __restrict__ out_nchw, int B) {
+  __shared__ float tile[32][257];
+  const int t = threadIdx.x;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) tile[i & 31][i >> 5] = g_nhwc[(size_t)b * 8192 + i];
+    __syncthreads();
+    for (int i = t; i < 8192; i += 256) {
+      const int c = i >> 8;
+      const float f = f8_nchw[(size_t)b * 8192 + i];
+      out_nchw[(size_t)b * 8192 + i] = f > 0.f ? fmaf(A[c], tile[c][i & 255], fmaf(Bc[c], f, Cc[c])) : 0.f;
+    }
+  }
+}
+
+extern "C" int ava_bn_stats(const float* x, int64_t n, int C, float* partials, int* nparts, ava_stream_t s) {
+  if (x == nullptr || partials == nullptr || n <= 0) return AVA_EINVAL;
+  int64_t work = C == 1 ? n / 4 : n;
+  int grid = (int)((work + 256 * 8 - 1) / (256 * 8));
+  if (grid < 1) grid = 1;
+  if (grid > 1024) grid = 1024;
+  hipStream_t st = to_stream(s);
+  switch (C) {
+    case 1: hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 8: hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 16: hipLaunchKernelGGL(bn_stats_kernel<16>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 24: hipLaunchKernelGGL(bn_stats_kernel<24>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 32: hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    default: return AVA_EINVAL;
+  }
+  AVA_CHECK_LAUNCH();
+  if (nparts != nullptr) *nparts = grid;
+  return AVA_OK;
+}
+
+extern "C" int ava_bn_finalize(const float* partials, int nparts, int64_t n, int C, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                               int train, float* mean, float* invstd, float* scale, float* shift, ava_stream_t s) {
+  if (C < 1 || C > 32 || gamma == nullptr || beta == nullptr || mean == nullptr) return AVA_EINVAL;
+  if (train && partials == nullptr) return AVA_EINVAL;
+  if (!train && (running_mean == nullptr || running_var == nullptr)) return AVA_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, to_stream(s), partials, nparts, (double)n, C, gamma,
+                     beta, running_mean, running_var, num_batches, train, mean, invstd, scale, shift);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+extern "C" int ava_bn_finalize_bwd(const float* partials, int nparts, int64_t n, int C, const float* gamma,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* A,
+                                   float* Bc, float* Cc, ava_stream_t s) {
+  if (C < 1 || C > 32 || partials == nullptr || gamma == nullptr) return AVA_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(1024), 0, to_stream(s), partials, nparts, (double)n, C,
+                     gamma, mean, invstd, dgamma, dbeta, A, Bc, Cc);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+// internal (model.hip)
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, hipStream_t st) {
+  const int grid = B < 256 ? B : 256;
+  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B);
+  AVA_CHECK_LAUNCH();
+  *nparts = grid;
+  return AVA_OK;
+}
+int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, st, in, out, B);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st) {
+  hipLaunchKernelGGL(relu_mask_to_nhwc_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, st, dy_nchw, y_nhwc, du, B);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
+                             float* out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}

@@ -1,0 +1,192 @@
+// Latent block (reparameterisation + entropy + prior), ELBO assembly, Adam and the counter RNG.
+//
+//  * latent_fwd/bwd replace torch.exp (vae.py:232), LowRankMultivariateNormal.__init__/rsample/entropy
+//    (vae.py:312-313,323; torch/distributions/lowrank_multivariate_normal.py:17-38,98-139,214-252)
+//    and their autograd; rank 1, so the "capacitance" matrix is the scalar K = 1 + sum u^2/d.
+//  * elbo_finalize assembles vae.py:316-323 from the per-sample / per-workgroup partial sums.
+//  * adam_flat is torch.optim.Adam's single-tensor update (torch/optim/adam.py:414-547) over the
+//    whole flat parameter arena in one launch.
+#include "common.h"
+
+#define LOG_2PI 1.8378770664093453
+
+// one wave per sample; lane j handles latent dims j, j+64
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ u,
+                                                         const float* __restrict__ logd,
+                                                         const float* __restrict__ eps_w,
+                                                         const float* __restrict__ eps_d, float* __restrict__ d_out,
+                                                         float* __restrict__ z_out, float* __restrict__ sums,
+                                                         int* __restrict__ status, int B, int zdim) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float ew = eps_w[b];
+  float sz2 = 0.f, su2d = 0.f, slogd = 0.f;
+  bool bad = false;
+  for (int j = lane; j < zdim; j += 64) {
+    const size_t i = (size_t)b * zdim + j;
+    const float a = logd[i];
+    const float d = expf(a);
+    const float uu = u[i];
+    const float z = mu[i] + uu * ew + sqrtf(d) * eps_d[i];
+    d_out[i] = d;
+    z_out[i] = z;
+    sz2 = fmaf(z, z, sz2);
+    su2d += uu * uu / d;
+    slogd += logf(d);
+    bad |= !(d > 0.f);
+  }
+  sz2 = wave_sum(sz2);
+  su2d = wave_sum(su2d);
+  slogd = wave_sum(slogd);
+  if (bad && status != nullptr) atomicOr(status, 1);
+  if (lane == 0) {
+    const float K = 1.f + su2d;
+    sums[2 * b] = sz2;
+    sums[2 * b + 1] = 0.5f * ((float)(zdim * (1.0 + LOG_2PI)) + logf(K) + slogd);
+  }
+}
+
+// g = z + dz_dec ; dmu = g ; du = g*eps_w - (u/d)/K ; dlogd = 0.5*g*eps_d*sqrt(d) - 0.5*(1 - u^2/(d K))
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dz,
+                                                         const float* __restrict__ u, const float* __restrict__ d,
+                                                         const float* __restrict__ eps_w,
+                                                         const float* __restrict__ eps_d, float* __restrict__ dmu,
+                                                         float* __restrict__ du, float* __restrict__ dlogd, int B,
+                                                         int zdim) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float su2d = 0.f;
+  for (int j = lane; j < zdim; j += 64) {
+    const size_t i = (size_t)b * zdim + j;
+    su2d += u[i] * u[i] / d[i];
+  }
+  const float K = 1.f + wave_sum(su2d);
+  const float ew = eps_w[b];
+  for (int j = lane; j < zdim; j += 64) {
+    const size_t i = (size_t)b * zdim + j;
+    const float g = z[i] + dz[i];
+    const float uu = u[i], dd = d[i];
+    dmu[i] = g;
+    du[i] = g * ew - (uu / dd) / K;
+    dlogd[i] = 0.5f * g * eps_d[i] * sqrtf(dd) - 0.5f * (1.f - uu * uu / (dd * K));
+  }
+}
+
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* __restrict__ latent_sums, int B,
+                                                            const float* __restrict__ sse_partials, int nparts,
+                                                            int stride, int zdim, float prec,
+                                                            float* __restrict__ loss_out) {
+  __shared__ double red[3][4];
+  double sz2 = 0.0, sh = 0.0, sse = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) { sz2 += (double)latent_sums[2 * b]; sh += (double)latent_sums[2 * b + 1]; }
+  for (int p = threadIdx.x; p < nparts; p += 256) sse += (double)sse_partials[(size_t)p * stride];
+  sz2 = wave_sum_d(sz2); sh = wave_sum_d(sh); sse = wave_sum_d(sse);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = sz2; red[1][w] = sh; red[2][w] = sse; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sz2 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    sh = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    sse = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    // -elbo = 0.5*(sum z^2 + zdim ln 2pi) + 0.5*X_DIM*ln(2pi/prec) + 0.5*prec*SSE - sum H   (vae.py:316-323)
+    const double c1 = 0.5 * zdim * LOG_2PI;
+    const double c2 = 0.5 * 16384.0 * (LOG_2PI - log((double)prec));
+    loss_out[0] = (float)(0.5 * sz2 + c1 + c2 + 0.5 * (double)prec * sse - sh);
+    loss_out[1] = (float)sz2;
+    loss_out[2] = (float)sse;
+    loss_out[3] = (float)sh;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                        float one_minus_b1, float b2, float one_minus_b2,
+                                                        float step_size, float sqrt_bc2, float eps) {
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const float4 gg = g4[i];
+#define AVA_ADAM1(c)                                                        \
+    mm.c = mm.c + (gg.c - mm.c) * one_minus_b1;       /* exp_avg.lerp_ */   \
+    vv.c = vv.c * b2 + (one_minus_b2 * gg.c) * gg.c;  /* mul_/addcmul_ */   \
+    pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) / sqrt_bc2 + eps));
+    AVA_ADAM1(x) AVA_ADAM1(y) AVA_ADAM1(z) AVA_ADAM1(w)
+#undef AVA_ADAM1
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+}
+
+// splitmix64 finaliser; matches ava_amd.synthetic.u01 / gauss so that injected and
+// device-generated noise agree to float rounding when seeded alike.
+__device__ __forceinline__ double u01_hash(uint64_t i, uint64_t salt) {
+  uint64_t x = i + salt * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ void fill_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double u1 = u01_hash((uint64_t)i + offset, seed), u2 = u01_hash((uint64_t)i + offset, seed + 7777);
+    out[i] = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2));
+  }
+}
+
+extern "C" int ava_latent_fwd(const float* mu, const float* u, const float* logd, const float* eps_w,
+                              const float* eps_d, float* d, float* z, float* sums, int* status, int B, int zdim,
+                              ava_stream_t s) {
+  if (B <= 0 || zdim <= 0 || mu == nullptr || eps_w == nullptr || eps_d == nullptr) return AVA_EINVAL;
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, to_stream(s), mu, u, logd, eps_w, eps_d, d,
+                     z, sums, status, B, zdim);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+extern "C" int ava_latent_bwd(const float* z, const float* dz_dec, const float* u, const float* d, const float* eps_w,
+                              const float* eps_d, float* dmu, float* du, float* dlogd, int B, int zdim,
+                              ava_stream_t s) {
+  if (B <= 0 || zdim <= 0 || z == nullptr) return AVA_EINVAL;
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, to_stream(s), z, dz_dec, u, d, eps_w, eps_d,
+                     dmu, du, dlogd, B, zdim);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
+                              int zdim, float prec, float* loss_out, hipStream_t st) {
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, latent_sums, B, sse_partials, nparts, stride, zdim,
+                     prec, loss_out);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+extern "C" int ava_elbo_finalize(const float* latent_sums, int B, const float* sse_partials, int nparts, int zdim,
+                                 float prec, float* loss_out, ava_stream_t s) {
+  if (latent_sums == nullptr || sse_partials == nullptr || loss_out == nullptr) return AVA_EINVAL;
+  return ava_elbo_finalize_strided(latent_sums, B, sse_partials, nparts, 2, zdim, prec, loss_out, to_stream(s));
+}
+extern "C" int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int step, ava_stream_t s) {
+  if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0 || n % 4 != 0 || step < 1)
+    return AVA_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float sqrt_bc2 = (float)sqrt(bc2);
+  int64_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, to_stream(s), p, g, m, v, n4, 1.f - beta1, beta2,
+                     1.f - beta2, step_size, sqrt_bc2, eps);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+extern "C" int ava_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, ava_stream_t s) {
+  if (out == nullptr || n <= 0) return AVA_EINVAL;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(blocks), dim3(256), 0, to_stream(s), out, n, seed, offset);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}

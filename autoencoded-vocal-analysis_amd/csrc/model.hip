@@ -1,0 +1,492 @@
+// Whole-path driver: VAE.forward / loss.backward() / Adam.step of ava/models/vae.py:273-353 as a
+// fixed sequence of kernel launches on one HIP stream, over a caller-provided workspace.
+// Host-only bookkeeping lives in `ava_model`; nothing here allocates device memory or synchronises.
+#include <string.h>
+#include <string>
+#include <map>
+#include "common.h"
+
+// internal entry points of the other translation units
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, hipStream_t st);
+int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st);
+int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st);
+int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
+                             float* out, int B, hipStream_t st);
+int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
+                              int zdim, float prec, float* loss_out, hipStream_t st);
+
+enum { MODE_S1 = 0, MODE_DOWN = 1, MODE_UP = 2 };
+enum { PRO_BN = 0, PRO_BWD = 1, PRO_ID = 2 };
+enum { EPI_FWD = 0, EPI_BWD = 1, EPI_SSE = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_EXP = 2 };
+
+#define NCONV 14
+#define NPARAM 80
+#define ALIGN_F 64
+
+struct ConvLayer {
+  int cin, cout, mode, hi;        // forward gather mode, input height (= width)
+  int ho;
+  int transposed;                 // 0: Conv2d, 1: ConvTranspose2d
+  int pw, pb, pg, pbeta;          // parameter indices: weight, bias, bn gamma, bn beta
+};
+
+// named_parameters() order (vae.py:125-168): conv1..7 (w,b) 0..13 ; bn1..7 (w,b) 14..27 ; fc1,fc2,fc31,fc32,fc33,
+// fc41,fc42,fc43,fc5..fc8 (w,b) 28..51 ; convt1..7 (w,b) 52..65 ; bn8..14 (w,b) 66..79
+static const ConvLayer kLayers[NCONV] = {
+    {1, 8, MODE_S1, 128, 128, 0, 0, 1, 14, 15},    {8, 8, MODE_DOWN, 128, 64, 0, 2, 3, 16, 17},
+    {8, 16, MODE_S1, 64, 64, 0, 4, 5, 18, 19},     {16, 16, MODE_DOWN, 64, 32, 0, 6, 7, 20, 21},
+    {16, 24, MODE_S1, 32, 32, 0, 8, 9, 22, 23},    {24, 24, MODE_DOWN, 32, 16, 0, 10, 11, 24, 25},
+    {24, 32, MODE_S1, 16, 16, 0, 12, 13, 26, 27},  {32, 24, MODE_S1, 16, 16, 1, 52, 53, 66, 67},
+    {24, 24, MODE_UP, 16, 32, 1, 54, 55, 68, 69},  {24, 16, MODE_S1, 32, 32, 1, 56, 57, 70, 71},
+    {16, 16, MODE_UP, 32, 64, 1, 58, 59, 72, 73},  {16, 8, MODE_S1, 64, 64, 1, 60, 61, 74, 75},
+    {8, 8, MODE_UP, 64, 128, 1, 62, 63, 76, 77},   {8, 1, MODE_S1, 128, 128, 1, 64, 65, 78, 79},
+};
+
+struct ParamInfo { int64_t off, numel; };
+
+// Arena order: named_parameters() order, except that the three 256->64 head layers are grouped as
+// fc31.w fc32.w fc33.w | fc31.b fc32.b fc33.b so that they form one [192,256] matrix and one [192] bias
+// (a single GEMM forward, a single pair of GEMMs backward).  Checkpoints are unaffected: the Python
+// parameters are views into the arena keyed by name.
+static void build_param_table(int z, ParamInfo* tab, int64_t* total) {
+  int64_t numel[NPARAM];
+  int p = 0;
+  const int enc[7][2] = {{1, 8}, {8, 8}, {8, 16}, {16, 16}, {16, 24}, {24, 24}, {24, 32}};
+  for (int i = 0; i < 7; ++i) { numel[p++] = (int64_t)enc[i][0] * enc[i][1] * 9; numel[p++] = enc[i][1]; }
+  const int bne[7] = {1, 8, 8, 16, 16, 24, 24};
+  for (int i = 0; i < 7; ++i) { numel[p++] = bne[i]; numel[p++] = bne[i]; }
+  const int fc[12][2] = {{8192, 1024}, {1024, 256}, {256, 64}, {256, 64}, {256, 64}, {64, z}, {64, z}, {64, z},
+                         {z, 64}, {64, 256}, {256, 1024}, {1024, 8192}};
+  for (int i = 0; i < 12; ++i) { numel[p++] = (int64_t)fc[i][0] * fc[i][1]; numel[p++] = fc[i][1]; }
+  const int dec[7][2] = {{32, 24}, {24, 24}, {24, 16}, {16, 16}, {16, 8}, {8, 8}, {8, 1}};
+  for (int i = 0; i < 7; ++i) { numel[p++] = (int64_t)dec[i][0] * dec[i][1] * 9; numel[p++] = dec[i][1]; }
+  const int bnd[7] = {32, 24, 24, 16, 16, 8, 8};
+  for (int i = 0; i < 7; ++i) { numel[p++] = bnd[i]; numel[p++] = bnd[i]; }
+  int order[NPARAM], n = 0;
+  for (int i = 0; i < 32; ++i) order[n++] = i;
+  order[n++] = 32; order[n++] = 34; order[n++] = 36;      // fc31.w fc32.w fc33.w
+  order[n++] = 33; order[n++] = 35; order[n++] = 37;      // fc31.b fc32.b fc33.b
+  for (int i = 38; i < NPARAM; ++i) order[n++] = i;
+  int64_t cur = 0;
+  for (int k = 0; k < NPARAM; ++k) {
+    const int i = order[k];
+    tab[i].off = cur;
+    tab[i].numel = numel[i];
+    cur += (numel[i] + ALIGN_F - 1) / ALIGN_F * ALIGN_F;
+  }
+  *total = cur;
+}
+
+struct ava_model {
+  int z, maxB;
+  float prec;
+  float *P, *G, *M, *V;
+  float* bn_running;
+  int64_t* bn_batches;
+  ParamInfo tab[NPARAM];
+  int64_t arena;
+  // workspace carving
+  float* X[NCONV];          // raw input of conv layer l (X[0] is the caller's x; X[7] = f8 NHWC)
+  float *y7, *y7t;          // conv7 output NHWC and NCHW-flatten
+  float *h1, *h2, *h3, *mu, *u, *logd, *d, *zs, *lat_sums;
+  float *h5, *h6, *h7, *f8;
+  float *xrec, *seed;
+  float* bn_part;           // [1024][64]
+  float* bn_save;           // [14][4][32]: mean, invstd, scale, shift
+  float* bn_bwd;            // [14][3][32]: A, Bc, Cc
+  float* Gf[NCONV];
+  float* Gb[NCONV];
+  float *gA, *gB;           // gradient ping-pong, B*131072 floats each
+  float* wg_part;           // wgrad partial rows
+  float *dF8, *dh7, *dh6, *dh5, *dz, *dmu, *du, *dlogd, *dh3, *dh2, *dh1, *dy7;
+  float* gemm_ws;
+  size_t gemm_ws_bytes;
+  float* loss_dev;          // 4 floats scratch when the caller passes none
+  int* status_dev;
+  float* eps_w_last;
+  float* eps_d_last;        // copies of the noise of the last forward (needed by backward)
+  int sse_parts;
+  int lastB;
+  std::map<std::string, std::pair<const float*, int64_t>> dbg;
+};
+
+static inline float* bn_mean(ava_model* m, int l) { return m->bn_save + (l * 4 + 0) * 32; }
+static inline float* bn_invstd(ava_model* m, int l) { return m->bn_save + (l * 4 + 1) * 32; }
+static inline float* bn_scale(ava_model* m, int l) { return m->bn_save + (l * 4 + 2) * 32; }
+static inline float* bn_shift(ava_model* m, int l) { return m->bn_save + (l * 4 + 3) * 32; }
+static inline float* bn_A(ava_model* m, int l) { return m->bn_bwd + (l * 3 + 0) * 32; }
+static inline float* bn_B(ava_model* m, int l) { return m->bn_bwd + (l * 3 + 1) * 32; }
+static inline float* bn_C(ava_model* m, int l) { return m->bn_bwd + (l * 3 + 2) * 32; }
+static inline float* PP(ava_model* m, int idx) { return m->P + m->tab[idx].off; }
+static inline float* GG(ava_model* m, int idx) { return m->G + m->tab[idx].off; }
+
+struct Carver {
+  char* base;
+  size_t off;
+  float* take(size_t floats) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += (floats * sizeof(float) + 255) / 256 * 256;
+    return p;
+  }
+};
+
+static size_t max_gemm_ws(int z, int B) {
+  size_t mx = 0;
+  const int shapes[][3] = {{B, 1024, 8192}, {B, 256, 1024}, {B, 192, 256}, {B, z, 64}, {B, 64, z}, {B, 256, 64},
+                           {B, 1024, 256}, {B, 8192, 1024},
+                           // dX products
+                           {B, 8192, 1024}, {B, 1024, 256}, {B, 256, 192}, {B, 64, z}, {B, z, 64}, {B, 64, 256},
+                           {B, 256, 1024}, {B, 1024, 8192}};
+  for (auto& s : shapes) {
+    size_t b = ava_gemm_workspace_bytes(s[0], s[1], s[2]);
+    if (b > mx) mx = b;
+  }
+  return mx;
+}
+
+static size_t wgrad_part_floats(int B) {
+  size_t mx = 0;
+  for (int l = 0; l < NCONV; ++l) {
+    const ConvLayer& L = kLayers[l];
+    const int grid = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+    size_t f = (size_t)grid * (9 * L.cin * L.cout + L.cout);
+    if (f > mx) mx = f;
+  }
+  return mx;
+}
+
+static void carve(ava_model* m, void* ws, size_t* total) {
+  Carver c{reinterpret_cast<char*>(ws), 0};
+  const size_t B = (size_t)m->maxB;
+  const int z = m->z;
+  m->X[0] = nullptr;
+  for (int l = 1; l < NCONV; ++l) {
+    const ConvLayer& L = kLayers[l];
+    if (l == 7) m->X[l] = c.take(B * 8192);
+    else m->X[l] = c.take(B * L.hi * L.hi * L.cin);
+  }
+  m->y7 = c.take(B * 8192); m->y7t = c.take(B * 8192);
+  m->h1 = c.take(B * 1024); m->h2 = c.take(B * 256); m->h3 = c.take(B * 192);
+  m->mu = c.take(B * z); m->u = c.take(B * z); m->logd = c.take(B * z); m->d = c.take(B * z); m->zs = c.take(B * z);
+  m->lat_sums = c.take(B * 2);
+  m->h5 = c.take(B * 64); m->h6 = c.take(B * 256); m->h7 = c.take(B * 1024); m->f8 = c.take(B * 8192);
+  m->xrec = c.take(B * 16384); m->seed = c.take(B * 16384);
+  m->bn_part = c.take(1024 * 64);
+  m->bn_save = c.take(NCONV * 4 * 32);
+  m->bn_bwd = c.take(NCONV * 3 * 32);
+  for (int l = 0; l < NCONV; ++l) {
+    m->Gf[l] = c.take(9 * kLayers[l].cin * kLayers[l].cout);
+    m->Gb[l] = c.take(9 * kLayers[l].cin * kLayers[l].cout);
+  }
+  m->gA = c.take(B * 131072); m->gB = c.take(B * 131072);
+  m->wg_part = c.take(wgrad_part_floats((int)B));
+  m->dF8 = c.take(B * 8192); m->dh7 = c.take(B * 1024); m->dh6 = c.take(B * 256); m->dh5 = c.take(B * 64);
+  m->dz = c.take(B * z); m->dmu = c.take(B * z); m->du = c.take(B * z); m->dlogd = c.take(B * z);
+  m->dh3 = c.take(B * 192); m->dh2 = c.take(B * 256); m->dh1 = c.take(B * 1024); m->dy7 = c.take(B * 8192);
+  m->gemm_ws_bytes = max_gemm_ws(z, (int)B);
+  m->gemm_ws = c.take(m->gemm_ws_bytes / sizeof(float) + 64);
+  m->loss_dev = c.take(64);
+  m->status_dev = reinterpret_cast<int*>(c.take(64));
+  m->eps_w_last = c.take(B);
+  m->eps_d_last = c.take(B * z);
+  *total = c.off;
+}
+
+extern "C" int ava_version(void) { return 100; }
+
+extern "C" int64_t ava_arena_floats(int z_dim) {
+  ParamInfo tab[NPARAM];
+  int64_t total;
+  build_param_table(z_dim, tab, &total);
+  return total;
+}
+extern "C" int64_t ava_param_offset(int z_dim, int index, int64_t* numel) {
+  if (index < 0 || index >= NPARAM) return -1;
+  ParamInfo tab[NPARAM];
+  int64_t total;
+  build_param_table(z_dim, tab, &total);
+  if (numel) *numel = tab[index].numel;
+  return tab[index].off;
+}
+extern "C" size_t ava_workspace_bytes(int z_dim, int max_batch) {
+  ava_model tmp;
+  tmp.z = z_dim;
+  tmp.maxB = max_batch;
+  size_t total = 0;
+  carve(&tmp, nullptr, &total);
+  return total;
+}
+
+extern "C" int ava_model_create(ava_model** out, int z_dim, int max_batch, float model_precision, float* params,
+                                float* grads, float* exp_avg, float* exp_avg_sq, float* bn_running,
+                                int64_t* bn_batches, void* workspace, size_t workspace_bytes) {
+  if (out == nullptr || z_dim < 1 || z_dim > 128 || max_batch < 1 || params == nullptr || workspace == nullptr)
+    return AVA_EINVAL;
+  ava_model* m = new ava_model();
+  m->z = z_dim; m->maxB = max_batch; m->prec = model_precision;
+  m->P = params; m->G = grads; m->M = exp_avg; m->V = exp_avg_sq;
+  m->bn_running = bn_running; m->bn_batches = bn_batches;
+  build_param_table(z_dim, m->tab, &m->arena);
+  size_t need = 0;
+  carve(m, workspace, &need);
+  if (need > workspace_bytes) { delete m; return AVA_EWORKSPACE; }
+  m->lastB = 0;
+  m->sse_parts = 0;
+  const size_t B = max_batch;
+  for (int l = 1; l < NCONV; ++l) {
+    char nm[16];
+    if (l < 7) { snprintf(nm, sizeof nm, "y%d", l); }
+    else if (l == 7) { snprintf(nm, sizeof nm, "f8t"); }
+    else { snprintf(nm, sizeof nm, "d%d", l - 7); }
+    m->dbg[nm] = {m->X[l], (int64_t)(l == 7 ? B * 8192 : B * kLayers[l].hi * kLayers[l].hi * kLayers[l].cin)};
+  }
+  m->dbg["y7"] = {m->y7, (int64_t)B * 8192}; m->dbg["y7t"] = {m->y7t, (int64_t)B * 8192};
+  m->dbg["h1"] = {m->h1, (int64_t)B * 1024}; m->dbg["h2"] = {m->h2, (int64_t)B * 256};
+  m->dbg["h3"] = {m->h3, (int64_t)B * 192};
+  m->dbg["mu"] = {m->mu, (int64_t)B * z_dim}; m->dbg["u"] = {m->u, (int64_t)B * z_dim};
+  m->dbg["logd"] = {m->logd, (int64_t)B * z_dim}; m->dbg["d"] = {m->d, (int64_t)B * z_dim};
+  m->dbg["z"] = {m->zs, (int64_t)B * z_dim};
+  m->dbg["h5"] = {m->h5, (int64_t)B * 64}; m->dbg["h6"] = {m->h6, (int64_t)B * 256};
+  m->dbg["h7"] = {m->h7, (int64_t)B * 1024}; m->dbg["f8"] = {m->f8, (int64_t)B * 8192};
+  m->dbg["xrec"] = {m->xrec, (int64_t)B * 16384}; m->dbg["seed"] = {m->seed, (int64_t)B * 16384};
+  m->dbg["bn_save"] = {m->bn_save, NCONV * 4 * 32}; m->dbg["bn_bwd"] = {m->bn_bwd, NCONV * 3 * 32};
+  m->dbg["dz"] = {m->dz, (int64_t)B * z_dim}; m->dbg["dF8"] = {m->dF8, (int64_t)B * 8192};
+  m->dbg["dy7"] = {m->dy7, (int64_t)B * 8192};
+  *out = m;
+  return AVA_OK;
+}
+extern "C" void ava_model_destroy(ava_model* m) { delete m; }
+extern "C" const float* ava_last_z(ava_model* m) { return m->zs; }
+extern "C" const float* ava_last_xrec(ava_model* m) { return m->xrec; }
+extern "C" const float* ava_debug_buffer(ava_model* m, const char* name, int64_t* floats) {
+  auto it = m->dbg.find(name);
+  if (it == m->dbg.end()) return nullptr;
+  if (floats) *floats = it->second.second;
+  return it->second.first;
+}
+
+#define TRY(expr)            \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc != AVA_OK) return _rc; \
+  } while (0)
+
+// ---- all 28 weight tables in one launch ---------------------------------------------------------------
+struct PackEntry { const float* w; float* g; int c0, c1, swap, flip; };
+struct PackTable { PackEntry e[2 * NCONV]; };
+__global__ void pack_all_kernel(const PackTable tab) {
+  const PackEntry e = tab.e[blockIdx.y];
+  const int n = e.c0 * e.c1 * 9;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int tt = i % 9, r = i / 9, i1 = r % e.c1, i0 = r / e.c1;
+    const int tg = e.flip ? 8 - tt : tt;
+    const int gi = e.swap ? (tg * e.c1 + i1) * e.c0 + i0 : (tg * e.c0 + i0) * e.c1 + i1;
+    e.g[gi] = e.w[i];
+  }
+}
+static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st) {
+  PackTable tab;
+  for (int l = 0; l < NCONV; ++l) {
+    const ConvLayer& L = kLayers[l];
+    const float* w = PP(m, L.pw);
+    // stored dims: Conv2d [cout][cin][9] ; ConvTranspose2d [cin][cout][9]
+    const int c0 = L.transposed ? L.cin : L.cout, c1 = L.transposed ? L.cout : L.cin;
+    int kf, kb;
+    if (!L.transposed) { kf = 0; kb = L.mode == MODE_S1 ? 3 : 4; }
+    else { kf = L.mode == MODE_S1 ? 1 : 2; kb = L.mode == MODE_S1 ? 5 : 6; }
+    tab.e[2 * l] = {w, m->Gf[l], c0, c1, (kf == 0) ? 1 : 0, (kf == 1) ? 1 : 0};
+    tab.e[2 * l + 1] = {w, m->Gb[l], c0, c1, (kb == 5 || kb == 6) ? 1 : 0, (kb == 3) ? 1 : 0};
+  }
+  hipLaunchKernelGGL(pack_all_kernel, dim3(7, with_bwd ? 2 * NCONV : 2 * NCONV), dim3(256), 0, st, tab);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+static int finalize_bn(ava_model* m, int l, int nparts, int64_t n, int train, hipStream_t st) {
+  const ConvLayer& L = kLayers[l];
+  return ava_bn_finalize(m->bn_part, nparts, n, L.cin, PP(m, L.pg), PP(m, L.pbeta), m->bn_running + l * 32,
+                         m->bn_running + (NCONV + l) * 32, m->bn_batches + l, train, bn_mean(m, l), bn_invstd(m, l),
+                         bn_scale(m, l), bn_shift(m, l), st);
+}
+
+static int gemm(ava_model* m, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                const float* mask, float* colsum, int M, int N, int K, int ak, int bk, int act, hipStream_t st) {
+  return ava_gemm(A, lda, B, ldb, bias, C, ldc, mask, colsum, M, N, K, ak, bk, act, m->gemm_ws, m->gemm_ws_bytes, st);
+}
+
+// parameter indices of the fully connected layers
+enum { FC1 = 28, FC2 = 30, FC31 = 32, FC32 = 34, FC33 = 36, FC41 = 38, FC42 = 40, FC43 = 42, FC5 = 44, FC6 = 46,
+       FC7 = 48, FC8 = 50 };
+
+static int encoder_forward(ava_model* m, const float* x, int B, int train, float* mu, float* u, float* logd_or_d,
+                           int last_act, hipStream_t st) {
+  const int z = m->z;
+  int nparts = 0;
+  if (train) TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, st));
+  TRY(finalize_bn(m, 0, nparts, (int64_t)B * 16384, train, st));
+  for (int l = 0; l < 7; ++l) {
+    const ConvLayer& L = kLayers[l];
+    const float* in = l == 0 ? x : m->X[l];
+    float* out = l == 6 ? m->y7 : m->X[l + 1];
+    TRY(ava_conv3x3(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nullptr,
+                    nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
+                    0.f, st));
+    if (l < 6) {
+      const int np = ava_conv_grid(B, L.ho, L.ho, L.mode);
+      TRY(finalize_bn(m, l + 1, np, (int64_t)B * L.ho * L.ho, train, st));
+    }
+  }
+  TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, st));
+  TRY(gemm(m, m->y7t, 0, PP(m, FC1), 0, PP(m, FC1 + 1), m->h1, 0, nullptr, nullptr, B, 1024, 8192, 1, 1, ACT_RELU, st));
+  TRY(gemm(m, m->h1, 0, PP(m, FC2), 0, PP(m, FC2 + 1), m->h2, 0, nullptr, nullptr, B, 256, 1024, 1, 1, ACT_RELU, st));
+  // fc31|fc32|fc33 as one [192,256] layer (arena keeps the three weights, then the three biases, contiguous)
+  TRY(gemm(m, m->h2, 0, PP(m, FC31), 0, PP(m, FC31 + 1), m->h3, 0, nullptr, nullptr, B, 192, 256, 1, 1, ACT_RELU, st));
+  TRY(gemm(m, m->h3 + 0, 192, PP(m, FC41), 0, PP(m, FC41 + 1), mu, 0, nullptr, nullptr, B, z, 64, 1, 1, ACT_NONE, st));
+  TRY(gemm(m, m->h3 + 64, 192, PP(m, FC42), 0, PP(m, FC42 + 1), u, 0, nullptr, nullptr, B, z, 64, 1, 1, ACT_NONE, st));
+  TRY(gemm(m, m->h3 + 128, 192, PP(m, FC43), 0, PP(m, FC43 + 1), logd_or_d, 0, nullptr, nullptr, B, z, 64, 1, 1,
+           last_act, st));
+  return AVA_OK;
+}
+
+static int decoder_forward(ava_model* m, const float* zin, const float* x_target, int B, int train, float* xrec,
+                           hipStream_t st) {
+  const int z = m->z;
+  TRY(gemm(m, zin, 0, PP(m, FC5), 0, PP(m, FC5 + 1), m->h5, 0, nullptr, nullptr, B, 64, z, 1, 1, ACT_RELU, st));
+  TRY(gemm(m, m->h5, 0, PP(m, FC6), 0, PP(m, FC6 + 1), m->h6, 0, nullptr, nullptr, B, 256, 64, 1, 1, ACT_RELU, st));
+  TRY(gemm(m, m->h6, 0, PP(m, FC7), 0, PP(m, FC7 + 1), m->h7, 0, nullptr, nullptr, B, 1024, 256, 1, 1, ACT_RELU, st));
+  TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, 8192, 1024, 1, 1, ACT_RELU, st));
+  int nparts = 0;
+  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, &nparts, st));
+  TRY(finalize_bn(m, 7, nparts, (int64_t)B * 256, train, st));
+  for (int l = 7; l < NCONV; ++l) {
+    const ConvLayer& L = kLayers[l];
+    const bool last = l == NCONV - 1;
+    float* out = last ? xrec : m->X[l + 1];
+    TRY(ava_conv3x3(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
+                    last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi,
+                    L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, st));
+    const int np = ava_conv_grid(B, L.ho, L.ho, L.mode);
+    if (!last) TRY(finalize_bn(m, l + 1, np, (int64_t)B * L.ho * L.ho, train, st));
+    else m->sse_parts = np;
+  }
+  return AVA_OK;
+}
+
+extern "C" int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d, int bn_train,
+                           float* loss_out, int* status_out, ava_stream_t s) {
+  if (m == nullptr || x == nullptr || eps_w == nullptr || eps_d == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
+  hipStream_t st = to_stream(s);
+  const int z = m->z;
+  TRY(pack_weights(m, true, st));
+  TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st));
+  if (status_out != nullptr) { if (hipMemsetAsync(status_out, 0, sizeof(int), st) != hipSuccess) return AVA_ELAUNCH; }
+  TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
+  if (eps_w != m->eps_w_last) {
+    if (hipMemcpyAsync(m->eps_w_last, eps_w, sizeof(float) * B, hipMemcpyDeviceToDevice, st) != hipSuccess) return AVA_ELAUNCH;
+    if (hipMemcpyAsync(m->eps_d_last, eps_d, sizeof(float) * B * z, hipMemcpyDeviceToDevice, st) != hipSuccess) return AVA_ELAUNCH;
+  }
+  TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st));
+  TRY(ava_elbo_finalize_strided(m->lat_sums, B, m->bn_part, m->sse_parts, 2, z, m->prec,
+                                loss_out != nullptr ? loss_out : m->loss_dev, st));
+  m->lastB = B;
+  return AVA_OK;
+}
+
+extern "C" int ava_encode(ava_model* m, const float* x, int B, int bn_train, float* mu, float* u, float* d,
+                          ava_stream_t s) {
+  if (m == nullptr || x == nullptr || mu == nullptr || u == nullptr || d == nullptr || B < 1 || B > m->maxB)
+    return AVA_EINVAL;
+  hipStream_t st = to_stream(s);
+  TRY(pack_weights(m, false, st));
+  return encoder_forward(m, x, B, bn_train, mu, u, d, ACT_EXP, st);
+}
+
+extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, float* x_rec, ava_stream_t s) {
+  if (m == nullptr || z == nullptr || x_rec == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
+  hipStream_t st = to_stream(s);
+  TRY(pack_weights(m, false, st));
+  return decoder_forward(m, z, nullptr, B, bn_train, x_rec, st);
+}
+
+// ---- all 14 weight-gradient reductions are issued per layer (partials buffer is shared) --------------
+static int conv_layer_backward(ava_model* m, int l, const float* x0, const float* gin, const float* gin2,
+                               const float* ca, const float* cb, const float* cc, int pro, float* gout, int B,
+                               hipStream_t st) {
+  const ConvLayer& L = kLayers[l];
+  const float* X = l == 0 ? x0 : m->X[l];
+  // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
+  TRY(ava_conv3x3_wgrad(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part, B, L.hi, L.hi, L.cin,
+                        L.cout, L.mode, pro, st));
+  const int wparts = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+  const int kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
+  TRY(ava_conv_wgrad_reduce(m->wg_part, wparts, GG(m, L.pw), GG(m, L.pb), L.cin, L.cout, kind, st));
+  // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
+  const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
+  TRY(ava_conv3x3(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
+                  m->bn_part, B, L.ho, L.ho, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f, st));
+  const int np = ava_conv_grid(B, L.hi, L.hi, bmode);
+  TRY(ava_bn_finalize_bwd(m->bn_part, np, (int64_t)B * L.hi * L.hi, L.cin, PP(m, L.pg), bn_mean(m, l),
+                          bn_invstd(m, l), GG(m, L.pg), GG(m, L.pbeta), bn_A(m, l), bn_B(m, l), bn_C(m, l), st));
+  return AVA_OK;
+}
+
+extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s) {
+  if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr) return AVA_EINVAL;
+  hipStream_t st = to_stream(s);
+  const int z = m->z;
+  // ---- decoder convolutions, last to first ----
+  float* gcur = m->gA;
+  float* gnext = m->gB;
+  TRY(conv_layer_backward(m, 13, x, m->seed, nullptr, nullptr, nullptr, nullptr, PRO_ID, gcur, B, st));
+  for (int l = 12; l >= 7; --l) {
+    // dU_l = (X_{l+1} > 0) ? A*g + Bc*X_{l+1} + Cc : 0 with the coefficients of BatchNorm l+1
+    TRY(conv_layer_backward(m, l, x, gcur, m->X[l + 1], bn_A(m, l + 1), bn_B(m, l + 1), bn_C(m, l + 1), PRO_BWD, gnext,
+                            B, st));
+    float* t = gcur; gcur = gnext; gnext = t;
+  }
+  // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
+  TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, st));
+  // ---- decoder fully connected: dW = dY^T X (+ db), dX = (dY W) masked by the producer's ReLU ----
+  TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), 8192, 1024, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dF8, 0, PP(m, FC8), 0, nullptr, m->dh7, 0, m->h7, nullptr, B, 1024, 8192, 1, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh7, 0, m->h6, 0, nullptr, GG(m, FC7), 0, nullptr, GG(m, FC7 + 1), 1024, 256, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh7, 0, PP(m, FC7), 0, nullptr, m->dh6, 0, m->h6, nullptr, B, 256, 1024, 1, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh6, 0, m->h5, 0, nullptr, GG(m, FC6), 0, nullptr, GG(m, FC6 + 1), 256, 64, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh6, 0, PP(m, FC6), 0, nullptr, m->dh5, 0, m->h5, nullptr, B, 64, 256, 1, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh5, 0, m->zs, 0, nullptr, GG(m, FC5), 0, nullptr, GG(m, FC5 + 1), 64, z, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh5, 0, PP(m, FC5), 0, nullptr, m->dz, 0, nullptr, nullptr, B, z, 64, 1, 0, ACT_NONE, st));
+  // ---- latent block ----
+  TRY(ava_latent_bwd(m->zs, m->dz, m->u, m->d, m->eps_w_last, m->eps_d_last, m->dmu, m->du, m->dlogd, B, z, st));
+  // ---- heads: fc41/42/43 (64 -> z) on the three 64-wide slices of h3 ----
+  const float* dheads[3] = {m->dmu, m->du, m->dlogd};
+  const int fc4[3] = {FC41, FC42, FC43};
+  for (int i = 0; i < 3; ++i) {
+    TRY(gemm(m, dheads[i], 0, m->h3 + 64 * i, 192, nullptr, GG(m, fc4[i]), 0, nullptr, GG(m, fc4[i] + 1), z, 64, B, 0,
+             0, ACT_NONE, st));
+    TRY(gemm(m, dheads[i], 0, PP(m, fc4[i]), 0, nullptr, m->dh3 + 64 * i, 192, m->h3 + 64 * i, nullptr, B, 64, z, 1, 0,
+             ACT_NONE, st));
+  }
+  TRY(gemm(m, m->dh3, 0, m->h2, 0, nullptr, GG(m, FC31), 0, nullptr, GG(m, FC31 + 1), 192, 256, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh3, 0, PP(m, FC31), 0, nullptr, m->dh2, 0, m->h2, nullptr, B, 256, 192, 1, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh2, 0, m->h1, 0, nullptr, GG(m, FC2), 0, nullptr, GG(m, FC2 + 1), 256, 1024, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh2, 0, PP(m, FC2), 0, nullptr, m->dh1, 0, m->h1, nullptr, B, 1024, 256, 1, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh1, 0, m->y7t, 0, nullptr, GG(m, FC1), 0, nullptr, GG(m, FC1 + 1), 1024, 8192, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, nullptr, nullptr, B, 8192, 1024, 1, 0, ACT_NONE, st));
+  // ---- encoder convolutions ----
+  gcur = m->gA; gnext = m->gB;
+  TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, st));             // dU_7 (ReLU of conv7)
+  TRY(conv_layer_backward(m, 6, x, gcur, nullptr, nullptr, nullptr, nullptr, PRO_ID, gnext, B, st));
+  { float* t = gcur; gcur = gnext; gnext = t; }
+  for (int l = 5; l >= 0; --l) {
+    TRY(conv_layer_backward(m, l, x, gcur, m->X[l + 1], bn_A(m, l + 1), bn_B(m, l + 1), bn_C(m, l + 1), PRO_BWD,
+                            l == 0 ? nullptr : gnext, B, st));
+    float* t = gcur; gcur = gnext; gnext = t;
+  }
+  return AVA_OK;
+}
+
+extern "C" int ava_adam_step(ava_model* m, float lr, float beta1, float beta2, float eps, int step, ava_stream_t s) {
+  if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr) return AVA_EINVAL;
+  return ava_adam_flat(m->P, m->G, m->M, m->V, m->arena, lr, beta1, beta2, eps, step, s);
+}

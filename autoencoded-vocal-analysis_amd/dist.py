@@ -1,0 +1,70 @@
+"""Data-parallel glue: one process per GPU, gradient SUM all-reduce over RCCL/xGMI.
+
+The reference is single-device (``ava/models/vae.py:112-115``); pure data parallelism is
+this build's extension.  Samples are independent except for the
+BatchNorm batch statistics (kept per rank) and the parameter update, so the only exchange
+per step is ONE all-reduce of the flat fp32 gradient arena (69.7 MB at z=32).  It is a SUM,
+not a mean, because the reference loss is a sum over the batch (vae.py:316-323).
+
+Nothing here is needed (or touched) when torch.distributed is not initialised.
+"""
+import math
+
+import torch
+import torch.distributed as td
+
+from .layout import X_DIM
+
+
+def active():
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def rank():
+    return td.get_rank() if (td.is_available() and td.is_initialized()) else 0
+
+
+def world_size():
+    return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
+
+
+def allreduce_gradients(flat_grads):
+    """In-place SUM over ranks of the flat gradient arena (backend 'nccl' is RCCL on ROCm)."""
+    if active():
+        td.all_reduce(flat_grads, op=td.ReduceOp.SUM)
+    return flat_grads
+
+
+def broadcast_parameters(model, src=0):
+    """Identical weights / BatchNorm buffers / Adam state on every rank."""
+    if active():
+        for t in (model._params, model._exp_avg, model._exp_avg_sq, model._bn_running, model._bn_batches):
+            td.broadcast(t, src=src)
+
+
+def per_call_constants(z_dim, model_precision):
+    """The two constants the reference adds once per forward call (vae.py:316,318)."""
+    return 0.5 * z_dim * math.log(2 * math.pi) + 0.5 * X_DIM * math.log(2 * math.pi / model_precision)
+
+
+def global_loss(local_sum, z_dim, model_precision, num_batches):
+    """Loss of the global batch from per-rank sums: every rank's forward added the per-call
+    constants once per batch, a single-process run adds them once per *global* batch:
+    ``L = sum_r L_r - (N-1) * num_batches * (c1 + c2)``."""
+    if not active():
+        return float(local_sum.item())
+    t = local_sum.detach().clone().double().reshape(1)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    n = world_size()
+    return float(t.item()) - (n - 1) * num_batches * per_call_constants(z_dim, model_precision)
+
+
+def global_dataset_len(local_len):
+    """len(loader.dataset) summed over ranks (each rank iterates its own shard)."""
+    if not active():
+        return local_len
+    t = torch.tensor([float(local_len)], dtype=torch.float64)
+    if td.get_backend() == "nccl":
+        t = t.cuda()
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return int(round(float(t.item())))

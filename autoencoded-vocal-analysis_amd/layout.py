@@ -78,16 +78,22 @@ def param_specs(z_dim):
 def arena_offsets(z_dim, align=64):
     """Offsets (in floats) of every parameter inside the flat fp32 arena.
 
-    The arena keeps ``named_parameters()`` order; every tensor starts on a
-    256-byte boundary (``align`` floats) so that float4 loads are always
-    aligned.  The same offsets index the gradient, exp_avg and exp_avg_sq
-    arenas.  Returns (OrderedDict name -> offset, total_floats)."""
-    offs = OrderedDict()
+    Mirror of ``build_param_table`` in ``csrc/model.hip`` (the native library is the source
+    of truth; ``tests/test_layout.py`` checks the two agree).  The arena keeps
+    ``named_parameters()`` order except that the three 256->64 head layers are grouped as
+    ``fc31.w fc32.w fc33.w | fc31.b fc32.b fc33.b`` so they form one [192,256] matrix and one
+    [192] bias.  Every tensor starts on a 256-byte boundary (``align`` floats); the same
+    offsets index the gradient, exp_avg and exp_avg_sq arenas.
+    Returns (OrderedDict name -> offset, total_floats)."""
+    specs = param_specs(z_dim)
+    order = list(range(32)) + [32, 34, 36, 33, 35, 37] + list(range(38, len(specs)))
+    offs = {}
     cur = 0
-    for s in param_specs(z_dim):
+    for i in order:
+        s = specs[i]
         offs[s.name] = cur
         cur += (s.numel + align - 1) // align * align
-    return offs, cur
+    return OrderedDict((s.name, offs[s.name]) for s in specs), cur
 
 
 def num_params(z_dim):

@@ -1,0 +1,89 @@
+"""Adam over the flat parameter arena, with torch.optim.Adam's state-dict layout.
+
+Replaces ``torch.optim.Adam(self.parameters(), lr)`` of the reference
+(``ava/models/vae.py:119``; update rule ``torch/optim/adam.py:414-547``, defaults
+betas=(0.9,0.999), eps=1e-8, no weight decay / amsgrad).  One HIP kernel updates
+all 80 tensors (``ava_adam_flat``).  ``state_dict()`` / ``load_state_dict()`` are
+torch's own, so checkpoints carry ``{'state': {i: {'step','exp_avg','exp_avg_sq'}},
+'param_groups': [...]}`` with i = 0..79 in ``named_parameters()`` order
+ and load into the reference unchanged.
+"""
+import torch
+
+from . import _lib
+
+
+class FlatAdam(torch.optim.Adam):
+    def __init__(self, model, lr=1e-3):
+        super().__init__(list(model.parameters()), lr=lr)
+        self._step_count_flat = 0
+        self.rebind(model)
+
+    def rebind(self, model):
+        """(Re)attach to the model's arenas (after construction or a device move)."""
+        self._model = model
+        names = [n for n, _ in model.named_parameters()]
+        self.param_groups[0]['params'] = [p for _, p in model.named_parameters()]
+        self._names = names
+        if self._step_count_flat > 0:
+            self._materialise_state()
+
+    def _views(self, name):
+        o, n, shape = self._model._arena_views[name]
+        return self._model._exp_avg[o:o + n].view(shape), self._model._exp_avg_sq[o:o + n].view(shape)
+
+    def _materialise_state(self):
+        """Expose exp_avg / exp_avg_sq / step per parameter exactly like torch's Adam does
+        (views into the flat arenas; ``step`` is a float32 scalar tensor)."""
+        self.state.clear()
+        for name, p in zip(self._names, self.param_groups[0]['params']):
+            m, v = self._views(name)
+            self.state[p] = {'step': torch.tensor(float(self._step_count_flat), dtype=torch.float32),
+                             'exp_avg': m, 'exp_avg_sq': v}
+
+    def zero_grad(self, set_to_none=True):
+        """The HIP backward overwrites the whole gradient arena every step (the reference
+        resets grads to None before each step, vae.py:348), so there is nothing to clear."""
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        if g['weight_decay'] != 0 or g['amsgrad'] or g['maximize']:
+            raise NotImplementedError("FlatAdam implements the reference's plain Adam only")
+        m = self._model
+        self._step_count_flat += 1
+        b1, b2 = g['betas']
+        lib = _lib.load()
+        rc = lib.ava_adam_flat(m._params.data_ptr(), m._grads.data_ptr(), m._exp_avg.data_ptr(),
+                               m._exp_avg_sq.data_ptr(), m._params.numel(), float(g['lr']), float(b1), float(b2),
+                               float(g['eps']), self._step_count_flat, _lib.stream())
+        _lib.check(rc, "ava_adam_flat")
+        return None
+
+    def state_dict(self):
+        if self._step_count_flat > 0:
+            self._materialise_state()
+        sd = super().state_dict()
+        # detach from the arenas so that a saved checkpoint is a plain snapshot
+        for st in sd['state'].values():
+            st['exp_avg'] = st['exp_avg'].detach().clone()
+            st['exp_avg_sq'] = st['exp_avg_sq'].detach().clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = [float(st['step']) for st in self.state.values() if 'step' in st]
+        self._step_count_flat = int(round(max(steps))) if steps else 0
+        if self._step_count_flat > 0:
+            for name, p in zip(self._names, self.param_groups[0]['params']):
+                st = self.state.get(p)
+                if st is None:
+                    continue
+                m, v = self._views(name)
+                m.copy_(st['exp_avg'])
+                v.copy_(st['exp_avg_sq'])
+            self._materialise_state()
+        else:
+            self._model._exp_avg.zero_()
+            self._model._exp_avg_sq.zero_()

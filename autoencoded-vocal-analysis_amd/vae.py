@@ -1,0 +1,450 @@
+"""MI355X-native drop-in for ``ava.models.vae`` (reference: ``ava/models/vae.py``).
+
+Same class surface (``VAE(save_dir, lr, z_dim, model_precision, device_name)``,
+``encode/decode/forward``, ``train_epoch/test_epoch/train_loop``,
+``save_state/load_state``, ``visualize``, ``get_latent``; constants ``X_SHAPE``,
+``X_DIM``) and the same checkpoint dict, but every arithmetic op of the training
+step runs in hand-written HIP kernels (``csrc/``) reached through the C ABI of
+``libava_hip.so``.  PyTorch is used for device memory, streams, serialisation and
+``torch.distributed`` only.  There is no CPU compute path: on a machine without
+the GPU library/GPU the model can be constructed, saved and loaded, but any
+forward raises.
+
+Memory model: all 80 parameters are views into ONE flat fp32 arena on the
+device (offsets from ``ava_param_offset``); three more arenas of the same shape
+hold the gradient and Adam's exp_avg / exp_avg_sq, so that Adam and the
+data-parallel gradient all-reduce are single flat operations.  The 40 layer
+attributes (``conv1`` ... ``bn14``) are stock ``torch.nn`` modules used purely
+as parameter containers so that ``state_dict()`` keys/shapes are the
+reference's.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import dist as _dist
+from .layout import X_SHAPE, X_DIM, param_specs, checkpoint_layer_order
+from .optim import FlatAdam
+
+__all__ = ["VAE", "X_SHAPE", "X_DIM"]
+
+X_DIM = int(np.prod(X_SHAPE))
+
+_BN_CH = [1, 8, 8, 16, 16, 24, 24, 32, 24, 24, 16, 16, 8, 8]
+
+
+class _ElboFn(torch.autograd.Function):
+    """Makes ``loss = model(x); loss.backward()`` work: forward ran the HIP forward,
+    backward runs the HIP backward into the gradient arena (vae.py:350-352)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x):
+        ctx.model = model
+        ctx.x = x
+        return model._forward_device(x, need_grad=True).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._backward_device(ctx.x)
+        # the reference's loss is the root of the graph (grad_out == 1); honour other scalings
+        ctx.model._grads.mul_(grad_out)
+        ctx.model._attach_grads()
+        return None, None, None
+
+
+class VAE(nn.Module):
+    """Variational Autoencoder for 128x128 single-channel spectrograms
+    (reference: ``ava/models/vae.py:40-122``)."""
+
+    def __init__(self, save_dir='', lr=1e-3, z_dim=32, model_precision=10.0, device_name="auto"):
+        super(VAE, self).__init__()
+        self.save_dir = save_dir
+        self.lr = lr
+        self.z_dim = z_dim
+        self.model_precision = model_precision
+        assert device_name != "cuda" or torch.cuda.is_available()          # vae.py:112
+        if device_name == "auto":
+            device_name = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device_name)
+        if self.save_dir != '' and not os.path.exists(self.save_dir):
+            os.makedirs(self.save_dir)
+        self._build_network()
+        self._flatten_parameters()
+        self.optimizer = FlatAdam(self, lr=self.lr)
+        self.epoch = 0
+        self.loss = {'train': {}, 'test': {}}
+        # noise for rsample: None -> device counter RNG; or callable(B, z_dim) -> (eps_W [B,1], eps_D [B,z])
+        self.noise_source = None
+        self._rng_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        self._rng_offset = 0
+        self._handle = None
+        self._max_batch = 0
+        self._workspace = None
+        self._last_x = None
+
+    # ------------------------------------------------------------------ network definition
+    def _build_network(self):
+        """Same modules, same registration order as the reference (vae.py:125-168); they only
+        hold parameters/buffers -- their forward() is never called."""
+        self.conv1 = nn.Conv2d(1, 8, 3, 1, padding=1)
+        self.conv2 = nn.Conv2d(8, 8, 3, 2, padding=1)
+        self.conv3 = nn.Conv2d(8, 16, 3, 1, padding=1)
+        self.conv4 = nn.Conv2d(16, 16, 3, 2, padding=1)
+        self.conv5 = nn.Conv2d(16, 24, 3, 1, padding=1)
+        self.conv6 = nn.Conv2d(24, 24, 3, 2, padding=1)
+        self.conv7 = nn.Conv2d(24, 32, 3, 1, padding=1)
+        self.bn1 = nn.BatchNorm2d(1)
+        self.bn2 = nn.BatchNorm2d(8)
+        self.bn3 = nn.BatchNorm2d(8)
+        self.bn4 = nn.BatchNorm2d(16)
+        self.bn5 = nn.BatchNorm2d(16)
+        self.bn6 = nn.BatchNorm2d(24)
+        self.bn7 = nn.BatchNorm2d(24)
+        self.fc1 = nn.Linear(8192, 1024)
+        self.fc2 = nn.Linear(1024, 256)
+        self.fc31 = nn.Linear(256, 64)
+        self.fc32 = nn.Linear(256, 64)
+        self.fc33 = nn.Linear(256, 64)
+        self.fc41 = nn.Linear(64, self.z_dim)
+        self.fc42 = nn.Linear(64, self.z_dim)
+        self.fc43 = nn.Linear(64, self.z_dim)
+        self.fc5 = nn.Linear(self.z_dim, 64)
+        self.fc6 = nn.Linear(64, 256)
+        self.fc7 = nn.Linear(256, 1024)
+        self.fc8 = nn.Linear(1024, 8192)
+        self.convt1 = nn.ConvTranspose2d(32, 24, 3, 1, padding=1)
+        self.convt2 = nn.ConvTranspose2d(24, 24, 3, 2, padding=1, output_padding=1)
+        self.convt3 = nn.ConvTranspose2d(24, 16, 3, 1, padding=1)
+        self.convt4 = nn.ConvTranspose2d(16, 16, 3, 2, padding=1, output_padding=1)
+        self.convt5 = nn.ConvTranspose2d(16, 8, 3, 1, padding=1)
+        self.convt6 = nn.ConvTranspose2d(8, 8, 3, 2, padding=1, output_padding=1)
+        self.convt7 = nn.ConvTranspose2d(8, 1, 3, 1, padding=1)
+        self.bn8 = nn.BatchNorm2d(32)
+        self.bn9 = nn.BatchNorm2d(24)
+        self.bn10 = nn.BatchNorm2d(24)
+        self.bn11 = nn.BatchNorm2d(16)
+        self.bn12 = nn.BatchNorm2d(16)
+        self.bn13 = nn.BatchNorm2d(8)
+        self.bn14 = nn.BatchNorm2d(8)
+
+    def _get_layers(self):
+        """name -> layer, in the reference's checkpoint key order (vae.py:171-186)."""
+        return {name: getattr(self, name) for name in checkpoint_layer_order()}
+
+    # ------------------------------------------------------------------ flat arenas
+    def _arena_layout(self):
+        """(offsets by parameter name, total floats).  The native library is the source of truth;
+        ``layout.arena_offsets`` mirrors it (tests/test_layout.py) for machines without it."""
+        specs = param_specs(self.z_dim)
+        try:
+            lib = _lib.load()
+            offs = {s.name: int(lib.ava_param_offset(self.z_dim, s.index, None)) for s in specs}
+            total = int(lib.ava_arena_floats(self.z_dim))
+        except (_lib.AvaHipError, OSError):
+            from .layout import arena_offsets
+            offs, total = arena_offsets(self.z_dim)
+        return specs, offs, total
+
+    def _flatten_parameters(self):
+        """Move every parameter / BatchNorm buffer into the flat device arenas and re-point the
+        container modules at views of them."""
+        specs, offs, total = self._arena_layout()
+        dev = self.device
+        old = dict(self.named_parameters())
+        self._params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._arena_views = {}
+        for s in specs:
+            o = offs[s.name]
+            view = self._params[o:o + s.numel].view(s.shape)
+            view.copy_(old[s.name].detach().to(dev))
+            p = nn.Parameter(view)
+            setattr(getattr(self, s.layer), s.kind, p)
+            self._arena_views[s.name] = (o, s.numel, s.shape)
+        self._bn_running = torch.zeros(2, 14, 32, dtype=torch.float32, device=dev)
+        self._bn_running[1].fill_(1.0)
+        self._bn_batches = torch.zeros(14, dtype=torch.int64, device=dev)
+        for l, c in enumerate(_BN_CH):
+            bn = getattr(self, "bn%d" % (l + 1))
+            self._bn_running[0, l, :c].copy_(bn.running_mean.detach().to(dev))
+            self._bn_running[1, l, :c].copy_(bn.running_var.detach().to(dev))
+            self._bn_batches[l].copy_(bn.num_batches_tracked.detach().to(dev))
+            bn.running_mean = self._bn_running[0, l, :c]
+            bn.running_var = self._bn_running[1, l, :c]
+            bn.num_batches_tracked = self._bn_batches[l]
+        self._attach_grads()
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        self._loss_buf = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._loss_acc = torch.zeros((), dtype=torch.float64, device=dev)
+        self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def _grad_view(self, name):
+        o, n, shape = self._arena_views[name]
+        return self._grads[o:o + n].view(shape)
+
+    def _attach_grads(self):
+        for name, p in self.named_parameters():
+            p.grad = self._grad_view(name)
+
+    def _linked(self):
+        p = self.conv1.weight
+        return p.device == self._params.device and p.data_ptr() == self._params.data_ptr() + 4 * self._arena_views["conv1.weight"][0]
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to()/.cuda()/.float() re-create parameters; fold them back into fresh arenas afterwards
+        out = super(VAE, self)._apply(fn, *args, **kwargs)
+        if hasattr(self, "_params") and not self._linked():
+            self.device = self.conv1.weight.device
+            m, v = self._exp_avg, self._exp_avg_sq
+            self._destroy_handle()
+            self._flatten_parameters()
+            self._exp_avg.copy_(m.to(self.device))
+            self._exp_avg_sq.copy_(v.to(self.device))
+            if hasattr(self, "optimizer"):
+                self.optimizer.rebind(self)
+        return out
+
+    # ------------------------------------------------------------------ native model handle
+    def _destroy_handle(self):
+        if getattr(self, "_handle", None):
+            _lib.load().ava_model_destroy(self._handle)
+        self._handle = None
+        self._max_batch = 0
+        self._workspace = None
+
+    def __del__(self):
+        try:
+            self._destroy_handle()
+        except Exception:
+            pass
+
+    def _ensure(self, batch):
+        """(Re)create the native model with a workspace large enough for ``batch`` samples."""
+        if self.device.type != "cuda":
+            raise _lib.AvaHipError("the VAE hot path only runs on an MI355X (device %s): there is no CPU "
+                                   "fallback in this package" % self.device)
+        if self._handle is not None and batch <= self._max_batch:
+            return
+        lib = _lib.load()
+        self._destroy_handle()
+        cap = max(batch, 8)
+        nbytes = lib.ava_workspace_bytes(self.z_dim, cap)
+        self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        h = ctypes.c_void_p()
+        rc = lib.ava_model_create(ctypes.byref(h), self.z_dim, cap, float(self.model_precision),
+                                  self._params.data_ptr(), self._grads.data_ptr(), self._exp_avg.data_ptr(),
+                                  self._exp_avg_sq.data_ptr(), self._bn_running.data_ptr(),
+                                  self._bn_batches.data_ptr(), self._workspace.data_ptr(), nbytes)
+        _lib.check(rc, "ava_model_create")
+        self._handle = h
+        self._max_batch = cap
+        self._eps = torch.empty(cap * (self.z_dim + 1), dtype=torch.float32, device=self.device)
+
+    def _prep_x(self, x):
+        x = x.to(device=self.device, dtype=torch.float32)
+        assert x.dim() == 3 and tuple(x.shape[1:]) == X_SHAPE, "expected [batch,128,128] spectrograms"
+        return x.contiguous()
+
+    def _noise(self, B):
+        """eps_W [B] and eps_D [B,z] on the device (reference draw order: eps_W first)."""
+        if self.noise_source is not None:
+            ew, ed = self.noise_source(B, self.z_dim)
+            ew = torch.as_tensor(ew, dtype=torch.float32).reshape(B).to(self.device).contiguous()
+            ed = torch.as_tensor(ed, dtype=torch.float32).reshape(B, self.z_dim).to(self.device).contiguous()
+            return ew, ed
+        n = B * (self.z_dim + 1)
+        _lib.check(_lib.load().ava_fill_normal(self._eps.data_ptr(), n, self._rng_seed, self._rng_offset,
+                                               _lib.stream()), "ava_fill_normal")
+        self._rng_offset += n
+        return self._eps[:B], self._eps[B:n].view(B, self.z_dim)
+
+    # ------------------------------------------------------------------ device-side step pieces
+    def _forward_device(self, x, need_grad):
+        """Runs ava_forward; returns the 0-dim loss view (device).  BatchNorm mode follows
+        ``self.training`` exactly like nn.BatchNorm2d does in the reference."""
+        B = x.shape[0]
+        self._ensure(B)
+        ew, ed = self._noise(B)
+        rc = _lib.load().ava_forward(self._handle, x.data_ptr(), B, ew.data_ptr(), ed.data_ptr(),
+                                     1 if self.training else 0, self._loss_buf.data_ptr(),
+                                     self._status.data_ptr(), _lib.stream())
+        _lib.check(rc, "ava_forward")
+        self._last_x = x
+        self._last_noise = (ew, ed)
+        return self._loss_buf[0]
+
+    def _backward_device(self, x):
+        rc = _lib.load().ava_backward(self._handle, x.data_ptr(), x.shape[0], _lib.stream())
+        _lib.check(rc, "ava_backward")
+        _dist.allreduce_gradients(self._grads)
+
+    def _check_status(self):
+        if int(self._status.item()) != 0:
+            # LowRankMultivariateNormal's argument validation (vae.py:312) raises the same type
+            raise ValueError("Expected parameter cov_diag to be positive (d = exp(.) under/overflowed)")
+
+    def _workspace_tensor(self, name, shape):
+        n = ctypes.c_int64()
+        p = _lib.load().ava_debug_buffer(self._handle, name.encode(), ctypes.byref(n))
+        if not p:
+            raise KeyError(name)
+        off = p - self._workspace.data_ptr()
+        numel = int(np.prod(shape))
+        return self._workspace[off:off + 4 * numel].view(torch.float32).view(shape)
+
+    # ------------------------------------------------------------------ reference API
+    def encode(self, x):
+        """q(z|x): returns ``mu [B,z], u [B,z,1], d [B,z]`` (vae.py:189-233)."""
+        x = self._prep_x(x)
+        B = x.shape[0]
+        self._ensure(B)
+        mu = torch.empty(B, self.z_dim, device=self.device)
+        u = torch.empty(B, self.z_dim, device=self.device)
+        d = torch.empty(B, self.z_dim, device=self.device)
+        rc = _lib.load().ava_encode(self._handle, x.data_ptr(), B, 1 if self.training else 0, mu.data_ptr(),
+                                    u.data_ptr(), d.data_ptr(), _lib.stream())
+        _lib.check(rc, "ava_encode")
+        return mu, u.unsqueeze(-1), d
+
+    def decode(self, z):
+        """p(x|z) mean: ``[B,z] -> [B,16384]`` (vae.py:236-270)."""
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        B = z.shape[0]
+        self._ensure(B)
+        out = torch.empty(B, X_DIM, device=self.device)
+        rc = _lib.load().ava_decode(self._handle, z.data_ptr(), B, 1 if self.training else 0, out.data_ptr(),
+                                    _lib.stream())
+        _lib.check(rc, "ava_decode")
+        return out
+
+    def forward(self, x, return_latent_rec=False):
+        """-ELBO summed over the batch (vae.py:273-327).  The returned tensor supports
+        ``.backward()`` (fills ``param.grad`` from the HIP backward) and ``.item()``."""
+        x = self._prep_x(x)
+        if torch.is_grad_enabled():
+            loss = _ElboFn.apply(self._anchor, self, x)
+        else:
+            loss = self._forward_device(x, need_grad=False).clone()
+        self._check_status()
+        if return_latent_rec:
+            B = x.shape[0]
+            z = self._workspace_tensor("z", (B, self.z_dim)).detach().cpu().numpy()
+            rec = self._workspace_tensor("xrec", (B, X_SHAPE[0], X_SHAPE[1])).detach().cpu().numpy()
+            return loss, z, rec
+        return loss
+
+    def train_epoch(self, train_loader):
+        """One epoch of Adam steps; returns the mean -ELBO per sample (vae.py:330-358).
+
+        Same per-batch sequence as the reference (zero_grad, H2D, forward, backward, step) with
+        the loss accumulated on the device and read back once per epoch instead of ``.item()``
+        every step."""
+        self.train()
+        self._loss_acc.zero_()
+        batch_idx = -1
+        for batch_idx, data in enumerate(train_loader):
+            self.optimizer.zero_grad()
+            data = self._prep_x(data)
+            loss = self._forward_device(data, need_grad=True)
+            self._loss_acc += loss
+            self._backward_device(data)
+            self.optimizer.step()
+        self._check_status()
+        train_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, batch_idx + 1)
+        train_loss /= _dist.global_dataset_len(len(train_loader.dataset))
+        print('Epoch: {} Average loss: {:.4f}'.format(self.epoch, train_loss))
+        self.epoch += 1
+        return train_loss
+
+    def test_epoch(self, test_loader):
+        """Mean -ELBO per sample with BatchNorm on running statistics (vae.py:361-385)."""
+        self.eval()
+        self._loss_acc.zero_()
+        with torch.no_grad():
+            for i, data in enumerate(test_loader):
+                data = self._prep_x(data)
+                self._loss_acc += self._forward_device(data, need_grad=False)
+        self._check_status()
+        test_loss = float(self._loss_acc.item()) / len(test_loader.dataset)
+        print('Test loss: {:.4f}'.format(test_loss))
+        return test_loss
+
+    def train_loop(self, loaders, epochs=100, test_freq=2, save_freq=10, vis_freq=1):
+        """Epoch scheduler (vae.py:388-430)."""
+        print("=" * 40)
+        print("Training: epochs", self.epoch, "to", self.epoch + epochs - 1)
+        print("Training set:", len(loaders['train'].dataset))
+        print("Test set:", len(loaders['test'].dataset))
+        print("=" * 40)
+        for epoch in range(self.epoch, self.epoch + epochs):
+            loss = self.train_epoch(loaders['train'])
+            self.loss['train'][epoch] = loss
+            if (test_freq is not None) and (epoch % test_freq == 0):
+                loss = self.test_epoch(loaders['test'])
+                self.loss['test'][epoch] = loss
+            if (save_freq is not None) and (epoch % save_freq == 0) and (epoch > 0):
+                filename = "checkpoint_" + str(epoch).zfill(3) + '.tar'
+                if _dist.rank() == 0:
+                    self.save_state(filename)
+            if (vis_freq is not None) and (epoch % vis_freq == 0):
+                self.visualize(loaders['test'])
+
+    def save_state(self, filename):
+        """Checkpoint with the reference's dict layout (vae.py:433-446)."""
+        layers = self._get_layers()
+        state = {}
+        for layer_name in layers:
+            state[layer_name] = {k: v.detach().clone() for k, v in layers[layer_name].state_dict().items()}
+        state['optimizer_state'] = self.optimizer.state_dict()
+        state['loss'] = self.loss
+        state['z_dim'] = self.z_dim
+        state['epoch'] = self.epoch
+        state['lr'] = self.lr
+        state['save_dir'] = self.save_dir
+        filename = os.path.join(self.save_dir, filename)
+        torch.save(state, filename)
+
+    def load_state(self, filename):
+        """Load a checkpoint written by this class or by the reference (vae.py:449-472);
+        ``lr``, ``save_dir`` and ``z_dim`` are not restored, like the reference."""
+        checkpoint = torch.load(filename, map_location=self.device)
+        assert checkpoint['z_dim'] == self.z_dim
+        layers = self._get_layers()
+        for layer_name in layers:
+            layers[layer_name].load_state_dict(checkpoint[layer_name])
+        self.optimizer.load_state_dict(checkpoint['optimizer_state'])
+        self.loss = checkpoint['loss']
+        self.epoch = checkpoint['epoch']
+
+    def visualize(self, loader, num_specs=5, gap=(2, 6), save_filename='reconstruction.pdf'):
+        """Plot random spectrograms and their reconstructions (vae.py:475-516)."""
+        from .plotting import grid_plot
+        assert num_specs <= len(loader.dataset) and num_specs >= 1
+        indices = np.random.choice(np.arange(len(loader.dataset)), size=num_specs, replace=False)
+        specs = torch.stack(loader.dataset[indices]).to(self.device)
+        with torch.no_grad():
+            _, _, rec_specs = self.forward(specs, return_latent_rec=True)
+        specs = specs.detach().cpu().numpy()
+        all_specs = np.stack([specs, rec_specs])
+        save_filename = os.path.join(self.save_dir, save_filename)
+        grid_plot(all_specs, gap=gap, filename=save_filename)
+        return specs, rec_specs
+
+    def get_latent(self, loader):
+        """Latent means of everything in ``loader`` as float64 ``[N,z]`` (vae.py:519-547).
+        Like the reference this does not switch to eval mode."""
+        latent = np.zeros((len(loader.dataset), self.z_dim))
+        i = 0
+        for data in loader:
+            with torch.no_grad():
+                mu, _, _ = self.encode(data)
+            mu = mu.detach().cpu().numpy()
+            latent[i:i + len(mu)] = mu
+            i += len(mu)
+        return latent

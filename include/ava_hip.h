@@ -1,0 +1,160 @@
+/*
+ * ava_hip.h -- C ABI of libava_hip.so: the MI355X (gfx950) implementation of the VAE
+ * training hot path of pearsonlab/autoencoded-vocal-analysis (reference file
+ * ava/models/vae.py).
+ *
+ * The reference has no FFI of its own (it is 100 % Python on top of torch); the entry
+ * points below are what a binding for this path replaces, one per implicit library op
+ * the reference dispatches, plus a fused whole-step driver.
+ * Every function takes raw device pointers, sizes and a hipStream_t (passed as void*),
+ * returns 0 on success or a negative AVA_E* code, allocates nothing and never
+ * synchronises: all scratch memory comes from the caller-provided workspace.
+ *
+ * Layouts: activations are NHWC fp32 (`[B,H,W,C]`) between the convolutions, row-major
+ * `[B,features]` on the fully connected side with the reference's NCHW flatten order
+ * (c*256 + h*16 + w, vae.py:224,262) at the two boundaries.  Parameters live in ONE
+ * flat fp32 arena in named_parameters() order (offsets: ava_param_offset), shadowed by
+ * three arenas of the same shape for the gradient, Adam exp_avg and exp_avg_sq.
+ */
+#ifndef AVA_HIP_H
+#define AVA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVA_OK 0
+#define AVA_EINVAL (-1)   /* bad argument (shape, null pointer, unsupported channel count) */
+#define AVA_ELAUNCH (-2)  /* hipGetLastError() reported a launch failure                    */
+#define AVA_EWORKSPACE (-3) /* workspace too small                                          */
+
+typedef void* ava_stream_t;            /* hipStream_t */
+typedef struct ava_model ava_model;    /* opaque: pointer table + workspace carving, host memory only */
+
+/* ---- library / layout queries ------------------------------------------------------------- */
+int ava_version(void);
+/* number of floats of the flat parameter arena for this z_dim (tensors padded to 64 floats) */
+int64_t ava_arena_floats(int z_dim);
+/* offset (in floats) of parameter `index` (0..79, reference named_parameters() order,
+ * vae.py:125-168) inside the arena; numel returned through *numel (may be NULL) */
+int64_t ava_param_offset(int z_dim, int index, int64_t* numel);
+/* bytes of scratch the model needs for batches up to max_batch */
+size_t ava_workspace_bytes(int z_dim, int max_batch);
+
+/* ---- model object: replaces VAE.__init__/_build_network bookkeeping (vae.py:80-168) -------- */
+/* bn_running: [2][14][32] floats = running_mean then running_var of bn1..bn14, 32 slots per layer
+ * (channel counts 1,8,8,16,16,24,24,32,24,24,16,16,8,8); bn_batches: 14 int64 counters. */
+int ava_model_create(ava_model** out, int z_dim, int max_batch, float model_precision,
+                     float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                     float* bn_running, int64_t* bn_batches, void* workspace, size_t workspace_bytes);
+void ava_model_destroy(ava_model* m);
+
+/* ---- whole-path entry points ------------------------------------------------------------------ */
+/* VAE.forward (vae.py:273-327): encode -> rsample -> decode -> -ELBO.
+ *   x [B,128,128]; eps_w [B], eps_d [B,z]: the two normal draws of rsample in reference order.
+ *   bn_train: 1 = batch statistics + running-stat update (module.train()), 0 = running stats.
+ *   loss_out (device, 4 floats): {-ELBO, sum z^2, SSE, sum entropy}.
+ *   status_out (device int): set to 1 when some d is not > 0 (reference raises ValueError).
+ * Leaves every intermediate needed by ava_backward in the workspace. */
+int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d,
+                int bn_train, float* loss_out, int* status_out, ava_stream_t s);
+/* loss.backward() (vae.py:352) for the forward that just ran: fills the gradient arena
+ * (overwrites: the reference zero_grad()s before every step, vae.py:348). */
+int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);
+/* torch.optim.Adam.step (torch/optim/adam.py:414-547), one fused pass over the four arenas.
+ * `step` is the 1-based count after increment. */
+int ava_adam_step(ava_model* m, float lr, float beta1, float beta2, float eps, int step, ava_stream_t s);
+/* VAE.encode (vae.py:216-233): mu,u,d [B,z] (d = exp(.)); bn_train as above. */
+int ava_encode(ava_model* m, const float* x, int B, int bn_train, float* mu, float* u, float* d, ava_stream_t s);
+/* VAE.decode (vae.py:258-270): z [B,z] -> x_rec [B,16384]. */
+int ava_decode(ava_model* m, const float* z, int B, int bn_train, float* x_rec, ava_stream_t s);
+/* pointers into the workspace after ava_forward: z [B,z] and x_rec [B,16384] */
+const float* ava_last_z(ava_model* m);
+const float* ava_last_xrec(ava_model* m);
+/* name -> workspace buffer of an intermediate (tests): "y1".."y7","d1".."d6","f8","mu","u","logd",... */
+const float* ava_debug_buffer(ava_model* m, const char* name, int64_t* floats);
+
+/* ---- per-op entry points (what the reference reaches through ATen) ---------------------------- */
+/* counter-based standard normals (replaces torch's normal_() in rsample when no noise is injected) */
+int ava_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, ava_stream_t s);
+
+/* pack a Conv2d weight [Cout,Cin,3,3] / ConvTranspose2d weight [Cin,Cout,3,3] into the
+ * gather form G[9][Cin_g][Cout_g] used by the kernels.
+ *   kind: 0 conv fwd, 1 convT stride-1 fwd, 2 convT stride-2 fwd,
+ *         3 conv stride-1 bwd-data, 4 conv stride-2 bwd-data, 5 convT stride-1 bwd-data, 6 convT stride-2 bwd-data */
+int ava_pack_conv_weight(const float* w, float* g, int c_first, int c_second, int kind, ava_stream_t s);
+
+/* 3x3 gather convolution, NHWC.  mode: 0 same-resolution (conv s1 / convT s1 / their bwd-data),
+ * 1 down x2 (conv s2 fwd, convT s2 bwd-data), 2 up x2 (convT s2 fwd, conv s2 bwd-data).
+ * Prologue applied to the input while it is staged into LDS (zero padding is applied AFTER it):
+ *   pro 0: v*pa[c] + pb[c]                      (BatchNorm apply, vae.py:217-223)
+ *   pro 1: (in2 > 0) ? pa[c]*v + pb[c]*in2 + pc[c] : 0   (ReLU mask + BatchNorm backward, in2 = saved activation)
+ *   pro 2: v
+ * Epilogue:
+ *   epi 0: + bias, optional ReLU, store, per-channel {sum, sum^2} partials (next BatchNorm's statistics)
+ *   epi 1: store, per-channel {sum g, sum g*xhat} partials with xhat = (epi_x - mean)*invstd (BatchNorm backward sums)
+ *   epi 2: + bias, store x_rec, r = x_rec - epi_x, store prec*r to out2, partial {sum r^2}  (vae.py:319-320)
+ * partials: [ava_conv_grid(...)][2*Cout] floats. */
+int ava_conv_grid(int B, int Ho, int Wo, int mode);
+int ava_conv3x3(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
+                const float* G, const float* bias, float* out, float* out2,
+                const float* epi_x, const float* epi_mean, const float* epi_invstd, float* partials,
+                int B, int Hi, int Wi, int Cin, int Cout, int mode, int pro, int epi, int relu, float prec,
+                ava_stream_t s);
+/* weight/bias gradient of the same gather convolution: dG[9][Cin][Cout] and db[Cout] partials per
+ * workgroup ([grid][9*Cin*Cout + Cout]); x side uses prologue 0 (BatchNorm apply), dy side pro 1 or 2. */
+int ava_conv3x3_wgrad(const float* x, const float* xa, const float* xb,
+                      const float* dy, const float* dy2, const float* da, const float* db_, const float* dc,
+                      float* partials, int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro,
+                      ava_stream_t s);
+int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode);
+/* reduce the per-workgroup partials and scatter into the reference weight layout
+ * (kind as in ava_pack_conv_weight, 0..2 only) */
+int ava_conv_wgrad_reduce(const float* partials, int nparts, float* dw, float* dbias,
+                          int Cin, int Cout, int kind, ava_stream_t s);
+
+/* BatchNorm2d statistics of a raw tensor [n, C] (channel innermost) -> partials [grid][2C] */
+int ava_bn_stats(const float* x, int64_t n, int C, float* partials, int* nparts, ava_stream_t s);
+/* partials -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; train: running-stat update
+ * (momentum 0.1, unbiased variance, eps 1e-5); eval: uses running stats. */
+int ava_bn_finalize(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches, int train,
+                    float* mean, float* invstd, float* scale, float* shift, ava_stream_t s);
+/* backward: partials {sum g, sum g*xhat} -> dgamma, dbeta and the per-channel coefficients
+ * dx = A*g + Bc*x + Cc */
+int ava_bn_finalize_bwd(const float* partials, int nparts, int64_t n, int C, const float* gamma,
+                        const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                        float* A, float* Bc, float* Cc, ava_stream_t s);
+
+/* C[M,N] = relu_mask(act(A*B + bias)) on the fp32 matrix cores (nn.Linear and its two backward products).
+ *   a_kmajor: 1 = A stored [M,K] (K contiguous), 0 = A stored [K,M] ; lda = stored leading dimension (0: dense)
+ *   b_kmajor: 1 = B stored [N,K] (K contiguous), 0 = B stored [K,N] ; ldb likewise ; ldc: row stride of C (0: N)
+ *   act: 0 none, 1 ReLU, 2 exp ; bias may be NULL ; split-K partial slabs go to `ws`
+ *   mask (may be NULL, row stride ldc): C = mask > 0 ? value : 0  (ReLU backward of the layer that produced mask)
+ *   colsum (may be NULL): receives sum over K of A (bias gradient when A = dY^T) */
+size_t ava_gemm_workspace_bytes(int M, int N, int K);
+int ava_gemm(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+             const float* mask, float* colsum, int M, int N, int K, int a_kmajor, int b_kmajor, int act,
+             void* ws, size_t ws_bytes, ava_stream_t s);
+
+/* latent block: d = exp(a), z = mu + u*eps_w + sqrt(d)*eps_d, per-sample sum z^2 and entropy
+ * (torch/distributions/lowrank_multivariate_normal.py:17-38,214-252).  sums: [B][2]. */
+int ava_latent_fwd(const float* mu, const float* u, const float* logd, const float* eps_w, const float* eps_d,
+                   float* d, float* z, float* sums, int* status, int B, int zdim, ava_stream_t s);
+/* closed-form backward: g = z + dz_dec */
+int ava_latent_bwd(const float* z, const float* dz_dec, const float* u, const float* d, const float* eps_w,
+                   const float* eps_d, float* dmu, float* du, float* dlogd, int B, int zdim, ava_stream_t s);
+/* assemble -ELBO from the partial sums (vae.py:316-323); loss_out = {loss, sum z^2, SSE, sum H} */
+int ava_elbo_finalize(const float* latent_sums, int B, const float* sse_partials, int nparts,
+                      int zdim, float prec, float* loss_out, ava_stream_t s);
+/* Adam over flat arenas */
+int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, ava_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVA_HIP_H */

@@ -24,6 +24,18 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_EXP = 2 };
 #define NPARAM 80
 #define ALIGN_F 64
 
+// ---- optional per-category timing with HIP events on the launch stream (bench.py roofline leg) ----
+enum { CAT_CONV_FWD = 0, CAT_CONV_BWD_DATA, CAT_CONV_WGRAD, CAT_BN, CAT_GEMM, CAT_LAYOUT, CAT_LATENT_LOSS, CAT_ADAM,
+       CAT_PACK, NCAT };
+#define PROF_MAX_EVENTS 1024
+struct Prof {
+  bool on = false;
+  int n = 0;
+  hipEvent_t ev[PROF_MAX_EVENTS];
+  int cat[PROF_MAX_EVENTS];
+  int created = 0;
+};
+
 struct ConvLayer {
   int cin, cout, mode, hi;        // forward gather mode, input height (= width)
   int ho;
@@ -108,6 +120,7 @@ struct ava_model {
   float* eps_d_last;        // copies of the noise of the last forward (needed by backward)
   int sse_parts;
   int lastB;
+  Prof prof;
   std::map<std::string, std::pair<const float*, int64_t>> dbg;
 };
 
@@ -266,6 +279,41 @@ extern "C" const float* ava_debug_buffer(ava_model* m, const char* name, int64_t
   return it->second.first;
 }
 
+// record an event after a launch (group) of category `cat`; the time since the previous event is
+// attributed to `cat` by ava_profile_read
+static inline void mark(ava_model* m, int cat, hipStream_t st) {
+  Prof& p = m->prof;
+  if (!p.on || p.n >= PROF_MAX_EVENTS) return;
+  if (p.n >= p.created) { if (hipEventCreate(&p.ev[p.created]) != hipSuccess) return; p.created++; }
+  hipEventRecord(p.ev[p.n], st);
+  p.cat[p.n] = cat;
+  p.n++;
+}
+
+extern "C" int ava_profile_enable(ava_model* m, int on) {
+  if (m == nullptr) return AVA_EINVAL;
+  m->prof.on = on != 0;
+  m->prof.n = 0;
+  return AVA_OK;
+}
+// synchronises on the last event, sums elapsed ms per category into ms[NCAT] (adds to it), returns the
+// number of categories; resets the event list
+extern "C" int ava_profile_read(ava_model* m, float* ms, int* launches) {
+  if (m == nullptr || ms == nullptr) return AVA_EINVAL;
+  Prof& p = m->prof;
+  if (p.n > 0) hipEventSynchronize(p.ev[p.n - 1]);
+  for (int i = 1; i < p.n; ++i) {
+    if (p.cat[i] < 0) continue;           // step-begin marker
+    float e = 0.f;
+    if (hipEventElapsedTime(&e, p.ev[i - 1], p.ev[i]) == hipSuccess) {
+      ms[p.cat[i]] += e;
+      if (launches) launches[p.cat[i]] += 1;
+    }
+  }
+  p.n = 0;
+  return NCAT;
+}
+
 #define TRY(expr)            \
   do {                       \
     int _rc = (expr);        \
@@ -298,13 +346,16 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st) {
     tab.e[2 * l] = {w, m->Gf[l], c0, c1, (kf == 0) ? 1 : 0, (kf == 1) ? 1 : 0};
     tab.e[2 * l + 1] = {w, m->Gb[l], c0, c1, (kb == 5 || kb == 6) ? 1 : 0, (kb == 3) ? 1 : 0};
   }
+  mark(m, -1, st);
   hipLaunchKernelGGL(pack_all_kernel, dim3(7, with_bwd ? 2 * NCONV : 2 * NCONV), dim3(256), 0, st, tab);
   AVA_CHECK_LAUNCH();
+  mark(m, CAT_PACK, st);
   return AVA_OK;
 }
 
 static int finalize_bn(ava_model* m, int l, int nparts, int64_t n, int train, hipStream_t st) {
   const ConvLayer& L = kLayers[l];
+  struct M { ava_model* m; hipStream_t st; ~M() { mark(m, CAT_BN, st); } } _mk{m, st};
   return ava_bn_finalize(m->bn_part, nparts, n, L.cin, PP(m, L.pg), PP(m, L.pbeta), m->bn_running + l * 32,
                          m->bn_running + (NCONV + l) * 32, m->bn_batches + l, train, bn_mean(m, l), bn_invstd(m, l),
                          bn_scale(m, l), bn_shift(m, l), st);
@@ -312,6 +363,7 @@ static int finalize_bn(ava_model* m, int l, int nparts, int64_t n, int train, hi
 
 static int gemm(ava_model* m, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
                 const float* mask, float* colsum, int M, int N, int K, int ak, int bk, int act, hipStream_t st) {
+  struct Mk { ava_model* m; hipStream_t st; ~Mk() { mark(m, CAT_GEMM, st); } } _mk{m, st};
   return ava_gemm(A, lda, B, ldb, bias, C, ldc, mask, colsum, M, N, K, ak, bk, act, m->gemm_ws, m->gemm_ws_bytes, st);
 }
 
@@ -323,7 +375,7 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
                            int last_act, hipStream_t st) {
   const int z = m->z;
   int nparts = 0;
-  if (train) TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, st));
+  if (train) { TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, st)); mark(m, CAT_BN, st); }
   TRY(finalize_bn(m, 0, nparts, (int64_t)B * 16384, train, st));
   for (int l = 0; l < 7; ++l) {
     const ConvLayer& L = kLayers[l];
@@ -332,12 +384,14 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
     TRY(ava_conv3x3(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nullptr,
                     nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
                     0.f, st));
+    mark(m, CAT_CONV_FWD, st);
     if (l < 6) {
       const int np = ava_conv_grid(B, L.ho, L.ho, L.mode);
       TRY(finalize_bn(m, l + 1, np, (int64_t)B * L.ho * L.ho, train, st));
     }
   }
   TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, st));
+  mark(m, CAT_LAYOUT, st);
   TRY(gemm(m, m->y7t, 0, PP(m, FC1), 0, PP(m, FC1 + 1), m->h1, 0, nullptr, nullptr, B, 1024, 8192, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h1, 0, PP(m, FC2), 0, PP(m, FC2 + 1), m->h2, 0, nullptr, nullptr, B, 256, 1024, 1, 1, ACT_RELU, st));
   // fc31|fc32|fc33 as one [192,256] layer (arena keeps the three weights, then the three biases, contiguous)
@@ -358,6 +412,7 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
   TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, 8192, 1024, 1, 1, ACT_RELU, st));
   int nparts = 0;
   TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, &nparts, st));
+  mark(m, CAT_LAYOUT, st);
   TRY(finalize_bn(m, 7, nparts, (int64_t)B * 256, train, st));
   for (int l = 7; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
@@ -366,6 +421,7 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
     TRY(ava_conv3x3(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
                     last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi,
                     L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, st));
+    mark(m, CAT_CONV_FWD, st);
     const int np = ava_conv_grid(B, L.ho, L.ho, L.mode);
     if (!last) TRY(finalize_bn(m, l + 1, np, (int64_t)B * L.ho * L.ho, train, st));
     else m->sse_parts = np;
@@ -381,14 +437,17 @@ extern "C" int ava_forward(ava_model* m, const float* x, int B, const float* eps
   TRY(pack_weights(m, true, st));
   TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st));
   if (status_out != nullptr) { if (hipMemsetAsync(status_out, 0, sizeof(int), st) != hipSuccess) return AVA_ELAUNCH; }
+  mark(m, CAT_LAYOUT, st);
   TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
   if (eps_w != m->eps_w_last) {
     if (hipMemcpyAsync(m->eps_w_last, eps_w, sizeof(float) * B, hipMemcpyDeviceToDevice, st) != hipSuccess) return AVA_ELAUNCH;
     if (hipMemcpyAsync(m->eps_d_last, eps_d, sizeof(float) * B * z, hipMemcpyDeviceToDevice, st) != hipSuccess) return AVA_ELAUNCH;
   }
+  mark(m, CAT_LATENT_LOSS, st);
   TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st));
   TRY(ava_elbo_finalize_strided(m->lat_sums, B, m->bn_part, m->sse_parts, 2, z, m->prec,
                                 loss_out != nullptr ? loss_out : m->loss_dev, st));
+  mark(m, CAT_LATENT_LOSS, st);
   m->lastB = B;
   return AVA_OK;
 }
@@ -418,16 +477,20 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
   TRY(ava_conv3x3_wgrad(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part, B, L.hi, L.hi, L.cin,
                         L.cout, L.mode, pro, st));
+  mark(m, CAT_CONV_WGRAD, st);
   const int wparts = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
   const int kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
   TRY(ava_conv_wgrad_reduce(m->wg_part, wparts, GG(m, L.pw), GG(m, L.pb), L.cin, L.cout, kind, st));
+  mark(m, CAT_CONV_WGRAD, st);
   // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
   const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
   TRY(ava_conv3x3(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
                   m->bn_part, B, L.ho, L.ho, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f, st));
+  mark(m, CAT_CONV_BWD_DATA, st);
   const int np = ava_conv_grid(B, L.hi, L.hi, bmode);
   TRY(ava_bn_finalize_bwd(m->bn_part, np, (int64_t)B * L.hi * L.hi, L.cin, PP(m, L.pg), bn_mean(m, l),
                           bn_invstd(m, l), GG(m, L.pg), GG(m, L.pbeta), bn_A(m, l), bn_B(m, l), bn_C(m, l), st));
+  mark(m, CAT_BN, st);
   return AVA_OK;
 }
 
@@ -438,6 +501,7 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
   // ---- decoder convolutions, last to first ----
   float* gcur = m->gA;
   float* gnext = m->gB;
+  mark(m, -1, st);
   TRY(conv_layer_backward(m, 13, x, m->seed, nullptr, nullptr, nullptr, nullptr, PRO_ID, gcur, B, st));
   for (int l = 12; l >= 7; --l) {
     // dU_l = (X_{l+1} > 0) ? A*g + Bc*X_{l+1} + Cc : 0 with the coefficients of BatchNorm l+1
@@ -447,6 +511,7 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
   }
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
   TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, st));
+  mark(m, CAT_LAYOUT, st);
   // ---- decoder fully connected: dW = dY^T X (+ db), dX = (dY W) masked by the producer's ReLU ----
   TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), 8192, 1024, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dF8, 0, PP(m, FC8), 0, nullptr, m->dh7, 0, m->h7, nullptr, B, 1024, 8192, 1, 0, ACT_NONE, st));
@@ -458,6 +523,7 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
   TRY(gemm(m, m->dh5, 0, PP(m, FC5), 0, nullptr, m->dz, 0, nullptr, nullptr, B, z, 64, 1, 0, ACT_NONE, st));
   // ---- latent block ----
   TRY(ava_latent_bwd(m->zs, m->dz, m->u, m->d, m->eps_w_last, m->eps_d_last, m->dmu, m->du, m->dlogd, B, z, st));
+  mark(m, CAT_LATENT_LOSS, st);
   // ---- heads: fc41/42/43 (64 -> z) on the three 64-wide slices of h3 ----
   const float* dheads[3] = {m->dmu, m->du, m->dlogd};
   const int fc4[3] = {FC41, FC42, FC43};
@@ -476,6 +542,7 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
   // ---- encoder convolutions ----
   gcur = m->gA; gnext = m->gB;
   TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, st));             // dU_7 (ReLU of conv7)
+  mark(m, CAT_LAYOUT, st);
   TRY(conv_layer_backward(m, 6, x, gcur, nullptr, nullptr, nullptr, nullptr, PRO_ID, gnext, B, st));
   { float* t = gcur; gcur = gnext; gnext = t; }
   for (int l = 5; l >= 0; --l) {
@@ -488,5 +555,8 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
 
 extern "C" int ava_adam_step(ava_model* m, float lr, float beta1, float beta2, float eps, int step, ava_stream_t s) {
   if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr) return AVA_EINVAL;
-  return ava_adam_flat(m->P, m->G, m->M, m->V, m->arena, lr, beta1, beta2, eps, step, s);
+  mark(m, -1, to_stream(s));
+  const int rc = ava_adam_flat(m->P, m->G, m->M, m->V, m->arena, lr, beta1, beta2, eps, step, s);
+  mark(m, CAT_ADAM, to_stream(s));
+  return rc;
 }

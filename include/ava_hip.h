@@ -77,6 +77,14 @@ const float* ava_last_xrec(ava_model* m);
 /* name -> workspace buffer of an intermediate (tests): "y1".."y7","d1".."d6","f8","mu","u","logd",... */
 const float* ava_debug_buffer(ava_model* m, const char* name, int64_t* floats);
 
+/* Optional timing of the driver's launches with HIP events recorded on the launch stream
+ * (bench.py's roofline leg).  Categories, in order: conv forward, conv backward-data, conv weight-grad
+ * (+ its reduction), BatchNorm statistics/finalise, GEMM, layout hand-offs, latent+ELBO, Adam, weight pack.
+ * ava_profile_read adds elapsed milliseconds (and launch-group counts) per category and clears the list. */
+#define AVA_PROFILE_CATEGORIES 9
+int ava_profile_enable(ava_model* m, int on);
+int ava_profile_read(ava_model* m, float* ms, int* launches);
+
 /* ---- per-op entry points (what the reference reaches through ATen) ---------------------------- */
 /* counter-based standard normals (replaces torch's normal_() in rsample when no noise is injected) */
 int ava_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, ava_stream_t s);

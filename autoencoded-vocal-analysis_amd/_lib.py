@@ -36,6 +36,7 @@ _p = C.c_void_p
 _i = C.c_int
 _i64 = C.c_int64
 _f = C.c_float
+_d = C.c_double
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/ava_hip.h one to one
@@ -48,7 +49,7 @@ SIGNATURES = {
     "ava_model_destroy": (None, [_p]),
     "ava_forward": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
     "ava_backward": (_i, [_p, _p, _i, _p]),
-    "ava_adam_step": (_i, [_p, _f, _f, _f, _f, _i, _p]),
+    "ava_adam_step": (_i, [_p, _d, _d, _d, _d, _i, _p]),
     "ava_encode": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
     "ava_decode": (_i, [_p, _p, _i, _i, _p, _p]),
     "ava_last_z": (_p, [_p]),
@@ -71,7 +72,7 @@ SIGNATURES = {
     "ava_latent_fwd": (_i, [_p] * 9 + [_i, _i, _p]),
     "ava_latent_bwd": (_i, [_p] * 9 + [_i, _i, _p]),
     "ava_elbo_finalize": (_i, [_p, _i, _p, _i, _i, _f, _p, _p]),
-    "ava_adam_flat": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
+    "ava_adam_flat": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _i, _p]),
 }
 
 _lib = None

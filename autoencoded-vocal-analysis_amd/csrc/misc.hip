@@ -167,18 +167,18 @@ extern "C" int ava_elbo_finalize(const float* latent_sums, int B, const float* s
   if (latent_sums == nullptr || sse_partials == nullptr || loss_out == nullptr) return AVA_EINVAL;
   return ava_elbo_finalize_strided(latent_sums, B, sse_partials, nparts, 2, zdim, prec, loss_out, to_stream(s));
 }
-extern "C" int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                             float beta2, float eps, int step, ava_stream_t s) {
+extern "C" int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                             double beta2, double eps, int step, ava_stream_t s) {
   if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0 || n % 4 != 0 || step < 1)
     return AVA_EINVAL;
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  const float step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bc1);
   const float sqrt_bc2 = (float)sqrt(bc2);
   int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, to_stream(s), p, g, m, v, n4, 1.f - beta1, beta2,
-                     1.f - beta2, step_size, sqrt_bc2, eps);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, to_stream(s), p, g, m, v, n4,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, sqrt_bc2, (float)eps);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -553,7 +553,8 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
   return AVA_OK;
 }
 
-extern "C" int ava_adam_step(ava_model* m, float lr, float beta1, float beta2, float eps, int step, ava_stream_t s) {
+extern "C" int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step,
+                             ava_stream_t s) {
   if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr) return AVA_EINVAL;
   mark(m, -1, to_stream(s));
   const int rc = ava_adam_flat(m->P, m->G, m->M, m->V, m->arena, lr, beta1, beta2, eps, step, s);

@@ -55,10 +55,14 @@ class FlatAdam(torch.optim.Adam):
         self._step_count_flat += 1
         b1, b2 = g['betas']
         lib = _lib.load()
-        rc = lib.ava_adam_flat(m._params.data_ptr(), m._grads.data_ptr(), m._exp_avg.data_ptr(),
-                               m._exp_avg_sq.data_ptr(), m._params.numel(), float(g['lr']), float(b1), float(b2),
-                               float(g['eps']), self._step_count_flat, _lib.stream())
-        _lib.check(rc, "ava_adam_flat")
+        if m._handle is not None:
+            rc = lib.ava_adam_step(m._handle, float(g['lr']), float(b1), float(b2), float(g['eps']),
+                                   self._step_count_flat, _lib.stream())
+        else:
+            rc = lib.ava_adam_flat(m._params.data_ptr(), m._grads.data_ptr(), m._exp_avg.data_ptr(),
+                                   m._exp_avg_sq.data_ptr(), m._params.numel(), float(g['lr']), float(b1), float(b2),
+                                   float(g['eps']), self._step_count_flat, _lib.stream())
+        _lib.check(rc, "Adam step")
         return None
 
     def state_dict(self):

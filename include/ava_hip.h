@@ -66,7 +66,7 @@ int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const f
 int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);
 /* torch.optim.Adam.step (torch/optim/adam.py:414-547), one fused pass over the four arenas.
  * `step` is the 1-based count after increment. */
-int ava_adam_step(ava_model* m, float lr, float beta1, float beta2, float eps, int step, ava_stream_t s);
+int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step, ava_stream_t s);
 /* VAE.encode (vae.py:216-233): mu,u,d [B,z] (d = exp(.)); bn_train as above. */
 int ava_encode(ava_model* m, const float* x, int B, int bn_train, float* mu, float* u, float* d, ava_stream_t s);
 /* VAE.decode (vae.py:258-270): z [B,z] -> x_rec [B,16384]. */
@@ -159,8 +159,10 @@ int ava_latent_bwd(const float* z, const float* dz_dec, const float* u, const fl
 int ava_elbo_finalize(const float* latent_sums, int B, const float* sse_partials, int nparts,
                       int zdim, float prec, float* loss_out, ava_stream_t s);
 /* Adam over flat arenas */
-int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int step, ava_stream_t s);
+/* hyper-parameters are doubles like the Python floats torch receives; each is rounded to fp32 exactly where
+ * torch's kernels round it (1-beta1, beta2, 1-beta2, lr/bias_correction1, sqrt(bias_correction2), eps) */
+int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int step, ava_stream_t s);
 
 #ifdef __cplusplus
 }

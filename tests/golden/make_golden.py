@@ -246,11 +246,12 @@ def harness_case(z_dim=32, B=8, nb=2):
     out["epoch"] = m.epoch
     files = sorted(os.listdir(tmp))
     ck = torch.load(os.path.join(tmp, "checkpoint_001.tar"), weights_only=True)
-    manifest = {"files": files, "keys": list(ck.keys()), "layers": {}, "epoch": ck["epoch"],
+    manifest = {"files": files, "keys": list(ck.keys()), "layers": {}, "layer_key_order": {}, "epoch": ck["epoch"],
                 "z_dim": ck["z_dim"], "lr": ck["lr"], "loss_keys": {k: sorted(v.keys()) for k, v in ck["loss"].items()}}
     for k, v in ck.items():
         if isinstance(v, dict) and k not in ("optimizer_state", "loss"):
             manifest["layers"][k] = {kk: [list(vv.shape), str(vv.dtype)] for kk, vv in v.items()}
+            manifest["layer_key_order"][k] = list(v.keys())
     pg = ck["optimizer_state"]["param_groups"]
     manifest["param_groups"] = [{k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in g.items()} for g in pg]
     st = ck["optimizer_state"]["state"]

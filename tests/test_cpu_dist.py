@@ -1,0 +1,80 @@
+"""World-size-2 tests of the data-parallel glue on CPU (gloo): gradient SUM all-reduce of the flat arena
+and the global-loss assembly, fed with per-shard results of the CPU oracle and pinned by the
+reference-generated two-shard golden (tests/golden/ddp2.npz)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden, ROOT
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    from ava_amd import dist as adist, synthetic as syn, layout
+    from oracle import vae_oracle as O
+    torch.set_num_threads(2)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert adist.active() and adist.rank() == rank and adist.world_size() == world
+        z, B = 32, 8
+        x = syn.spectrograms(B * world)
+        ew, ed = syn.noise(B * world, z)
+        sl = slice(B * rank, B * rank + B)
+        P = O.to_params(syn.fixture_parameters(z), requires_grad=True)
+        out = O.forward(P, torch.from_numpy(x[sl]), torch.from_numpy(ew[sl]), torch.from_numpy(ed[sl]), None, True)
+        out["loss"].backward()
+        offs, total = layout.arena_offsets(z)
+        flat = torch.zeros(total)
+        for s in layout.param_specs(z):
+            flat[offs[s.name]:offs[s.name] + s.numel] = P[s.name].grad.reshape(-1)
+        adist.allreduce_gradients(flat)                       # SUM, not mean (the loss is a batch sum)
+        norms = {s.name: float(flat[offs[s.name]:offs[s.name] + s.numel].double().norm()) for s in layout.param_specs(z)}
+        gl = adist.global_loss(out["loss"].detach().double(), z, 10.0, 1)
+        n = adist.global_dataset_len(B)
+        q.put((rank, float(out["loss"]), norms, gl, n))
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_gradient_sum_and_global_loss():
+    G = load_golden("ddp2.npz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    from ava_amd import dist as adist
+    c = adist.per_call_constants(32, 10.0)
+    assert abs(c - (29.406 - 3806.888)) < 1e-2             # SURVEY Appendix B constants at z=32, prec=10
+    for rank, loss, norms, gl, n in res:
+        assert abs(loss - float(G["shard%d.loss" % rank])) / abs(loss) < 1e-5
+        assert n == 16
+        # every rank added the per-call constants once; a single-process step adds them once per global batch
+        want = float(G["shard0.loss"]) + float(G["shard1.loss"]) - c
+        assert abs(gl - want) / abs(want) < 1e-5
+        for name, v in norms.items():
+            sens = name.split(".")[0] in ("conv1", "bn1")
+            ref = float(G["gradnorm." + name])
+            scale = max(ref, float(G["gradnorm.conv1.bias"]) if sens else 0.0)
+            assert abs(v - ref) < (2e-2 if sens else 1e-3) * scale, name
+    assert res[0][2] == res[1][2]                            # both ranks hold the identical reduced gradient
+
+
+def test_single_process_is_passthrough():
+    from ava_amd import dist as adist
+    t = torch.arange(4.0)
+    assert adist.allreduce_gradients(t) is t and not adist.active()
+    assert adist.rank() == 0 and adist.world_size() == 1 and adist.global_dataset_len(7) == 7
+    assert adist.global_loss(torch.tensor(5.0), 32, 10.0, 3) == 5.0

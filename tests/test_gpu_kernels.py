@@ -1,0 +1,300 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle's ops (fp64 ATen
+conv / conv_transpose / autograd on the same seeded inputs).  fp32 tolerance 2e-5 relative to the
+tensor's max magnitude unless noted.  Run with -m gpu on the MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import (LAYERS, MODE_S1, MODE_DOWN, MODE_UP, PRO_BN, PRO_BWD, PRO_ID, EPI_FWD, EPI_BWD, EPI_SSE, dev,
+                      pack, conv3x3, wgrad, gemm, rel, nhwc, out_size, p, stream)
+from ava_amd import _lib, synthetic as syn
+from oracle import vae_oracle as O
+
+TOL = 2e-5
+
+
+def ref_conv(xhat, w, b, mode, transposed):
+    """fp64 reference of one layer's convolution (NCHW)."""
+    if not transposed:
+        return F.conv2d(xhat, w, b, stride=1 if mode == MODE_S1 else 2, padding=1)
+    s = 1 if mode == MODE_S1 else 2
+    return F.conv_transpose2d(xhat, w, b, stride=s, padding=1, output_padding=s - 1)
+
+
+def layer_tensors(name, cin, cout, hi, transposed, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, hi, hi, generator=g, dtype=torch.float64)
+    x = torch.relu(x) if seed % 2 else x
+    wshape = (cin, cout, 3, 3) if transposed else (cout, cin, 3, 3)
+    w = torch.randn(wshape, generator=g, dtype=torch.float64) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g, dtype=torch.float64) * 0.1
+    scale = 0.5 + torch.rand(cin, generator=g, dtype=torch.float64)
+    shift = torch.randn(cin, generator=g, dtype=torch.float64) * 0.3
+    return x, w, b, scale, shift
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+@pytest.mark.parametrize("B", [1, 3])
+def test_conv_forward(layer, B):
+    """BN-apply prologue (zero padding AFTER BatchNorm) + conv/convT + bias + ReLU + statistics epilogue."""
+    name, cin, cout, mode, hi, tr = layer
+    x, w, b, scale, shift = layer_tensors(name, cin, cout, hi, tr, B, 11)
+    xhat = x * scale[None, :, None, None] + shift[None, :, None, None]
+    want = torch.relu(ref_conv(xhat, w, b, mode, tr))
+    kind = 0 if not tr else (1 if mode == MODE_S1 else 2)
+    G = pack(dev(w), kind)
+    out, _, partials = conv3x3(dev(nhwc(x)), G, cin, cout, mode, PRO_BN, EPI_FWD, B, hi, pa=dev(scale), pb=dev(shift),
+                               bias=dev(b), relu=1)
+    assert rel(out.cpu(), nhwc(want)) < TOL
+    sums = partials.double().sum(dim=0).cpu()
+    assert rel(sums[:cout], want.sum(dim=(0, 2, 3))) < 1e-5
+    assert rel(sums[cout:], (want * want).sum(dim=(0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_backward_data_and_wgrad(layer):
+    """ReLU-mask + BatchNorm-backward prologue, backward-data with BN-backward sums, weight/bias gradient."""
+    name, cin, cout, mode, hi, tr = layer
+    B = 2
+    x, w, b, scale, shift = layer_tensors(name, cin, cout, hi, tr, B, 12)
+    g = torch.Generator().manual_seed(5)
+    ho = out_size(hi, mode)
+    # upstream: gradient w.r.t. next BN's output `gn`, saved activation y (post-ReLU), coefficients A,Bc,Cc
+    gn = torch.randn(B, cout, ho, ho, generator=g, dtype=torch.float64)
+    y = torch.relu(torch.randn(B, cout, ho, ho, generator=g, dtype=torch.float64))
+    A = 0.5 + torch.rand(cout, generator=g, dtype=torch.float64)
+    Bc = torch.randn(cout, generator=g, dtype=torch.float64) * 0.1
+    Cc = torch.randn(cout, generator=g, dtype=torch.float64) * 0.1
+    dU = torch.where(y > 0, A[None, :, None, None] * gn + Bc[None, :, None, None] * y + Cc[None, :, None, None],
+                     torch.zeros_like(gn))
+    xhat = (x * scale[None, :, None, None] + shift[None, :, None, None]).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref_conv(xhat, wr, br, mode, tr).backward(dU)
+    # ---- backward-data (+ BN-backward sums against x with mean/invstd) ----
+    mean = x.mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(x.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    kind_b = (3 if mode == MODE_S1 else 4) if not tr else (5 if mode == MODE_S1 else 6)
+    bmode = MODE_S1 if mode == MODE_S1 else (MODE_UP if mode == MODE_DOWN else MODE_DOWN)
+    Gb = pack(dev(w), kind_b)
+    out, _, partials = conv3x3(dev(nhwc(gn)), Gb, cout, cin, bmode, PRO_BWD, EPI_BWD, B, ho, in2=dev(nhwc(y)),
+                               pa=dev(A), pb=dev(Bc), pc=dev(Cc), epi_x=dev(nhwc(x)), epi_mean=dev(mean),
+                               epi_invstd=dev(invstd))
+    assert rel(out.cpu(), nhwc(xhat.grad)) < TOL
+    xn = (x - mean[None, :, None, None]) * invstd[None, :, None, None]
+    sums = partials.double().sum(dim=0).cpu()
+    scale_ref = xhat.grad.abs().sum(dim=(0, 2, 3)).max()
+    assert float((sums[:cin] - xhat.grad.sum(dim=(0, 2, 3))).abs().max() / scale_ref) < 1e-5
+    assert float((sums[cin:] - (xhat.grad * xn).sum(dim=(0, 2, 3))).abs().max() / scale_ref) < 1e-5
+    # identity prologue (first backward layer of each stack)
+    out_id, _, _ = conv3x3(dev(nhwc(dU)), Gb, cout, cin, bmode, PRO_ID, EPI_BWD, B, ho, epi_x=dev(nhwc(x)),
+                           epi_mean=dev(mean), epi_invstd=dev(invstd))
+    assert rel(out_id.cpu(), nhwc(xhat.grad)) < TOL
+    # ---- weight / bias gradient ----
+    kind_f = 0 if not tr else (1 if mode == MODE_S1 else 2)
+    dw, dbias = wgrad(dev(nhwc(x)), dev(scale), dev(shift), dev(nhwc(gn)), cin, cout, mode, PRO_BWD, B, hi,
+                      dy2=dev(nhwc(y)), da=dev(A), db=dev(Bc), dc=dev(Cc), kind=kind_f)
+    assert rel(dw.cpu(), wr.grad.reshape(-1)) < TOL
+    assert rel(dbias.cpu(), br.grad) < TOL
+    dw2, dbias2 = wgrad(dev(nhwc(x)), dev(scale), dev(shift), dev(nhwc(dU)), cin, cout, mode, PRO_ID, B, hi,
+                        kind=kind_f)
+    assert rel(dw2.cpu(), wr.grad.reshape(-1)) < TOL and rel(dbias2.cpu(), br.grad) < TOL
+
+
+def test_convt7_sse_epilogue():
+    """x_rec, the SSE partial sums and the seed gradient prec*(x_rec - x) (vae.py:319-320)."""
+    name, cin, cout, mode, hi, tr = LAYERS[13]
+    B = 2
+    x, w, b, scale, shift = layer_tensors(name, cin, cout, hi, tr, B, 13)
+    target = torch.rand(B, 1, hi, hi, dtype=torch.float64)
+    xhat = x * scale[None, :, None, None] + shift[None, :, None, None]
+    want = ref_conv(xhat, w, b, mode, tr)
+    out, seed, partials = conv3x3(dev(nhwc(x)), pack(dev(w), 1), cin, cout, mode, PRO_BN, EPI_SSE, B, hi,
+                                  pa=dev(scale), pb=dev(shift), bias=dev(b), epi_x=dev(nhwc(target)), prec=10.0)
+    assert rel(out.cpu(), nhwc(want)) < TOL
+    assert rel(seed.cpu(), nhwc(10.0 * (want - target))) < TOL
+    assert rel(partials.double().sum(dim=0)[0].cpu(), ((want - target) ** 2).sum()) < 1e-6
+
+
+GEMM_CASES = [
+    # M, N, K, a_kmajor, b_kmajor   (forward / dX / dW products of the Linear layers, incl. tails and split-K)
+    (256, 1024, 8192, 1, 1), (8, 1024, 8192, 1, 1), (256, 8192, 1024, 1, 1), (256, 192, 256, 1, 1),
+    (5, 32, 64, 1, 1), (256, 64, 32, 1, 1), (3, 20, 64, 1, 1), (7, 64, 20, 1, 1),
+    (256, 1024, 8192, 1, 0), (64, 256, 192, 1, 0), (5, 64, 32, 1, 0),
+    (1024, 8192, 256, 0, 0), (8192, 1024, 8, 0, 0), (192, 256, 64, 0, 0), (32, 64, 5, 0, 0), (64, 20, 3, 0, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ak,bk", GEMM_CASES)
+def test_gemm(M, N, K, ak, bk):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g, dtype=torch.float64)
+    Bm = torch.randn(K, N, generator=g, dtype=torch.float64)
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    want = A @ Bm
+    As = dev(A if ak else A.t())
+    Bs = dev(Bm.t() if bk else Bm)
+    scale = float(want.abs().max())
+    C, cs = gemm(As, Bs, M, N, K, ak, bk, colsum=(ak == 0))
+    assert float((C.cpu().double() - want).abs().max()) / scale < 1e-5
+    if ak == 0:
+        assert rel(cs.cpu(), A.sum(dim=1)) < 1e-5
+    # bias + ReLU epilogue, and ReLU-backward mask
+    C2, _ = gemm(As, Bs, M, N, K, ak, bk, bias=dev(bias), act=1)
+    assert float((C2.cpu().double() - torch.relu(want + bias)).abs().max()) / scale < 1e-5
+    mask = torch.randn(M, N, generator=g)
+    C3, _ = gemm(As, Bs, M, N, K, ak, bk, mask=dev(mask))
+    assert float((C3.cpu().double() - torch.where(mask > 0, want, torch.zeros_like(want))).abs().max()) / scale < 1e-5
+
+
+def test_gemm_exp_and_leading_dims():
+    """fc43's exp epilogue (vae.py:232) and the strided 64-wide head slices of the fused [B,192] buffer."""
+    g = torch.Generator().manual_seed(3)
+    B, z = 37, 32
+    h3 = torch.randn(B, 192, generator=g, dtype=torch.float64)
+    W = torch.randn(z, 64, generator=g, dtype=torch.float64) * 0.1
+    bias = torch.randn(z, generator=g, dtype=torch.float64) * 0.1
+    h3d = dev(h3)
+    for i in range(3):
+        want = torch.exp(h3[:, 64 * i:64 * i + 64] @ W.t() + bias)
+        C, _ = gemm(h3d[:, 64 * i:], dev(W), B, z, 64, 1, 1, bias=dev(bias), act=2, lda=192)
+        assert rel(C.cpu(), want) < 1e-5
+    # dX into a slice of a [B,192] buffer with ldc = 192
+    dmu = torch.randn(B, z, generator=g, dtype=torch.float64)
+    buf = torch.zeros(B, 192, device="cuda")
+    gemm(dev(dmu), dev(W), B, 64, z, 1, 0, ldc=192, C=buf[:, 64:])
+    assert rel(buf[:, 64:128].cpu(), dmu @ W) < 1e-5
+    assert float(buf[:, :64].abs().max()) == 0.0 and float(buf[:, 128:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C", [1, 8, 24, 32])
+def test_bn_stats_and_finalize(C):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C)
+    n = 4 * 128 * 128 if C == 1 else 3000
+    x = torch.randn(n, C, generator=g) * 2 + 0.7
+    partials = torch.zeros(1024, 2 * C, device="cuda")
+    import ctypes
+    nparts = ctypes.c_int()
+    xdev = dev(x)
+    _lib.check(lib.ava_bn_stats(p(xdev), n, C, p(partials), ctypes.byref(nparts), stream()), "bn_stats")
+    gamma, beta = 0.5 + torch.rand(C, generator=g), torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+    rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros(1, dtype=torch.int64, device="cuda")
+    outs = [torch.empty(C, device="cuda") for _ in range(4)]
+    gd, bd = dev(gamma), dev(beta)          # keep the device tensors alive across the launches
+    _lib.check(lib.ava_bn_finalize(p(partials), nparts.value, n, C, p(gd), p(bd), p(rmd), p(rvd), p(nbt),
+                                   1, *[p(o) for o in outs], stream()), "bn_finalize")
+    xd = x.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    assert rel(outs[0].cpu(), mean) < 1e-6 and rel(outs[1].cpu(), invstd) < 1e-6
+    assert rel(outs[2].cpu(), gamma.double() * invstd) < 1e-6
+    assert rel(outs[3].cpu(), beta.double() - mean * gamma.double() * invstd) < 2e-6
+    assert rel(rmd.cpu(), 0.9 * rm.double() + 0.1 * mean) < 1e-6
+    assert rel(rvd.cpu(), 0.9 * rv.double() + 0.1 * var * n / (n - 1)) < 1e-6
+    assert int(nbt.item()) == 1
+    # eval mode: running statistics, buffers untouched
+    _lib.check(lib.ava_bn_finalize(None, 0, n, C, p(gd), p(bd), p(rmd), p(rvd), p(nbt), 0,
+                                   *[p(o) for o in outs], stream()), "bn_finalize eval")
+    assert rel(outs[1].cpu(), 1 / torch.sqrt(rvd.cpu().double() + 1e-5)) < 1e-6 and int(nbt.item()) == 1
+
+
+def test_bn_finalize_bwd():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    C, n, rows = 24, 5000, 37
+    partials = torch.randn(rows, 2 * C, generator=g)
+    gamma, mean, invstd = [torch.rand(C, generator=g) + 0.5 for _ in range(3)]
+    outs = [torch.empty(C, device="cuda") for _ in range(5)]
+    pd_, gd, md, isd = dev(partials), dev(gamma), dev(mean), dev(invstd)
+    _lib.check(lib.ava_bn_finalize_bwd(p(pd_), rows, n, C, p(gd), p(md), p(isd),
+                                       *[p(o) for o in outs], stream()), "bn_finalize_bwd")
+    s = partials.double().sum(0)
+    dB, dG = s[:C], s[C:]
+    a = gamma.double() * invstd.double()
+    b = -gamma.double() * invstd.double() ** 2 * dG / n
+    assert rel(outs[0].cpu(), dG) < 1e-6 and rel(outs[1].cpu(), dB) < 1e-6
+    assert rel(outs[2].cpu(), a) < 1e-6 and rel(outs[3].cpu(), b) < 1e-6
+    assert rel(outs[4].cpu(), -a * dB / n - b * mean.double()) < 1e-5
+
+
+@pytest.mark.parametrize("z", [8, 32, 64, 100])
+def test_latent_forward_backward(z):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(z)
+    B = 19
+    mu, u, a, ed, gdec = [torch.randn(B, z, generator=g, dtype=torch.float64) * 0.7 for _ in range(5)]
+    ew = torch.randn(B, 1, generator=g, dtype=torch.float64)
+    d = torch.exp(a)
+    zs = O.rsample(mu, u, d, ew, ed)
+    H = O.entropy(u, d)
+    dd, zd, sums = torch.empty(B, z, device="cuda"), torch.empty(B, z, device="cuda"), torch.empty(B, 2, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mud, ud, ad, ewd, edd = dev(mu), dev(u), dev(a), dev(ew.reshape(B)), dev(ed)
+    _lib.check(lib.ava_latent_fwd(p(mud), p(ud), p(ad), p(ewd), p(edd), p(dd), p(zd), p(sums), p(status), B, z, stream()), "lat")
+    assert rel(dd.cpu(), d) < 1e-6 and rel(zd.cpu(), zs) < 1e-6
+    assert rel(sums[:, 0].cpu(), (zs * zs).sum(1)) < 1e-6 and rel(sums[:, 1].cpu(), H) < 1e-6
+    assert int(status.item()) == 0
+    dmu, du, da = O.latent_backward(zs + gdec, u, d, ew, ed)
+    o = [torch.empty(B, z, device="cuda") for _ in range(3)]
+    gdd = dev(gdec)
+    _lib.check(lib.ava_latent_bwd(p(zd), p(gdd), p(ud), p(dd), p(ewd), p(edd), p(o[0]), p(o[1]), p(o[2]), B, z, stream()), "latb")
+    assert rel(o[0].cpu(), dmu) < 1e-5 and rel(o[1].cpu(), du) < 1e-5 and rel(o[2].cpu(), da) < 1e-5
+    # d underflows to 0 -> status flag (the reference raises ValueError from argument validation)
+    ad2 = ad.clone()
+    ad2[3, 1] = -200.0
+    _lib.check(lib.ava_latent_fwd(p(mud), p(ud), p(ad2), p(ewd), p(edd), p(dd), p(zd), p(sums), p(status), B, z, stream()), "lat")
+    assert int(status.item()) == 1
+
+
+def test_elbo_finalize_constants():
+    lib = _lib.load()
+    B, z, prec = 5, 32, 10.0
+    lat = torch.rand(B, 2, dtype=torch.float64)
+    sse = torch.rand(7, 2, dtype=torch.float64) * 100
+    out = torch.empty(4, device="cuda")
+    latd, ssed = dev(lat), dev(sse)
+    _lib.check(lib.ava_elbo_finalize(p(latd), B, p(ssed), 7, z, prec, p(out), stream()), "elbo")
+    want = (0.5 * lat[:, 0].sum() + 0.5 * z * math.log(2 * math.pi) + 0.5 * 16384 * math.log(2 * math.pi / prec)
+            + 0.5 * prec * sse[:, 0].sum() - lat[:, 1].sum())
+    assert rel(out[0].cpu(), want) < 1e-6
+
+
+def test_adam_flat_matches_torch_adam():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    n = 4096 * 3
+    p0, m0, v0 = torch.randn(n, generator=g), torch.zeros(n), torch.zeros(n)
+    pd, md, vd = dev(p0), dev(m0), dev(v0)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * (10.0 ** (step - 2))
+        gr[::7] = 0.0
+        ref.grad = gr.clone()
+        opt.step()
+        grd = dev(gr)
+        _lib.check(lib.ava_adam_flat(p(pd), p(grd), p(md), p(vd), n, 1e-3, 0.9, 0.999, 1e-8, step, stream()), "adam")
+        st = opt.state[ref]
+        assert float((pd.cpu() - ref.detach()).abs().max()) < 2e-7
+        assert rel(md.cpu(), st["exp_avg"]) < 1e-6 and rel(vd.cpu(), st["exp_avg_sq"]) < 1e-6
+
+
+def test_fill_normal_matches_fixture_recipe():
+    lib = _lib.load()
+    n = 8 * 33
+    out = torch.empty(n, device="cuda")
+    _lib.check(lib.ava_fill_normal(p(out), n, 2002, 0, stream()), "fill_normal")
+    assert rel(out.cpu(), syn.gauss(n, 2002)) < 1e-6
+    out2 = torch.empty(100, device="cuda")
+    _lib.check(lib.ava_fill_normal(p(out2), 100, 2002, 50, stream()), "fill_normal")
+    assert rel(out2.cpu(), syn.gauss(150, 2002)[50:]) < 1e-6
+    big = torch.empty(1 << 20, device="cuda")
+    _lib.check(lib.ava_fill_normal(p(big), big.numel(), 7, 0, stream()), "fill_normal")
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1) < 5e-3

@@ -1,0 +1,306 @@
+"""Whole-path parity of the HIP VAE (through ava_amd.vae.VAE -> C ABI) against
+(1) golden vectors captured from the real reference (tests/golden/*.npz) and
+(2) the CPU oracle on the same seeded inputs; plus size-independent properties at the
+benchmark's full batch of 256.  Tolerances: ELBO 1e-5 relative (north-star asks 1e-4);
+gradients as in tests/test_oracle_golden.py (fp32 noise floor of the reference itself)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, sample_idx, GOLDEN
+from gpu_util import build_model, rel
+from ava_amd import synthetic as syn
+from ava_amd.layout import param_specs
+from oracle import vae_oracle as O
+
+FLIP_TOL = 2e-2
+GTOL = {8: 1e-4, 64: 1e-2}
+
+
+def fixed_noise(model, B, z, sw=2002, sd=3003):
+    ew, ed = syn.noise(B, z, sw, sd)
+    model.noise_source = lambda b, zz: (ew, ed)
+    return ew, ed
+
+
+@pytest.mark.parametrize("B,z", [(8, 32), (8, 64), (64, 32)])
+def test_train_step_matches_reference_golden(B, z):
+    G = load_golden("step_B%d_z%d.npz" % (B, z))
+    model = build_model(z)
+    fixed_noise(model, B, z)
+    x = torch.from_numpy(syn.spectrograms(B))
+    loss = model.forward(x)
+    lb = model._loss_buf.cpu().numpy()
+    assert rel(float(loss.item()), G["s1.loss"]) < 1e-5
+    assert rel(lb[1], G["s1.sum_z2"]) < 1e-5 and rel(lb[2], G["s1.sse"]) < 1e-5 and rel(lb[3], G["s1.sum_h"]) < 1e-5
+    assert rel(model._workspace_tensor("mu", (B, z))[:2].cpu(), G["s1.mu"]) < 1e-4
+    assert rel(model._workspace_tensor("u", (B, z))[:2].cpu(), G["s1.u"]) < 1e-4
+    assert rel(model._workspace_tensor("d", (B, z))[:2].cpu(), G["s1.d"]) < 1e-4
+    assert rel(model._workspace_tensor("z", (B, z))[:2].cpu(), G["s1.z"]) < 1e-4
+    xr = model._workspace_tensor("xrec", (B * 16384,)).cpu().numpy()
+    assert rel(xr[G["s1.xrec_idx"]], G["s1.xrec"]) < 1e-4
+    bn_save = model._workspace_tensor("bn_save", (14, 4, 32)).cpu().numpy()
+    for i in range(1, 15):
+        c = len(G["s1.bn%d.mean" % i])
+        assert rel(bn_save[i - 1, 0, :c], G["s1.bn%d.mean" % i]) < 1e-4
+        assert rel(1.0 / bn_save[i - 1, 1, :c] ** 2 - 1e-5, G["s1.bn%d.var" % i]) < 1e-4
+    loss.backward()
+    named = dict(model.named_parameters())
+    for s in param_specs(z):
+        g = named[s.name].grad.cpu().numpy().ravel()
+        sens = s.layer in ("conv1", "bn1")
+        tol = FLIP_TOL if sens else GTOL[B]
+        ref_scale = max(float(G["s1.gradnorm." + s.name]), float(G["s1.gradnorm.conv1.bias"]) if sens else 0.0)
+        gn = np.sqrt((g.astype(np.float64) ** 2).sum())
+        assert abs(gn - float(G["s1.gradnorm." + s.name])) < tol * ref_scale, s.name
+        scale = max(np.abs(g).max(), ref_scale if sens else 0.0)
+        np.testing.assert_allclose(g[sample_idx(g.size, s.index)], G["s1.grad." + s.name], rtol=10 * tol,
+                                   atol=tol * scale, err_msg=s.name)
+    for i in range(1, 15):
+        bn = getattr(model, "bn%d" % i)
+        assert rel(bn.running_mean.cpu(), G["s1.bn%d.running_mean" % i]) < 1e-5
+        assert rel(bn.running_var.cpu(), G["s1.bn%d.running_var" % i]) < 1e-5
+        assert int(bn.num_batches_tracked) == int(G["s1.bn%d.num_batches_tracked" % i])
+    model.optimizer.step()
+    st = model.optimizer.state_dict()["state"]
+    for s in param_specs(z):
+        idx = sample_idx(s.numel, s.index)
+        sens = s.layer in ("conv1", "bn1")
+        tol = FLIP_TOL if sens else GTOL[B]
+        gs = float(G["s1.gradnorm.conv1.bias"]) if sens else 0.0
+        m = st[s.index]["exp_avg"].cpu().numpy().ravel()
+        v = st[s.index]["exp_avg_sq"].cpu().numpy().ravel()
+        np.testing.assert_allclose(m[idx], G["s1.exp_avg." + s.name], rtol=20 * tol, atol=tol * max(np.abs(m).max(), 0.1 * gs))
+        np.testing.assert_allclose(v[idx], G["s1.exp_avg_sq." + s.name], rtol=40 * tol,
+                                   atol=tol * max(np.abs(v).max(), 1e-3 * gs * gs))
+        pv = named[s.name].detach().cpu().numpy().ravel()
+        np.testing.assert_allclose(pv[idx], G["s1.val." + s.name], rtol=0, atol=2.2e-3)
+        assert float(st[s.index]["step"]) == float(G["s1.adam_step"])
+
+
+def test_three_steps_then_eval_matches_golden():
+    """Loss trajectory over three Adam steps and the eval-mode (running statistics) forward."""
+    B, z = 8, 32
+    G = load_golden("step_B8_z32.npz")
+    model = build_model(z)
+    fixed_noise(model, B, z)
+    x = torch.from_numpy(syn.spectrograms(B))
+    for step in (1, 2, 3):
+        model.optimizer.zero_grad()
+        loss = model.forward(x)
+        assert rel(float(loss.item()), G["s%d.loss" % step]) < (1e-5 if step == 1 else 1e-4)
+        loss.backward()
+        model.optimizer.step()
+    for i in range(1, 15):
+        assert rel(getattr(model, "bn%d" % i).running_var.cpu(), G["final.bn%d.running_var" % i]) < 1e-4
+    model.eval()
+    with torch.no_grad():
+        assert rel(float(model.forward(x).item()), G["eval.loss"]) < 2e-3
+    fresh = build_model(z, train=False)
+    fixed_noise(fresh, B, z)
+    with torch.no_grad():
+        assert rel(float(fresh.forward(x).item()), G["eval_fresh.loss"]) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 5, 37])
+def test_forward_backward_matches_oracle_odd_batches(B):
+    """Ragged batch sizes (visualize uses 5, shotgun_movie batch 1: vae.py:503-510, shotgun_movie.py:116-120)."""
+    z = 32
+    model = build_model(z)
+    ew, ed = fixed_noise(model, B, z, 11, 12)
+    x = torch.from_numpy(syn.spectrograms(B, salt=77))
+    loss = model.forward(x)
+    loss.backward()
+    P = O.to_params(syn.fixture_parameters(z), requires_grad=True)
+    out = O.forward(P, x, torch.from_numpy(ew), torch.from_numpy(ed), None, True)
+    out["loss"].backward()
+    assert rel(float(loss.item()), float(out["loss"])) < 1e-5
+    named = dict(model.named_parameters())
+    bad = []
+    for s in param_specs(z):
+        g = named[s.name].grad.cpu().double().numpy().ravel()
+        w = P[s.name].grad.double().numpy().ravel()
+        e = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-30)
+        # loose on purpose: a single ReLU pre-activation within an ulp of zero flips its mask between two
+        # fp32 evaluations and moves every gradient upstream of it by O(1e-3); the kernels themselves are
+        # pinned at 2e-5 with the masks as inputs in test_gpu_kernels.py, the whole path at B=8 by the goldens
+        if e > 5e-2:
+            bad.append((s.name, e))
+    assert not bad, bad
+
+
+def test_encode_decode_and_get_latent_golden():
+    """get_latent on a fresh module runs BatchNorm in TRAIN mode and keeps updating the running
+    statistics (vae.py:538-547 never calls eval())."""
+    G = load_golden("get_latent.npz")
+    model = build_model(32)
+    loader = syn.get_synthetic_data_loaders(16, batch_size=8, shuffle=(False, False))["train"]
+    lat = model.get_latent(loader)
+    assert lat.dtype == np.float64 and lat.shape == (16, 32)
+    assert rel(lat, G["latent"]) < 1e-4
+    for i in range(1, 8):
+        assert rel(getattr(model, "bn%d" % i).running_mean.cpu(), G["after.bn%d.running_mean" % i]) < 1e-5
+        assert int(getattr(model, "bn%d" % i).num_batches_tracked) == 2
+    for i in range(8, 15):
+        assert int(getattr(model, "bn%d" % i).num_batches_tracked) == 0
+    # encode -> (mu,u,d), decode(z) consistent with forward's x_rec
+    B = 6
+    model2 = build_model(32)
+    ew, ed = fixed_noise(model2, B, 32)
+    x = torch.from_numpy(syn.spectrograms(B))
+    with torch.no_grad():
+        _, zs, rec = model2.forward(x, return_latent_rec=True)
+        mu, u, d = model2.encode(x)
+        assert u.shape == (B, 32, 1) and d.min() > 0
+        z2 = mu + u[..., 0] * torch.from_numpy(ew).cuda() + torch.sqrt(d) * torch.from_numpy(ed).cuda()
+        assert rel(z2.cpu(), zs) < 1e-5
+        rec2 = model2.decode(torch.from_numpy(zs))
+        assert rec2.shape == (B, 16384) and rel(rec2.cpu().numpy().reshape(B, 128, 128), rec) < 1e-5
+
+
+def test_two_shard_data_parallel_equivalence():
+    """an N-rank step == each shard stepped from identical weights with its own noise,
+    gradients summed.  Emulated on one GPU; pinned by the reference-generated ddp2 golden."""
+    G = load_golden("ddp2.npz")
+    x = syn.spectrograms(16)
+    ew, ed = syn.noise(16, 32)
+    total = None
+    for r in range(2):
+        model = build_model(32)
+        sl = slice(8 * r, 8 * r + 8)
+        model.noise_source = lambda b, zz, sl=sl: (ew[sl], ed[sl])
+        loss = model.forward(torch.from_numpy(x[sl]))
+        assert rel(float(loss.item()), G["shard%d.loss" % r]) < 1e-5
+        loss.backward()
+        g = model._grads.double().clone()
+        total = g if total is None else total + g
+    for s in param_specs(32):
+        o, n, _ = model._arena_views[s.name]
+        gn = float(total[o:o + n].norm())
+        sens = s.layer in ("conv1", "bn1")
+        ref_scale = max(float(G["gradnorm." + s.name]), float(G["gradnorm.conv1.bias"]) if sens else 0.0)
+        assert abs(gn - float(G["gradnorm." + s.name])) < (FLIP_TOL if sens else 1e-3) * ref_scale, s.name
+
+
+def test_harness_train_loop_checkpoint_golden(tmp_path):
+    """train_epoch / test_epoch / train_loop side effects and the checkpoint layout (vae.py:330-472)."""
+    G = load_golden("harness.npz")
+    manifest = json.load(open(os.path.join(GOLDEN, "checkpoint_manifest.json")))
+    B, nb, z = 8, 2, 32
+    from ava_amd.vae import VAE
+    model = build_model(z)
+    model.save_dir = str(tmp_path)
+    loaders = syn.get_synthetic_data_loaders(B * nb, batch_size=B, shuffle=(False, False))
+    loaders["test"] = loaders["train"]
+    queue = []
+    for tag in (0, 100, 1, 101):
+        for k in range(nb):
+            queue.append(syn.noise(B, z, 2002 + 10 * k + tag, 3003 + 10 * k + tag))
+    model.noise_source = lambda b, zz: queue.pop(0)
+    model.train_loop(loaders, epochs=2, test_freq=1, save_freq=1, vis_freq=None)
+    assert not queue
+    assert model.epoch == int(G["epoch"]) == 2
+    assert rel(model.loss["train"][0], G["train_loss"][0]) < 1e-5
+    assert rel(model.loss["test"][0], G["test_loss"][0]) < 1e-3          # behind the first Adam step
+    assert rel(model.loss["train"][1], G["train_loss"][1]) < 1e-3
+    assert sorted(os.listdir(tmp_path)) == manifest["files"] == ["checkpoint_001.tar"]
+    ck = torch.load(os.path.join(tmp_path, "checkpoint_001.tar"), weights_only=True)
+    assert list(ck.keys()) == manifest["keys"]
+    assert ck["epoch"] == manifest["epoch"] and ck["z_dim"] == manifest["z_dim"] and ck["lr"] == manifest["lr"]
+    for name, entries in manifest["layers"].items():
+        assert list(ck[name].keys()) == manifest["layer_key_order"][name], name
+        for k, (shape, dtype) in entries.items():
+            assert list(ck[name][k].shape) == shape and str(ck[name][k].dtype) == dtype, (name, k)
+    pg = ck["optimizer_state"]["param_groups"]
+    assert len(pg) == 1
+    for k, v in manifest["param_groups"][0].items():
+        got = pg[0][k]
+        assert (list(got) if isinstance(got, (tuple, list)) else got) == v, k
+    st = ck["optimizer_state"]["state"]
+    assert sorted(st.keys()) == list(range(80))
+    for i, entries in manifest["opt_state"].items():
+        for k, (shape, dtype) in entries.items():
+            assert list(st[int(i)][k].shape) == shape and str(st[int(i)][k].dtype) == dtype
+    assert {k: sorted(v.keys()) for k, v in ck["loss"].items()} == manifest["loss_keys"]
+    # resume: construct + load_state reproduces the eval loss of the trained model bit for bit
+    model.eval()
+    x = torch.from_numpy(syn.spectrograms(B))
+    ew, ed = syn.noise(B, z)
+    model.noise_source = lambda b, zz: (ew, ed)
+    with torch.no_grad():
+        want = float(model.forward(x).item())
+    m2 = VAE(save_dir=str(tmp_path), z_dim=z, device_name="cuda")
+    m2.load_state(os.path.join(tmp_path, "checkpoint_001.tar"))   # load_state takes the path as given (vae.py:464)
+    assert m2.epoch == 2 and m2.loss["train"].keys() == model.loss["train"].keys()
+    m2.eval()
+    m2.noise_source = model.noise_source
+    with torch.no_grad():
+        assert float(m2.forward(x).item()) == want
+    # a resumed step equals a continued step (Adam state restored)
+    model.train(); m2.train()
+    for mm in (model, m2):
+        mm.optimizer.zero_grad()
+        mm.forward(x).backward()
+        mm.optimizer.step()
+    assert torch.equal(model._params, m2._params)
+    with pytest.raises(AssertionError):
+        VAE(z_dim=64, device_name="cuda").load_state(os.path.join(tmp_path, "checkpoint_001.tar"))
+
+
+def test_visualize_writes_pdf(tmp_path):
+    model = build_model(32)
+    model.save_dir = str(tmp_path)
+    loaders = syn.get_synthetic_data_loaders(12, batch_size=4)
+    specs, rec = model.visualize(loaders["train"])
+    assert specs.shape == rec.shape == (5, 128, 128)
+    assert os.path.exists(os.path.join(tmp_path, "reconstruction.pdf"))
+    with pytest.raises(AssertionError):
+        model.visualize(loaders["train"], num_specs=13)
+
+
+def test_invalid_posterior_raises_value_error():
+    """d = exp(.) overflowing to inf/NaN -> the reference's distribution validation raises ValueError."""
+    model = build_model(32)
+    with torch.no_grad():
+        model.fc43.bias.fill_(float("nan"))
+    with pytest.raises(ValueError):
+        model.forward(torch.from_numpy(syn.spectrograms(4)))
+
+
+def test_full_batch_properties():
+    """B = 256 (the benchmark's size): run-to-run bit determinism (no float atomics anywhere), the
+    fused SSE / sum z^2 reductions against torch reductions of the kernels' own outputs, gradient
+    finiteness, and step-to-step loss decrease under Adam."""
+    B, z = 256, 32
+    x = torch.from_numpy(syn.spectrograms(B, salt=4242)).cuda()
+    ew, ed = syn.noise(B, z, 5, 6)
+    runs = []
+    for _ in range(2):
+        model = build_model(z)
+        model.noise_source = lambda b, zz: (ew, ed)
+        loss = model.forward(x)
+        loss.backward()
+        runs.append((float(loss.item()), model._grads.clone()))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert bool(torch.isfinite(runs[0][1]).all())
+    xr = model._workspace_tensor("xrec", (B, 16384))
+    zs = model._workspace_tensor("z", (B, z))
+    lb = model._loss_buf.cpu().double().numpy()
+    assert rel(lb[2], float(((x.view(B, -1).double() - xr.double()) ** 2).sum())) < 1e-6
+    assert rel(lb[1], float((zs.double() ** 2).sum())) < 1e-6
+    seed = model._workspace_tensor("seed", (B, 16384))
+    assert rel(seed.cpu(), (10.0 * (xr - x.view(B, -1))).cpu()) < 1e-6
+    losses = []
+    for _ in range(5):
+        model.optimizer.zero_grad()
+        l = model.forward(x)
+        l.backward()
+        model.optimizer.step()
+        losses.append(float(l.item()))
+    assert losses[-1] < losses[0]

@@ -16,91 +16,9 @@
 // owns one output pixel x all output channels; the weights are wave-uniform and are fetched with
 // scalar loads.  Per-channel statistics are accumulated in registers across all tiles of the
 // workgroup and written once as a deterministic partial row (no float atomics).
-#include "common.h"
-
-enum { MODE_S1 = 0, MODE_DOWN = 1, MODE_UP = 2 };
-enum { PRO_BN = 0, PRO_BWD = 1, PRO_ID = 2 };
-enum { EPI_FWD = 0, EPI_BWD = 1, EPI_SSE = 2 };
-
-struct ConvArgs {
-  const float* in;
-  const float* in2;
-  const float* pa;
-  const float* pb;
-  const float* pc;
-  const float* G;
-  const float* bias;
-  float* out;
-  float* out2;
-  const float* epi_x;
-  const float* epi_mean;
-  const float* epi_invstd;
-  float* partials;
-  int B, Hi, Wi, Ho, Wo;
-  int relu;
-  float prec;
-  int tiles_y, tiles_x, ntiles;
-};
-
-template <int MODE, int TW>
-struct Geom {
-  static constexpr int TH = 256 / TW;
-  static constexpr int IR = MODE == MODE_S1 ? TH + 2 : (MODE == MODE_DOWN ? 2 * TH + 1 : TH / 2 + 1);
-  static constexpr int IC = MODE == MODE_S1 ? TW + 2 : (MODE == MODE_DOWN ? 2 * TW + 1 : TW / 2 + 1);
-};
-
-// prologue on one value of channel c
-template <int PRO>
-__device__ __forceinline__ float prologue(float v, float v2, float a, float b, float c) {
-  if (PRO == PRO_BN) return fmaf(v, a, b);
-  if (PRO == PRO_BWD) return v2 > 0.f ? fmaf(a, v, fmaf(b, v2, c)) : 0.f;
-  return v;
-}
-
-// stage a [R x C x CIN] window of `in` (origin gy0,gx0; out-of-bounds -> 0 AFTER the prologue) into LDS
-template <int CIN, int PRO, int R, int C>
-__device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float* __restrict__ in,
-                                           const float* __restrict__ in2, const float* coef, int b, int Hi, int Wi,
-                                           int gy0, int gx0) {
-  const int t = threadIdx.x;
-  if constexpr (CIN % 4 == 0) {
-    constexpr int Q = CIN / 4;
-    constexpr int NV = R * C * Q;
-    for (int v = t; v < NV; v += 256) {
-      const int pix = v / Q, q = v - pix * Q;
-      const int r = pix / C, c = pix - r * C;
-      const int gy = gy0 + r, gx = gx0 + c;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) {
-        const size_t off = (((size_t)b * Hi + gy) * Wi + gx) * CIN + 4 * q;
-        const float4 x = *reinterpret_cast<const float4*>(in + off);
-        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO == PRO_BWD) y = *reinterpret_cast<const float4*>(in2 + off);
-        const float* ca = coef + 4 * q;
-        o.x = prologue<PRO>(x.x, y.x, ca[0], ca[32 + 0], ca[64 + 0]);
-        o.y = prologue<PRO>(x.y, y.y, ca[1], ca[32 + 1], ca[64 + 1]);
-        o.z = prologue<PRO>(x.z, y.z, ca[2], ca[32 + 2], ca[64 + 2]);
-        o.w = prologue<PRO>(x.w, y.w, ca[3], ca[32 + 3], ca[64 + 3]);
-      }
-      *reinterpret_cast<float4*>(lds + (size_t)pix * CIN + 4 * q) = o;
-    }
-  } else {
-    constexpr int NV = R * C * CIN;
-    for (int v = t; v < NV; v += 256) {
-      const int pix = v / CIN, ch = v - pix * CIN;
-      const int r = pix / C, c = pix - r * C;
-      const int gy = gy0 + r, gx = gx0 + c;
-      float o = 0.f;
-      if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) {
-        const size_t off = (((size_t)b * Hi + gy) * Wi + gx) * CIN + ch;
-        const float x = in[off];
-        const float y = PRO == PRO_BWD ? in2[off] : 0.f;
-        o = prologue<PRO>(x, y, coef[ch], coef[32 + ch], coef[64 + ch]);
-      }
-      lds[v] = o;
-    }
-  }
-}
+#include <stdlib.h>
+#include <string.h>
+#include "conv_common.h"
 
 // acc[co] += sum_ci px[ci] * Gt[ci][co]   (Gt wave-uniform -> scalar loads)
 template <int CIN, int COUT>
@@ -257,19 +175,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------------
 // weight / bias gradient: dG[t][ci][co] = sum_pixels xhat(in-pos(t)) * dU(out-pos), db[co] = sum dU
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-  const float* x;      // raw layer input [B,Hi,Wi,CIN]; prologue 0 with xa, xb
-  const float* xa;
-  const float* xb;
-  const float* dy;     // [B,Ho,Wo,COUT]
-  const float* dy2;
-  const float* da;
-  const float* db;
-  const float* dc;
-  float* partials;     // [grid][9*CIN*COUT + COUT]
-  int B, Hi, Wi, Ho, Wo;
-  int tiles_y, tiles_x, ntiles;
-};
 
 template <int CIN, int COUT, int MODE, int DYPRO, int TW>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
@@ -424,32 +329,52 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 }
 
 // dw (reference layout [c0][c1][9]) from partial dG rows; kind 0: conv (G[t][ci=c1][co=c0]),
-// kind 1: convT s1 (G[8-t][c0][c1]), kind 2: convT s2 (G[t][c0][c1]).  fp64 accumulation over rows.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ dw,
-                                    float* __restrict__ dbias, int cin, int cout, int kind) {
+// kind 1: convT s1 (G[8-t][c0][c1]), kind 2: convT s2 (G[t][c0][c1]).
+// 256 threads = 32 row entries x 8 row groups: reads are coalesced along a partial row, the rows are
+// summed in fp64 in a fixed order (deterministic), the (tiny) result is scattered to the weight layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts,
+                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                           int cin, int cout, int kind) {
+  __shared__ double red[8][33];
   const int nw = 9 * cin * cout, row = nw + cout;
-  const int c0 = kind == 0 ? cout : cin, c1 = kind == 0 ? cin : cout;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nw) {
-    const int tt = i % 9, r = i / 9, i1 = r % c1, i0 = r / c1;
-    int gi;
-    if (kind == 0) gi = (tt * cin + i1) * cout + i0;
-    else if (kind == 1) gi = ((8 - tt) * cin + i0) * cout + i1;
-    else gi = (tt * cin + i0) * cout + i1;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)partials[(size_t)p * row + gi];
-    dw[i] = (float)s;
-  } else if (i < nw + cout) {
-    const int co = i - nw;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)partials[(size_t)p * row + nw + co];
-    dbias[co] = (float)s;
+  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int gi = blockIdx.x * 32 + e;                 // index inside a partial row
+  double s = 0.0;
+  if (gi < row)
+    for (int p = rg; p < nparts; p += 8) s += (double)partials[(size_t)p * row + gi];
+  red[rg][e] = s;
+  __syncthreads();
+  if (rg == 0 && gi < row) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k][e];
+    if (gi >= nw) { dbias[gi - nw] = (float)tot; return; }
+    // gi = (tg*cin + a)*cout + b  in gather form G[tg][cin index a][cout index b]
+    const int b = gi % cout, r = gi / cout, a = r % cin, tg = r / cin;
+    int i;
+    if (kind == 0) i = (b * cin + a) * 9 + tg;                 // W[co=b][ci=a][t]
+    else if (kind == 1) i = (a * cout + b) * 9 + (8 - tg);     // Wt[ci=a][co=b][8-t]
+    else i = (a * cout + b) * 9 + tg;                          // Wt[ci=a][co=b][t]
+    dw[i] = (float)tot;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st);
+int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);
+
+// AVA_CONV_IMPL=valu forces the version-0 VALU kernels everywhere (A/B comparisons, debugging)
+static bool use_mfma() {
+  static int cached = -1;
+  if (cached < 0) {
+    const char* e = getenv("AVA_CONV_IMPL");
+    cached = (e != nullptr && strcmp(e, "valu") == 0) ? 0 : 1;
+  }
+  return cached == 1;
+}
+
 static int tile_w(int Wo) { return Wo >= 32 ? 32 : 16; }
 
 static int conv_geometry(int B, int Ho, int Wo, int* tiles_y, int* tiles_x) {
@@ -520,6 +445,10 @@ extern "C" int ava_conv3x3(const float* in, const float* in2, const float* pa, c
   const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
   const int tw = tile_w(a.Wo);
   hipStream_t st = to_stream(s);
+  if (use_mfma() && epi != EPI_SSE) {
+    const int rc = ava_conv3x3_mfma(a, grid, Cin, Cout, mode, pro, epi, st);
+    if (rc != AVA_EINVAL) return rc;       // AVA_EINVAL: no matrix-core instantiation for this shape
+  }
 #define AVA_CONV_CASE(ci, co, md, tww) \
   if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_conv_pe<ci, co, md, tww>(a, grid, pro, epi, st);
   // encoder forward / decoder backward-data shapes
@@ -577,6 +506,10 @@ extern "C" int ava_conv3x3_wgrad(const float* x, const float* xa, const float* x
   const int grid = a.ntiles < 512 ? a.ntiles : 512;
   const int tw = tile_w(a.Wo);
   hipStream_t st = to_stream(s);
+  if (use_mfma()) {
+    const int rc = ava_conv3x3_wgrad_mfma(a, grid, Cin, Cout, mode, dy_pro, st);
+    if (rc != AVA_EINVAL) return rc;
+  }
 #define AVA_WG_CASE(ci, co, md, tww)                                                          \
   if (Cin == ci && Cout == co && mode == md && tw == tww) {                                   \
     if (dy_pro == PRO_BWD) return launch_wgrad<ci, co, md, PRO_BWD, tww>(a, grid, st);        \
@@ -616,7 +549,7 @@ extern "C" int ava_conv_wgrad_reduce(const float* partials, int nparts, float* d
                                      int kind, ava_stream_t s) {
   if (partials == nullptr || dw == nullptr || dbias == nullptr || kind < 0 || kind > 2) return AVA_EINVAL;
   const int n = 9 * Cin * Cout + Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, to_stream(s), partials, nparts, dw,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n, 32)), dim3(256), 0, to_stream(s), partials, nparts, dw,
                      dbias, Cin, Cout, kind);
   AVA_CHECK_LAUNCH();
   return AVA_OK;

@@ -1,0 +1,519 @@
+// Matrix-core version of the 3x3 gather convolutions (forward and backward-data of every conv / convT
+// layer whose channel counts are multiples of 8), gfx950, exact fp32 (v_mfma_f32_16x16x4_f32).
+//
+// Implicit GEMM per output tile:  D[cout][pixel] += A[cout][k] * B[k][pixel],  k = (tap, cin).
+//   * B comes from the NHWC input tile staged in LDS (prologue already applied, zero padding in the
+//     post-BatchNorm domain).  One ds_read_b128 per lane fetches 4 consecutive input channels of
+//     "its" pixel for "its" tap; element j of that read is the K-slot of MFMA j, so one LDS read feeds
+//     4 MFMAs (the K order inside a 16-wide chunk is permuted identically for A and B).
+//   * A (the weights, <= 6912 floats per layer) lives in registers for the whole kernel: lane
+//     (m = lane&15, kg = lane>>4) keeps G[k = 16c+4kg+j][cout = 16mt+m] for every chunk c, j, mt.
+//   * D: lane holds 4 consecutive output channels of one pixel -> one 16-byte NHWC store per lane,
+//     1 KiB contiguous per wave instruction; bias/ReLU/BN statistics fused in registers.
+// A workgroup (4 waves) walks a list of output tiles; each wave owns groups of 16 consecutive output
+// pixels of a row (for the x2-upsampling pattern: of one output-parity class, so the tap set is uniform).
+#include "conv_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- tap sets ------------------------------------------------------------------------------------
+// S1 / DOWN: one class with all 9 taps.  UP: class = (oy&1)*2 + (ox&1); a tap (ky,kx) exists for
+// oy parity py iff (py ? ky != 1 : ky == 1), same for kx.
+template <int MODE> __host__ __device__ constexpr int n_classes() { return MODE == MODE_UP ? 4 : 1; }
+template <int MODE> __host__ __device__ constexpr int n_taps(int cls) {
+  return MODE != MODE_UP ? 9 : (cls == 0 ? 1 : (cls == 3 ? 4 : 2));
+}
+// t-th tap of a class -> (ky, kx)
+template <int MODE> __host__ __device__ constexpr int tap_ky(int cls, int t) {
+  if (MODE != MODE_UP) return t / 3;
+  const int py = cls >> 1, px = cls & 1;
+  const int nkx = px ? 2 : 1;
+  const int iy = t / nkx;
+  return py ? 2 * iy : 1;
+}
+template <int MODE> __host__ __device__ constexpr int tap_kx(int cls, int t) {
+  if (MODE != MODE_UP) return t % 3;
+  const int px = cls & 1;
+  const int nkx = px ? 2 : 1;
+  const int ix = t % nkx;
+  return px ? 2 * ix : 1;
+}
+
+// per-lane, per-class constants: LDS offsets of the chunk reads and the A (weight) fragments
+template <int CIN, int COUT, int MODE, int CLS, int IC>
+struct ClassFrag {
+  static constexpr int KTOT = n_taps<MODE>(CLS) * CIN;
+  static constexpr int NCH = (KTOT + 15) / 16;
+  static constexpr int MT = (COUT + 15) / 16;
+  int off[NCH];
+  float w[NCH][4][MT];
+
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane) {
+    const int m = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = 16 * c + 4 * kg;
+      const bool valid = k < KTOT;
+      const int t = valid ? k / CIN : 0;
+      const int ci = valid ? k - t * CIN : 0;
+      int ky = 0, kx = 0;
+      // (ky,kx) of the t-th tap of this class; t is lane dependent only through kg (<= 4 values)
+#pragma unroll
+      for (int tt = 0; tt < n_taps<MODE>(CLS); ++tt)
+        if (tt == t) { ky = tap_ky<MODE>(CLS, tt); kx = tap_kx<MODE>(CLS, tt); }
+      int dr, dc;
+      if (MODE == MODE_UP) { dr = ky == 0 ? 1 : 0; dc = kx == 0 ? 1 : 0; }
+      else { dr = ky; dc = kx; }
+      off[c] = (dr * IC + dc) * CIN + ci;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int co = 16 * mt + m;
+          w[c][j][mt] = (valid && co < COUT) ? G[((ky * 3 + kx) * CIN + ci + j) * COUT + co] : 0.f;
+        }
+    }
+  }
+
+  // acc[2][MT] += over all chunks; px = LDS address of this lane's pixel (tap (0,0), channel 0)
+  __device__ __forceinline__ void run(const float* __restrict__ px, f32x4 (&acc)[2][MT]) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 b = *reinterpret_cast<const float4*>(px + off[c]);
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[j & 1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][j][mt], bv[j], acc[j & 1][mt], 0, 0, 0);
+    }
+  }
+};
+
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
+  using G = Geom<MODE, TW, TH>;
+  constexpr int IR = G::IR, IC = G::IC;
+  constexpr int MT = (COUT + 15) / 16;
+  constexpr int NCLS = n_classes<MODE>();
+  extern __shared__ __align__(16) float smem[];
+  float* tile = smem;                       // [IR*IC*CIN]
+  float* coef = smem + IR * IC * CIN;       // [3][32]
+  float* red = coef + 96;                   // [4][2*16*MT]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = lane & 15, kg = lane >> 4;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
+    coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
+  }
+
+  ClassFrag<CIN, COUT, MODE, 0, IC> f0;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC> f1;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC> f2;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC> f3;
+  f0.init(a.G, lane);
+  if (NCLS > 1) { f1.init(a.G, lane); f2.init(a.G, lane); f3.init(a.G, lane); }
+
+  // epilogue constants for this lane's 4 output channels per cout tile
+  float bias[MT][4], emean[MT][4], einv[MT][4];
+  float s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * mt + 4 * kg + r;
+      bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
+      emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
+      einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
+      s1[mt][r] = s2[mt][r] = 0.f;
+    }
+
+  constexpr int GROUPS = (MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16);
+  constexpr int GPW = GROUPS / 4;           // groups per wave
+  static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
+
+  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+    const int b = tl / (a.tiles_y * a.tiles_x);
+    const int rem = tl - b * (a.tiles_y * a.tiles_x);
+    const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
+    int gy0, gx0;
+    if (MODE == MODE_S1) { gy0 = oy0 - 1; gx0 = ox0 - 1; }
+    else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
+    else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
+    __syncthreads();
+    stage_tile<CIN, PRO, IR, IC>(tile, a.in, a.in2, coef, b, a.Hi, a.Wi, gy0, gx0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int g = wave * GPW + gi;
+      f32x4 acc[2][MT];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int oy, ox;        // this lane's output pixel inside the tile
+      if (MODE == MODE_UP) {
+        // TW/2 = 16 columns per parity class and row: group = (r, class)
+        const int cls = g & 3, r = g >> 2;
+        const float* px = tile + (r * IC + n) * CIN;
+        if (cls == 0) f0.run(px, acc);
+        else if (cls == 1) f1.run(px, acc);
+        else if (cls == 2) f2.run(px, acc);
+        else f3.run(px, acc);
+        oy = 2 * r + (cls >> 1);
+        ox = 2 * n + (cls & 1);
+      } else {
+        constexpr int GPR = TW / 16;
+        constexpr int S = MODE == MODE_S1 ? 1 : 2;
+        const int ty = g / GPR, tx = 16 * (g % GPR) + n;
+        f0.run(tile + ((S * ty) * IC + S * tx) * CIN, acc);
+        oy = ty;
+        ox = tx;
+      }
+      const size_t opix = ((size_t)b * a.Ho + oy0 + oy) * a.Wo + ox0 + ox;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb = 16 * mt + 4 * kg;
+        if (cb < COUT) {
+          f32x4 v = acc[0][mt] + acc[1][mt];
+          if (EPI == EPI_FWD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = v[r] + bias[mt][r];
+              if (a.relu) x = fmaxf(x, 0.f);
+              v[r] = x;
+              s1[mt][r] += x;
+              s2[mt][r] = fmaf(x, x, s2[mt][r]);
+            }
+          } else {   // EPI_BWD
+            const float4 xr = *reinterpret_cast<const float4*>(a.epi_x + opix * COUT + cb);
+            const float xv[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float xh = (xv[r] - emean[mt][r]) * einv[mt][r];
+              s1[mt][r] += v[r];
+              s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+            }
+          }
+          if (a.out != nullptr)
+            *reinterpret_cast<float4*>(a.out + opix * COUT + cb) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  }
+
+  // ---- per-workgroup partial statistics: reduce over the 16 pixel lanes, then over the 4 waves ----
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v1 = s1[mt][r], v2 = s2[mt][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+      if (n == 0) {
+        const int co = 16 * mt + 4 * kg + r;
+        red[wave * 32 * MT + co] = v1;
+        red[wave * 32 * MT + 16 * MT + co] = v2;
+      }
+    }
+  __syncthreads();
+  if (t < 2 * COUT && a.partials != nullptr) {
+    const int which = t / COUT, co = t - which * COUT;
+    const int idx = which * 16 * MT + co;
+    a.partials[(size_t)blockIdx.x * 2 * COUT + t] =
+        (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
+static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
+  using G = Geom<MODE, TW, TH>;
+  constexpr int MT = (COUT + 15) / 16;
+  const size_t lds = (size_t)(G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AVA_ELAUNCH;
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.tiles_y = a.Ho / TH;
+  b.tiles_x = a.Wo / TW;
+  b.ntiles = a.B * b.tiles_y * b.tiles_x;
+  if (grid > b.ntiles) return AVA_EINVAL;
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>), dim3(grid), dim3(256), lds, st, b);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+template <int CIN, int COUT, int MODE, int TW, int TH>
+static int launch_mfma_pe(const ConvArgs& a, int grid, int pro, int epi, hipStream_t st) {
+  if (pro == PRO_BN && epi == EPI_FWD) return launch_mfma<CIN, COUT, MODE, PRO_BN, EPI_FWD, TW, TH>(a, grid, st);
+  if (pro == PRO_BWD && epi == EPI_BWD) return launch_mfma<CIN, COUT, MODE, PRO_BWD, EPI_BWD, TW, TH>(a, grid, st);
+  if (pro == PRO_ID && epi == EPI_BWD) return launch_mfma<CIN, COUT, MODE, PRO_ID, EPI_BWD, TW, TH>(a, grid, st);
+  return AVA_EINVAL;
+}
+
+// returns AVA_EINVAL when the shape has no matrix-core instantiation (caller falls back to the VALU kernel)
+// `grid` = number of workgroups = number of partial rows (the caller's ava_conv_grid value)
+int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
+  const int tw = a.Wo >= 32 ? 32 : 16;
+#define AVA_MFMA_CASE(ci, co, md, tww, thh) \
+  if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_mfma_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
+  AVA_MFMA_CASE(8, 8, MODE_DOWN, 32, 4)
+  AVA_MFMA_CASE(8, 16, MODE_S1, 32, 8)
+  AVA_MFMA_CASE(16, 16, MODE_DOWN, 32, 4)
+  AVA_MFMA_CASE(16, 24, MODE_S1, 32, 8)
+  AVA_MFMA_CASE(24, 24, MODE_DOWN, 16, 8)
+  AVA_MFMA_CASE(24, 32, MODE_S1, 16, 16)
+  AVA_MFMA_CASE(32, 24, MODE_S1, 16, 16)
+  AVA_MFMA_CASE(24, 24, MODE_UP, 32, 8)
+  AVA_MFMA_CASE(24, 16, MODE_S1, 32, 8)
+  AVA_MFMA_CASE(16, 16, MODE_UP, 32, 8)
+  AVA_MFMA_CASE(16, 8, MODE_S1, 32, 8)
+  AVA_MFMA_CASE(8, 8, MODE_UP, 32, 8)
+#undef AVA_MFMA_CASE
+  return AVA_EINVAL;
+}
+
+// ================================================================================================
+// weight / bias gradient on the matrix cores:  dG[(tap,ci)][co] = sum_pixels xhat(in-pos)[ci] * dU(pixel)[co]
+//   M = (tap, ci) rows (A operand, read from the staged input tile), N = co (B operand, read from the
+//   staged dU tile), K = output pixels, 4 consecutive pixels of a row per MFMA.
+// Every wave sweeps a quarter of each tile's pixels into a full set of accumulators that lives in registers
+// across ALL tiles of the workgroup; at the end the four waves are summed through LDS in a fixed order
+// and the workgroup writes one partial row [9*CIN*COUT + COUT] (same format as the VALU kernel).
+// The bias gradient is the column sum of the B fragments (one VALU add per LDS read).
+// ================================================================================================
+template <int CIN, int COUT, int MODE, int CLS, int IC>
+struct WClass {
+  static constexpr int KROWS = n_taps<MODE>(CLS) * CIN;
+  static constexpr int MTK = (KROWS + 15) / 16;
+  static constexpr int NT = (COUT + 15) / 16;
+  int offA[MTK];
+  f32x4 acc[MTK][NT];
+
+  __device__ __forceinline__ static void tap_of_row(int mm, int& tapg, int& ci, int& dr, int& dc) {
+    const int t = mm / CIN;
+    ci = mm - t * CIN;
+    int ky = 0, kx = 0;
+#pragma unroll
+    for (int tt = 0; tt < n_taps<MODE>(CLS); ++tt)
+      if (tt == t) { ky = tap_ky<MODE>(CLS, tt); kx = tap_kx<MODE>(CLS, tt); }
+    tapg = ky * 3 + kx;
+    if (MODE == MODE_UP) { dr = ky == 0 ? 1 : 0; dc = kx == 0 ? 1 : 0; }
+    else { dr = ky; dc = kx; }
+  }
+
+  __device__ __forceinline__ void init(int lane) {
+    const int m = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt) {
+      const int mm = 16 * mt + m;
+      int tapg, ci, dr, dc;
+      tap_of_row(mm < KROWS ? mm : 0, tapg, ci, dr, dc);
+      offA[mt] = (dr * IC + dc) * CIN + ci;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  __device__ __forceinline__ void step(const float* __restrict__ xa, const float (&bf)[NT]) {
+    float af[MTK];
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt) af[mt] = xa[offA[mt]];
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+  }
+
+  // add (or store, first == true) this wave's accumulators into the LDS row in gather layout
+  __device__ __forceinline__ void flush(float* __restrict__ wacc, int lane, bool first) const {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = 16 * mt + 4 * kg + r;
+        if (mm < KROWS) {
+          int tapg, ci, dr, dc;
+          tap_of_row(mm, tapg, ci, dr, dc);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = 16 * nt + n;
+            if (co < COUT) {
+              float* p = wacc + (tapg * CIN + ci) * COUT + co;
+              *p = first ? acc[mt][nt][r] : *p + acc[mt][nt][r];
+            }
+          }
+        }
+      }
+  }
+};
+
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const WgradArgs a) {
+  using G = Geom<MODE, TW, TH>;
+  constexpr int IR = G::IR, IC = G::IC;
+  constexpr int NT = (COUT + 15) / 16;
+  constexpr int NCLS = n_classes<MODE>();
+  constexpr int NW = 9 * CIN * COUT;
+  extern __shared__ __align__(16) float smem[];
+  float* xt = smem;                               // [IR*IC*CIN]
+  float* dyt = xt + IR * IC * CIN;                // [TH*TW*COUT] (+16 pad: padded cout columns read past the end)
+  float* cx = dyt + TH * TW * COUT + 16;          // [3][32]
+  float* cd = cx + 96;                            // [3][32]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = lane & 15, kg = lane >> 4;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
+    cx[t] = (sx != nullptr && c < CIN) ? sx[c] : 0.f;
+    cd[t] = (sd != nullptr && c < COUT) ? sd[c] : 0.f;
+  }
+  if (t < 16) dyt[TH * TW * COUT + t] = 0.f;
+
+  WClass<CIN, COUT, MODE, 0, IC> w0;
+  WClass<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC> w1;
+  WClass<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC> w2;
+  WClass<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC> w3;
+  w0.init(lane);
+  if (NCLS > 1) { w1.init(lane); w2.init(lane); w3.init(lane); }
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+    const int b = tl / (a.tiles_y * a.tiles_x);
+    const int rem = tl - b * (a.tiles_y * a.tiles_x);
+    const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
+    int gy0, gx0;
+    if (MODE == MODE_S1) { gy0 = oy0 - 1; gx0 = ox0 - 1; }
+    else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
+    else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
+    __syncthreads();
+    stage_tile<CIN, PRO_BN, IR, IC>(xt, a.x, nullptr, cx, b, a.Hi, a.Wi, gy0, gx0);
+    stage_tile<COUT, DYPRO, TH, TW>(dyt, a.dy, a.dy2, cd, b, a.Ho, a.Wo, oy0, ox0);
+    __syncthreads();
+
+    if (MODE == MODE_UP) {
+      // wave <-> class row r (TH/2 == 4 rows); per class 16 columns c = 4*s + kg
+      const int r = wave;
+#pragma unroll 1
+      for (int s = 0; s < TW / 8; ++s) {
+        const int c = 4 * s + kg;
+        const float* xa = xt + (r * IC + c) * CIN;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+          const int py = cls >> 1, px = cls & 1;
+          const float* bp = dyt + ((2 * r + py) * TW + 2 * c + px) * COUT + n;
+          float bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (16 * nt + n < COUT) ? bf[nt] : 0.f; }
+          if (cls == 0) w0.step(xa, bf);
+          else if (cls == 1) w1.step(xa, bf);
+          else if (cls == 2) w2.step(xa, bf);
+          else w3.step(xa, bf);
+        }
+      }
+    } else {
+      constexpr int S = MODE == MODE_S1 ? 1 : 2;
+      constexpr int RPW = TH / 4;                 // rows per wave
+#pragma unroll 1
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int ty = wave * RPW + rr;
+#pragma unroll 1
+        for (int s = 0; s < TW / 4; ++s) {
+          const int x = 4 * s + kg;
+          const float* bp = dyt + (ty * TW + x) * COUT + n;
+          float bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (16 * nt + n < COUT) ? bf[nt] : 0.f; }
+          w0.step(xt + ((S * ty) * IC + S * x) * CIN, bf);
+        }
+      }
+    }
+  }
+
+  // ---- fixed-order reduction of the four waves through LDS, one partial row per workgroup ----------
+  __syncthreads();
+  float* wacc = smem;                             // [NW + COUT], aliases the tiles (all reads are done)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] += __shfl_xor(bsum[nt], 16, 64);
+    bsum[nt] += __shfl_xor(bsum[nt], 32, 64);
+  }
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      w0.flush(wacc, lane, w == 0);
+      if (NCLS > 1) { w1.flush(wacc, lane, w == 0); w2.flush(wacc, lane, w == 0); w3.flush(wacc, lane, w == 0); }
+      if (kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = 16 * nt + n;
+          if (co < COUT) wacc[NW + co] = (w == 0) ? bsum[nt] : wacc[NW + co] + bsum[nt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* prow = a.partials + (size_t)blockIdx.x * (NW + COUT);
+  for (int e = t; e < NW + COUT; e += 256) prow[e] = wacc[e];
+}
+
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
+static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
+  using G = Geom<MODE, TW, TH>;
+  const size_t tiles_f = (size_t)G::IR * G::IC * CIN + TH * TW * COUT + 16 + 192;
+  const size_t red_f = (size_t)9 * CIN * COUT + COUT;
+  const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AVA_ELAUNCH;
+    attr_set = true;
+  }
+  WgradArgs b = a;
+  b.tiles_y = a.Ho / TH;
+  b.tiles_x = a.Wo / TW;
+  b.ntiles = a.B * b.tiles_y * b.tiles_x;
+  if (grid > b.ntiles) return AVA_EINVAL;
+  hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>), dim3(grid), dim3(256), lds, st, b);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
+  const int tw = a.Wo >= 32 ? 32 : 16;
+#define AVA_WGM_CASE(ci, co, md, tww, thh)                                                     \
+  if (Cin == ci && Cout == co && mode == md && tw == tww) {                                    \
+    if (dy_pro == PRO_BWD) return launch_wgrad_mfma<ci, co, md, PRO_BWD, tww, thh>(a, grid, st); \
+    if (dy_pro == PRO_ID) return launch_wgrad_mfma<ci, co, md, PRO_ID, tww, thh>(a, grid, st);   \
+    return AVA_EINVAL;                                                                         \
+  }
+  AVA_WGM_CASE(8, 8, MODE_DOWN, 32, 4)
+  AVA_WGM_CASE(8, 16, MODE_S1, 32, 8)
+  AVA_WGM_CASE(16, 16, MODE_DOWN, 32, 4)
+  AVA_WGM_CASE(16, 24, MODE_S1, 32, 8)
+  AVA_WGM_CASE(24, 24, MODE_DOWN, 16, 8)
+  AVA_WGM_CASE(24, 32, MODE_S1, 16, 16)
+  AVA_WGM_CASE(32, 24, MODE_S1, 16, 16)
+  AVA_WGM_CASE(24, 24, MODE_UP, 32, 8)
+  AVA_WGM_CASE(24, 16, MODE_S1, 32, 8)
+  AVA_WGM_CASE(16, 16, MODE_UP, 32, 8)
+  AVA_WGM_CASE(16, 8, MODE_S1, 32, 8)
+  AVA_WGM_CASE(8, 8, MODE_UP, 32, 8)
+#undef AVA_WGM_CASE
+  return AVA_EINVAL;
+}

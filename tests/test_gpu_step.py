@@ -184,7 +184,7 @@ def test_two_shard_data_parallel_equivalence():
         gn = float(total[o:o + n].norm())
         sens = s.layer in ("conv1", "bn1")
         ref_scale = max(float(G["gradnorm." + s.name]), float(G["gradnorm.conv1.bias"]) if sens else 0.0)
-        assert abs(gn - float(G["gradnorm." + s.name])) < (FLIP_TOL if sens else 1e-3) * ref_scale, s.name
+        assert abs(gn - float(G["gradnorm." + s.name])) < (FLIP_TOL if sens else 3e-3) * ref_scale, s.name   # shard 1 has a ReLU flip upstream of conv2 (4e-4 in the oracle)
 
 
 def test_harness_train_loop_checkpoint_golden(tmp_path):

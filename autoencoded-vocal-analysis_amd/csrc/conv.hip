@@ -332,16 +332,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // kind 1: convT s1 (G[8-t][c0][c1]), kind 2: convT s2 (G[t][c0][c1]).
 // 256 threads = 32 row entries x 8 row groups: reads are coalesced along a partial row, the rows are
 // summed in fp64 in a fixed order (deterministic), the (tiny) result is scattered to the weight layout.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts,
-                                                           float* __restrict__ dw, float* __restrict__ dbias,
-                                                           int cin, int cout, int kind) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partials, int nparts,
+                                                  float* __restrict__ dw, float* __restrict__ dbias, int cin,
+                                                  int cout, int kind, int block) {
   __shared__ double red[8][33];
   const int nw = 9 * cin * cout, row = nw + cout;
   const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int gi = blockIdx.x * 32 + e;                 // index inside a partial row
+  const int gi = block * 32 + e;                      // index inside a partial row
   double s = 0.0;
-  if (gi < row)
-    for (int p = rg; p < nparts; p += 8) s += (double)partials[(size_t)p * row + gi];
+  if (gi < row) {
+    const float* p = partials + gi;
+    int r = rg;
+    for (; r + 24 < nparts; r += 32) {                // 4 independent loads in flight per thread
+      const float a0 = p[(size_t)r * row], a1 = p[(size_t)(r + 8) * row];
+      const float a2 = p[(size_t)(r + 16) * row], a3 = p[(size_t)(r + 24) * row];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; r < nparts; r += 8) s += (double)p[(size_t)r * row];
+  }
   red[rg][e] = s;
   __syncthreads();
   if (rg == 0 && gi < row) {
@@ -357,6 +365,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     else i = (a * cout + b) * 9 + tg;                          // Wt[ci=a][co=b][t]
     dw[i] = (float)tot;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts,
+                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                           int cin, int cout, int kind) {
+  wgrad_reduce_body(partials, nparts, dw, dbias, cin, cout, kind, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradReduceTable tab) {
+  int i = 0;
+#pragma unroll 1
+  for (int k = 1; k < tab.n; ++k)
+    if ((int)blockIdx.x >= tab.e[k].block0) i = k;
+  const WgradReduceEntry e = tab.e[i];
+  wgrad_reduce_body(e.partials, e.nparts, e.dw, e.dbias, e.cin, e.cout, e.kind, blockIdx.x - e.block0);
+}
+
+int ava_conv_wgrad_reduce_all(const WgradReduceTable& tab, int total_blocks, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(total_blocks), dim3(256), 0, st, tab);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

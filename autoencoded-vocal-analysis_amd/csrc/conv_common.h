@@ -99,3 +99,17 @@ struct WgradArgs {
   int B, Hi, Wi, Ho, Wo;
   int tiles_y, tiles_x, ntiles;
 };
+
+// all 14 weight-gradient reductions in one launch (model.hip)
+struct WgradReduceEntry {
+  const float* partials;
+  float* dw;
+  float* dbias;
+  int nparts, cin, cout, kind;
+  int block0;            // first block of this entry
+};
+struct WgradReduceTable {
+  WgradReduceEntry e[14];
+  int n;
+};
+int ava_conv_wgrad_reduce_all(const WgradReduceTable& tab, int total_blocks, hipStream_t st);

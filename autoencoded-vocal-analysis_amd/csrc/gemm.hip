@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   constexpr int TM = WM / 32, TN = WN / 32;      // 32x32 MFMA tiles per wave
   constexpr int NA = BM * BK / 4 / 256;          // float4 loads per thread for A (2 or 1)
   constexpr int NB = BN * BK / 4 / 256;
-  __shared__ __align__(16) float As[BK * LDA_S];
-  __shared__ __align__(16) float Bs[BK * LDB_S];
+  __shared__ __align__(16) float As2[2][BK * LDA_S];
+  __shared__ __align__(16) float Bs2[2][BK * LDB_S];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       rb[i] = x;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    float* As = As2[buf];
+    float* Bs = Bs2[buf];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int v = t + i * 256;
@@ -171,12 +173,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   float csum = 0.f;   // column sum of A (bias gradient), thread t < BM owns column t
   const bool do_colsum = g.colsum != nullptr && blockIdx.x == 0;
 
-  if (kbeg < kend) load_tile(kbeg);
+  // software pipeline: tile k+1 travels global -> registers while tile k is multiplied out of LDS buffer
+  // (k & 1); it is written to the other buffer after the MFMAs, one barrier per K step.
+  if (kbeg < kend) { load_tile(kbeg); store_tile(0); }
+  __syncthreads();
+  int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();                 // previous tile's fragment reads are done
-    store_tile();
-    __syncthreads();
-    if (k0 + BK < kend) load_tile(k0 + BK);   // prefetch the next tile into registers
+    const bool more = k0 + BK < kend;
+    if (more) load_tile(k0 + BK);
+    const float* As = As2[cur];
+    const float* Bs = Bs2[cur];
     if (do_colsum && t < BM) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) csum += As[k * LDA_S + t];
@@ -195,6 +201,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
@@ -223,14 +232,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         }
       }
     }
-  if (do_colsum && t < BM && m0 + t < g.M) g.colsum[m0 + t] = csum;
+  if (do_colsum && t < BM && m0 + t < g.M) {
+    if (fin) g.colsum[m0 + t] = csum;
+    else g.C[(size_t)g.splits * g.M * g.N + (size_t)split * g.M + m0 + t] = csum;   // partial, behind the slabs
+  }
 }
 
 // sum the split-K slabs in a fixed order, add bias, activation
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                     const float* __restrict__ mask, float* __restrict__ C, int M, int N, int ldc,
-                                     int splits, int act) {
+                                     const float* __restrict__ mask, float* __restrict__ C,
+                                     float* __restrict__ colsum, int M, int N, int ldc, int splits, int act) {
   const size_t mn = (size_t)M * N;
+  if (colsum != nullptr && blockIdx.x == 0) {
+    const float* cs = ws + (size_t)splits * mn;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+      float s = 0.f;
+      for (int p = 0; p < splits; ++p) s += cs[(size_t)p * M + m];
+      colsum[m] = s;
+    }
+  }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int p = 0; p < splits; ++p) s += ws[p * mn + i];
@@ -246,9 +266,10 @@ static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
   *bm = (M >= 128 && N >= 128) ? 128 : 64;
   const int tiles = ceil_div(M, *bm) * ceil_div(N, *bm);
   int s = 1;
-  if (tiles < 192) {
-    s = 256 / tiles;
-    const int max_s = K / 64 > 0 ? K / 64 : 1;      // at least 4 K-steps per split
+  if (tiles < 384) {
+    // aim at >= 2 workgroups per CU so that one workgroup's loads overlap another's MFMAs
+    s = ceil_div(512, tiles);
+    const int max_s = K / 32 > 0 ? K / 32 : 1;      // at least 2 K-steps per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
   }
@@ -261,7 +282,7 @@ static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
 extern "C" size_t ava_gemm_workspace_bytes(int M, int N, int K) {
   int bm, splits, klen;
   plan(M, N, K, &bm, &splits, &klen);
-  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+  return splits > 1 ? ((size_t)splits * M * N + (size_t)splits * M) * sizeof(float) : 0;
 }
 
 template <int BM>
@@ -278,8 +299,7 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   if (A == nullptr || B == nullptr || C == nullptr || M <= 0 || N <= 0 || K <= 0) return AVA_EINVAL;
   int bm, splits, klen;
   plan(M, N, K, &bm, &splits, &klen);
-  if (colsum != nullptr && splits > 1) { splits = 1; klen = ceil_div(K, 16) * 16; }
-  if (splits > 1 && (ws == nullptr || ws_bytes < (size_t)splits * M * N * sizeof(float))) return AVA_EWORKSPACE;
+  if (splits > 1 && (ws == nullptr || ws_bytes < ava_gemm_workspace_bytes(M, N, K))) return AVA_EWORKSPACE;
   GemmArgs g;
   g.A = A; g.B = B; g.bias = bias; g.colsum = colsum; g.mask = mask;
   g.C = splits > 1 ? reinterpret_cast<float*>(ws) : C;
@@ -300,7 +320,7 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
     int blocks = (int)((mn + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(ws), bias,
-                       mask, C, M, N, g.ldc, splits, act);
+                       mask, C, colsum, M, N, g.ldc, splits, act);
     AVA_CHECK_LAUNCH();
   }
   return AVA_OK;

@@ -4,7 +4,7 @@
 #include <string.h>
 #include <string>
 #include <map>
-#include "common.h"
+#include "conv_common.h"
 
 // internal entry points of the other translation units
 int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, hipStream_t st);
@@ -15,9 +15,6 @@ int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, co
 int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
                               int zdim, float prec, float* loss_out, hipStream_t st);
 
-enum { MODE_S1 = 0, MODE_DOWN = 1, MODE_UP = 2 };
-enum { PRO_BN = 0, PRO_BWD = 1, PRO_ID = 2 };
-enum { EPI_FWD = 0, EPI_BWD = 1, EPI_SSE = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_EXP = 2 };
 
 #define NCONV 14
@@ -110,7 +107,7 @@ struct ava_model {
   float* Gf[NCONV];
   float* Gb[NCONV];
   float *gA, *gB;           // gradient ping-pong, B*131072 floats each
-  float* wg_part;           // wgrad partial rows
+  float* wg_part[NCONV];    // wgrad partial rows, one region per layer (reduced in one launch at the end)
   float *dF8, *dh7, *dh6, *dh5, *dz, *dmu, *du, *dlogd, *dh3, *dh2, *dh1, *dy7;
   float* gemm_ws;
   size_t gemm_ws_bytes;
@@ -150,7 +147,10 @@ static size_t max_gemm_ws(int z, int B) {
                            {B, 1024, 256}, {B, 8192, 1024},
                            // dX products
                            {B, 8192, 1024}, {B, 1024, 256}, {B, 256, 192}, {B, 64, z}, {B, z, 64}, {B, 64, 256},
-                           {B, 256, 1024}, {B, 1024, 8192}};
+                           {B, 256, 1024}, {B, 1024, 8192},
+                           // dW products (K = batch)
+                           {8192, 1024, B}, {1024, 256, B}, {256, 64, B}, {64, z, B}, {z, 64, B}, {192, 256, B},
+                           {256, 1024, B}, {1024, 8192, B}};
   for (auto& s : shapes) {
     size_t b = ava_gemm_workspace_bytes(s[0], s[1], s[2]);
     if (b > mx) mx = b;
@@ -158,15 +158,10 @@ static size_t max_gemm_ws(int z, int B) {
   return mx;
 }
 
-static size_t wgrad_part_floats(int B) {
-  size_t mx = 0;
-  for (int l = 0; l < NCONV; ++l) {
-    const ConvLayer& L = kLayers[l];
-    const int grid = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
-    size_t f = (size_t)grid * (9 * L.cin * L.cout + L.cout);
-    if (f > mx) mx = f;
-  }
-  return mx;
+static size_t wgrad_part_floats(int B, int l) {
+  const ConvLayer& L = kLayers[l];
+  const int grid = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+  return (size_t)grid * (9 * L.cin * L.cout + L.cout);
 }
 
 static void carve(ava_model* m, void* ws, size_t* total) {
@@ -193,7 +188,7 @@ static void carve(ava_model* m, void* ws, size_t* total) {
     m->Gb[l] = c.take(9 * kLayers[l].cin * kLayers[l].cout);
   }
   m->gA = c.take(B * 131072); m->gB = c.take(B * 131072);
-  m->wg_part = c.take(wgrad_part_floats((int)B));
+  for (int l = 0; l < NCONV; ++l) m->wg_part[l] = c.take(wgrad_part_floats((int)B, l));
   m->dF8 = c.take(B * 8192); m->dh7 = c.take(B * 1024); m->dh6 = c.take(B * 256); m->dh5 = c.take(B * 64);
   m->dz = c.take(B * z); m->dmu = c.take(B * z); m->du = c.take(B * z); m->dlogd = c.take(B * z);
   m->dh3 = c.take(B * 192); m->dh2 = c.take(B * 256); m->dh1 = c.take(B * 1024); m->dy7 = c.take(B * 8192);
@@ -475,12 +470,8 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   const ConvLayer& L = kLayers[l];
   const float* X = l == 0 ? x0 : m->X[l];
   // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
-  TRY(ava_conv3x3_wgrad(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part, B, L.hi, L.hi, L.cin,
+  TRY(ava_conv3x3_wgrad(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], B, L.hi, L.hi, L.cin,
                         L.cout, L.mode, pro, st));
-  mark(m, CAT_CONV_WGRAD, st);
-  const int wparts = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
-  const int kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
-  TRY(ava_conv_wgrad_reduce(m->wg_part, wparts, GG(m, L.pw), GG(m, L.pb), L.cin, L.cout, kind, st));
   mark(m, CAT_CONV_WGRAD, st);
   // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
   const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
@@ -550,6 +541,23 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
                             l == 0 ? nullptr : gnext, B, st));
     float* t = gcur; gcur = gnext; gnext = t;
   }
+  // ---- all 14 weight/bias gradient reductions in one launch ----
+  WgradReduceTable tab;
+  int blocks = 0;
+  for (int l = 0; l < NCONV; ++l) {
+    const ConvLayer& L = kLayers[l];
+    tab.e[l].partials = m->wg_part[l];
+    tab.e[l].dw = GG(m, L.pw);
+    tab.e[l].dbias = GG(m, L.pb);
+    tab.e[l].nparts = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+    tab.e[l].cin = L.cin; tab.e[l].cout = L.cout;
+    tab.e[l].kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
+    tab.e[l].block0 = blocks;
+    blocks += ceil_div(9 * L.cin * L.cout + L.cout, 32);
+  }
+  tab.n = NCONV;
+  TRY(ava_conv_wgrad_reduce_all(tab, blocks, st));
+  mark(m, CAT_CONV_WGRAD, st);
   return AVA_OK;
 }
 

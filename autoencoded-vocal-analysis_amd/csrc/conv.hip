@@ -465,6 +465,7 @@ extern "C" int ava_conv3x3(const float* in, const float* in2, const float* pa, c
   a.in = in; a.in2 = in2; a.pa = pa; a.pb = pb; a.pc = pc; a.G = G; a.bias = bias; a.out = out; a.out2 = out2;
   a.epi_x = epi_x; a.epi_mean = epi_mean; a.epi_invstd = epi_invstd; a.partials = partials;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.prec = prec;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("AVA_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
   a.Ho = mode == MODE_S1 ? Hi : (mode == MODE_DOWN ? Hi / 2 : Hi * 2);
   a.Wo = mode == MODE_S1 ? Wi : (mode == MODE_DOWN ? Wi / 2 : Wi * 2);
   a.ntiles = conv_geometry(B, a.Ho, a.Wo, &a.tiles_y, &a.tiles_x);

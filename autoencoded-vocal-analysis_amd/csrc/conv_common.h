@@ -24,6 +24,7 @@ struct ConvArgs {
   int relu;
   float prec;
   int tiles_y, tiles_x, ntiles;
+  int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };
 
 template <int MODE, int TW, int TH_ = 256 / TW>
@@ -85,6 +86,88 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float*
     }
   }
 }
+
+// Register-staged tile prefetch: `load` issues the global loads of a [R x C x CIN] window (raw values,
+// out-of-bounds lanes remembered in a bit mask), `store` applies the prologue and writes LDS.  Splitting
+// the two lets a workgroup keep the NEXT tile's loads in flight while it multiplies the current one.
+// Everything that does not depend on the tile (which window element a thread owns, its offset relative
+// to the window origin) is computed once in `init`; per tile a load costs a handful of integer ops.
+typedef float avaf4 __attribute__((ext_vector_type(4)));
+
+// Plain (compiler-visible) 16-byte load.  An inline-asm "asynchronous" variant that hides the load from
+// hipcc's waitcnt pass was tried and rejected: the compiler is then free to copy/spill the destination
+// registers before the data has landed (observed: stale BatchNorm-backward sums in one kernel), and the
+// ablation runs show the matrix-core phase, not the memory phase, bounds these kernels anyway.
+__device__ __forceinline__ avaf4 ava_load_f4_async(const float* p) {
+  return *reinterpret_cast<const avaf4*>(p);
+}
+template <int N>
+__device__ __forceinline__ void ava_wait_vm0(avaf4 (&r)[N]) {}
+
+template <int CIN, int PRO, int R, int C>
+struct TileStager {
+  static_assert(CIN % 4 == 0, "vector staging needs a multiple of 4 channels");
+  static constexpr int Q = CIN / 4;
+  static constexpr int NV = R * C * Q;
+  static constexpr int NPF = (NV + 255) / 256;
+  avaf4 v[NPF];
+  avaf4 v2[PRO == PRO_BWD ? NPF : 1];
+  int rc[NPF];          // (r << 16) | c of the owned window element (clamped duplicate for idle lanes)
+  int q4[NPF];          // 4 * channel quad
+  unsigned live;        // bit i: element i exists (idx < NV)
+  unsigned inb;         // bit i: element i of the CURRENT register contents is inside the image
+
+  __device__ __forceinline__ void init() {
+    live = 0u;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      int idx = threadIdx.x + 256 * i;
+      if (idx < NV) live |= 1u << i;
+      else idx = NV - 1;
+      const int pix = idx / Q, q = idx - pix * Q;
+      const int r = pix / C, c = pix - r * C;
+      rc[i] = (r << 16) | c;
+      q4[i] = 4 * q;
+    }
+  }
+
+  // Branch-free: every lane always loads (out-of-range coordinates are clamped to a valid address and
+  // masked at store time).  The loads are asynchronous (see ava_load_f4_async).
+  __device__ __forceinline__ void load(const float* __restrict__ in, const float* __restrict__ in2, int b, int Hi,
+                                       int Wi, int gy0, int gx0) {
+    inb = 0u;
+    const float* __restrict__ base = in + (size_t)b * Hi * Wi * CIN;
+    const float* __restrict__ base2 = PRO == PRO_BWD ? in2 + (size_t)b * Hi * Wi * CIN : nullptr;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int gy = gy0 + (rc[i] >> 16), gx = gx0 + (rc[i] & 0xffff);
+      const bool ok = ((live >> i) & 1u) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+      const int cy = min(max(gy, 0), Hi - 1), cx = min(max(gx, 0), Wi - 1);
+      const int off = (cy * Wi + cx) * CIN + q4[i];
+      v[i] = ava_load_f4_async(base + off);
+      if (PRO == PRO_BWD) v2[i] = ava_load_f4_async(base2 + off);
+      inb |= ok ? (1u << i) : 0u;
+    }
+  }
+
+  // wait for the loads, apply the prologue, write LDS
+  __device__ __forceinline__ void store(float* __restrict__ lds, const float* __restrict__ coef) {
+    ava_wait_vm0(v);
+    if (PRO == PRO_BWD) ava_wait_vm0(v2);
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const float* ca = coef + q4[i];
+      const avaf4 x = v[i];
+      const avaf4 y = PRO == PRO_BWD ? v2[i] : x;
+      const bool ok = (inb >> i) & 1u;
+      avaf4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = ok ? prologue<PRO>(x[e], y[e], ca[e], ca[32 + e], ca[64 + e]) : 0.f;
+      if ((live >> i) & 1u) *reinterpret_cast<avaf4*>(lds + 4 * idx) = o;
+    }
+  }
+};
 
 struct WgradArgs {
   const float* x;      // raw layer input [B,Hi,Wi,CIN]; prologue 0 with xa, xb

@@ -12,6 +12,7 @@
 //     1 KiB contiguous per wave instruction; bias/ReLU/BN statistics fused in registers.
 // A workgroup (4 waves) walks a list of output tiles; each wave owns groups of 16 consecutive output
 // pixels of a row (for the x2-upsampling pattern: of one output-parity class, so the tap set is uniform).
+#include <stdlib.h>
 #include "conv_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,7 +49,8 @@ struct ClassFrag {
   int off[NCH];
   float w[NCH][4][MT];
 
-  __device__ __forceinline__ void init(const float* __restrict__ G, int lane) {
+  // lane_base: LDS offset (floats) of this lane's pixel inside a 16-pixel group (n * CIN * stride)
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base) {
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -64,7 +66,7 @@ struct ClassFrag {
       int dr, dc;
       if (MODE == MODE_UP) { dr = ky == 0 ? 1 : 0; dc = kx == 0 ? 1 : 0; }
       else { dr = ky; dc = kx; }
-      off[c] = (dr * IC + dc) * CIN + ci;
+      off[c] = lane_base + (dr * IC + dc) * CIN + ci;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -73,6 +75,15 @@ struct ClassFrag {
           w[c][j][mt] = (valid && co < COUT) ? G[((ky * 3 + kx) * CIN + ci + j) * COUT + co] : 0.f;
         }
     }
+    // Retire the weight loads HERE.  Left pending, their first use sits inside the tile loop and hipcc's
+    // conservative loop handling turns it into s_waitcnt vmcnt(0) there, which also drains the next tile's
+    // prefetch (vmcnt retires in order) and serialises memory against the matrix cores.
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(w[c][j][mt]));
   }
 
   // acc[2][MT] += over all chunks; px = LDS address of this lane's pixel (tap (0,0), channel 0)
@@ -113,8 +124,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC> f1;
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC> f2;
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC> f3;
-  f0.init(a.G, lane);
-  if (NCLS > 1) { f1.init(a.G, lane); f2.init(a.G, lane); f3.init(a.G, lane); }
+  constexpr int SP = MODE == MODE_DOWN ? 2 : 1;            // input pixels per output pixel along x
+  f0.init(a.G, lane, SP * n * CIN);
+  if (NCLS > 1) { f1.init(a.G, lane, n * CIN); f2.init(a.G, lane, n * CIN); f3.init(a.G, lane, n * CIN); }
+  // output offset (floats) of this lane inside a 16-pixel group: pixel n (every 2nd pixel for UP), channels 4kg..
+  const int lane_out = (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
 
   // epilogue constants for this lane's 4 output channels per cout tile
   float bias[MT][4], emean[MT][4], einv[MT][4];
@@ -128,52 +142,96 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
       emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
       einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
       s1[mt][r] = s2[mt][r] = 0.f;
+      // retire these loop-invariant loads before the tile loop (see ClassFrag::init)
+      asm volatile("" ::"v"(bias[mt][r]), "v"(emean[mt][r]), "v"(einv[mt][r]));
     }
 
-  constexpr int GROUPS = (MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16);
-  constexpr int GPW = GROUPS / 4;           // groups per wave
-  static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
-
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
-    const int b = tl / (a.tiles_y * a.tiles_x);
+  // tile origin (image, output row/col, input row/col) of tile `tl`
+  auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
+    b = tl / (a.tiles_y * a.tiles_x);
     const int rem = tl - b * (a.tiles_y * a.tiles_x);
-    const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
-    int gy0, gx0;
+    oy0 = (rem / a.tiles_x) * TH;
+    ox0 = (rem % a.tiles_x) * TW;
     if (MODE == MODE_S1) { gy0 = oy0 - 1; gx0 = ox0 - 1; }
     else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
+  };
+  constexpr int GROUPS = (MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16);
+  constexpr int GPW = GROUPS / 4;           // groups per wave
+  static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
+  // scalar offset (floats) of pixel group g's first pixel relative to the tile's first output pixel
+  //   S1/DOWN: group g = (row g / GPR, 16 columns from 16*(g % GPR));  UP: g = (row pair g >> 2, parity class g & 3)
+  auto group_out = [&](int g) -> int {
+    if (MODE == MODE_UP) return (((2 * (g >> 2)) + ((g & 3) >> 1)) * a.Wo + (g & 1)) * COUT;
+    constexpr int GPR = TW / 16;
+    return ((g / GPR) * a.Wo + 16 * (g % GPR)) * COUT;
+  };
+  avaf4 exn[EPI == EPI_BWD ? GPW * MT : 1];
+  auto load_ex = [&](int b, int oy0, int ox0) {
+    const float* __restrict__ xb = a.epi_x + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * COUT;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb = 16 * mt + 4 * kg;
+        // lanes whose 4-channel slot lies beyond COUT (COUT = 8 or 24) re-read slot 0: stays in bounds
+        exn[gi * MT + mt] = ava_load_f4_async(xb + group_out(wave * GPW + gi) + (cb < COUT ? lane_out + 16 * mt : lane_out - 4 * kg));
+      }
+  };
+  TileStager<CIN, PRO, IR, IC> stg;
+  stg.init();
+  {
+    int b, oy0, ox0, gy0, gx0;
+    origin(blockIdx.x, b, oy0, ox0, gy0, gx0);
+    stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+    if (EPI == EPI_BWD) load_ex(b, oy0, ox0);
+  }
+  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+    int b, oy0, ox0, gy0, gx0;
+    origin(tl, b, oy0, ox0, gy0, gx0);
+    __syncthreads();                       // previous tile fully consumed (and coef[] visible on the first pass)
+    if (!(a.dbg & 2)) stg.store(tile, coef);                 // s_waitcnt vmcnt(0): retires the prefetch (and exn) of this tile
+    if (EPI == EPI_BWD) ava_wait_vm0(exn);
     __syncthreads();
-    stage_tile<CIN, PRO, IR, IC>(tile, a.in, a.in2, coef, b, a.Hi, a.Wi, gy0, gx0);
-    __syncthreads();
+    // uniform (scalar) part of the addresses of this tile
+    const size_t tile_pix = ((size_t)b * a.Ho + oy0) * a.Wo + ox0;
+    float* __restrict__ obase = a.out != nullptr ? a.out + tile_pix * COUT : nullptr;
+    // EPI_BWD: the x values for the BatchNorm-backward sums of the NEXT tile travel with its prefetch
+    // (asynchronous loads, retired by the same wait); `ex` holds the current tile's, moved over here.
+    avaf4 ex[GPW * MT];
+    if (EPI == EPI_BWD) {
+#pragma unroll
+      for (int i = 0; i < GPW * MT; ++i) ex[i] = exn[i];
+    }
+    if (tl + (int)gridDim.x < a.ntiles && !(a.dbg & 2)) {  // next tile's loads stay in flight during the MFMAs below
+      int nb, noy0, nox0, ngy0, ngx0;
+      origin(tl + gridDim.x, nb, noy0, nox0, ngy0, ngx0);
+      stg.load(a.in, a.in2, nb, a.Hi, a.Wi, ngy0, ngx0);
+      if (EPI == EPI_BWD) load_ex(nb, noy0, nox0);
+    }
 
-#pragma unroll 1
-    for (int gi = 0; gi < GPW; ++gi) {
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {   // fully unrolled: hipcc drains vmcnt(0) in front of a loop that stores
       const int g = wave * GPW + gi;
       f32x4 acc[2][MT];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      int oy, ox;        // this lane's output pixel inside the tile
-      if (MODE == MODE_UP) {
-        // TW/2 = 16 columns per parity class and row: group = (r, class)
+      if (a.dbg & 1) {
+      } else if (MODE == MODE_UP) {
         const int cls = g & 3, r = g >> 2;
-        const float* px = tile + (r * IC + n) * CIN;
+        const float* px = tile + r * IC * CIN;
         if (cls == 0) f0.run(px, acc);
         else if (cls == 1) f1.run(px, acc);
         else if (cls == 2) f2.run(px, acc);
         else f3.run(px, acc);
-        oy = 2 * r + (cls >> 1);
-        ox = 2 * n + (cls & 1);
       } else {
         constexpr int GPR = TW / 16;
         constexpr int S = MODE == MODE_S1 ? 1 : 2;
-        const int ty = g / GPR, tx = 16 * (g % GPR) + n;
-        f0.run(tile + ((S * ty) * IC + S * tx) * CIN, acc);
-        oy = ty;
-        ox = tx;
+        f0.run(tile + (S * (g / GPR) * IC + S * 16 * (g % GPR)) * CIN, acc);
       }
-      const size_t opix = ((size_t)b * a.Ho + oy0 + oy) * a.Wo + ox0 + ox;
+      const int gout = group_out(g) + lane_out;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int cb = 16 * mt + 4 * kg;
@@ -182,15 +240,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
           if (EPI == EPI_FWD) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float x = v[r] + bias[mt][r];
-              if (a.relu) x = fmaxf(x, 0.f);
+              const float x = fmaxf(v[r] + bias[mt][r], 0.f);      // every matrix-core forward layer has a ReLU
               v[r] = x;
               s1[mt][r] += x;
               s2[mt][r] = fmaf(x, x, s2[mt][r]);
             }
           } else {   // EPI_BWD
-            const float4 xr = *reinterpret_cast<const float4*>(a.epi_x + opix * COUT + cb);
-            const float xv[4] = {xr.x, xr.y, xr.z, xr.w};
+            const avaf4 xr = ex[gi * MT + mt];
+            const float xv[4] = {xr[0], xr[1], xr[2], xr[3]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float xh = (xv[r] - emean[mt][r]) * einv[mt][r];
@@ -198,8 +255,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
               s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
             }
           }
-          if (a.out != nullptr)
-            *reinterpret_cast<float4*>(a.out + opix * COUT + cb) = make_float4(v[0], v[1], v[2], v[3]);
+          if (obase != nullptr && !(a.dbg & 4))
+            *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -247,6 +304,7 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid > b.ntiles) return AVA_EINVAL;
+  { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; }
   hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
@@ -264,6 +322,7 @@ static int launch_mfma_pe(const ConvArgs& a, int grid, int pro, int epi, hipStre
 // `grid` = number of workgroups = number of partial rows (the caller's ava_conv_grid value)
 int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
   const int tw = a.Wo >= 32 ? 32 : 16;
+  if (epi == EPI_FWD && !a.relu) return AVA_EINVAL;        // the fused epilogue always applies the ReLU
 #define AVA_MFMA_CASE(ci, co, md, tww, thh) \
   if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_mfma_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
   AVA_MFMA_CASE(8, 8, MODE_DOWN, 32, 4)
@@ -392,18 +451,36 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const WgradArgs
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
 
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
-    const int b = tl / (a.tiles_y * a.tiles_x);
+  auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
+    b = tl / (a.tiles_y * a.tiles_x);
     const int rem = tl - b * (a.tiles_y * a.tiles_x);
-    const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
-    int gy0, gx0;
+    oy0 = (rem / a.tiles_x) * TH;
+    ox0 = (rem % a.tiles_x) * TW;
     if (MODE == MODE_S1) { gy0 = oy0 - 1; gx0 = ox0 - 1; }
     else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
+  };
+  TileStager<CIN, PRO_BN, IR, IC> sx;
+  TileStager<COUT, DYPRO, TH, TW> sd;
+  sx.init();
+  sd.init();
+  {
+    int b, oy0, ox0, gy0, gx0;
+    origin(blockIdx.x, b, oy0, ox0, gy0, gx0);
+    sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy0, gx0);
+    sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, oy0, ox0);
+  }
+  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
     __syncthreads();
-    stage_tile<CIN, PRO_BN, IR, IC>(xt, a.x, nullptr, cx, b, a.Hi, a.Wi, gy0, gx0);
-    stage_tile<COUT, DYPRO, TH, TW>(dyt, a.dy, a.dy2, cd, b, a.Ho, a.Wo, oy0, ox0);
+    sx.store(xt, cx);
+    sd.store(dyt, cd);
     __syncthreads();
+    if (tl + (int)gridDim.x < a.ntiles) {
+      int b, oy0, ox0, gy0, gx0;
+      origin(tl + gridDim.x, b, oy0, ox0, gy0, gx0);
+      sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy0, gx0);
+      sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, oy0, ox0);
+    }
 
     if (MODE == MODE_UP) {
       // wave <-> class row r (TH/2 == 4 rows); per class 16 columns c = 4*s + kg

@@ -7,16 +7,19 @@
 // the tiny per-channel reductions between them.  Per-workgroup partial sums are fp32, everything
 // across workgroups is accumulated in fp64 in a fixed order (deterministic, and as accurate as the
 // reference's CPU kernels, which accumulate float tensors in double).
+#include <string.h>
 #include "common.h"
+#include "bn_fuse.h"
 
-#define BN_EPS 1e-5
-#define BN_MOMENTUM 0.1
+#define BN_EPS AVA_BN_EPS
+#define BN_MOMENTUM AVA_BN_MOMENTUM
 
 // ---- statistics of a raw tensor x[n][C] (used for bn1, whose input has no producer kernel) --------
 template <int C>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t n,
-                                                       float* __restrict__ partials) {
+                                                       float* __restrict__ partials, const BnFuse fuse) {
   __shared__ float red[4][2 * C];
+  __shared__ double fuse_scratch[260];
   float s1[C], s2[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) s1[c] = s2[c] = 0.f;
@@ -51,17 +54,29 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   if (threadIdx.x < 2 * C)
     partials[(size_t)blockIdx.x * 2 * C + threadIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  bn_fused_finalize(fuse, partials, gridDim.x, fuse_scratch);
 }
 
-// column sums of partials[nparts][ncols] in fp64; result in sums[ncols] (shared memory, double)
+// column sums of partials[nparts][ncols] in fp64; result in sums[ncols] (shared memory, double).
+// 8 independent loads are kept in flight per thread: the loop is latency- not bandwidth-bound.
 __device__ void column_sums(const float* __restrict__ partials, int nparts, int ncols, double* sums /*[ncols]*/,
                             double* scratch /*[1024]*/) {
   const int t = threadIdx.x;
   const int groups = 1024 / ncols;
   const int col = t % ncols, grp = t / ncols;
   double s = 0.0;
-  if (grp < groups)
-    for (int r = grp; r < nparts; r += groups) s += (double)partials[(size_t)r * ncols + col];
+  if (grp < groups) {
+    const float* p = partials + col;
+    int r = grp;
+    for (; r + 7 * groups < nparts; r += 8 * groups) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(r + k * groups) * ncols];
+      s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) +
+           (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
+    }
+    for (; r < nparts; r += groups) s += (double)p[(size_t)r * ncols];
+  }
   scratch[t] = grp < groups ? s : 0.0;
   __syncthreads();
   if (t < ncols) {
@@ -134,9 +149,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
 // ---- NCHW-flatten <-> NHWC hand-offs (per sample: 32 channels x 256 pixels) --------------------------
 // f8 [B][32*256] (c*256+p) -> out [B][256][32], plus per-channel {sum, sum^2} partials for bn8
 __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                 float* __restrict__ partials, int B) {
+                                                                 float* __restrict__ partials, int B,
+                                                                 const BnFuse fuse) {
   __shared__ float tile[32][257];
   __shared__ float red[8][64];
+  __shared__ double fuse_scratch[260];
   const int t = threadIdx.x;
   float s1 = 0.f, s2 = 0.f;                 // thread -> channel t&31, 8 threads per channel
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -160,6 +177,29 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
     for (int k = 0; k < 8; ++k) s += red[k][t];
     partials[(size_t)blockIdx.x * 64 + t] = s;
   }
+  bn_fused_finalize(fuse, partials, gridDim.x, fuse_scratch);
+}
+
+// eval mode (module.eval()): scale/shift of all 14 BatchNorm layers from their running statistics, one launch
+struct BnEvalTable { const float* gamma[14]; const float* beta[14]; int C[14]; };
+__global__ void bn_eval_all_kernel(const BnEvalTable tab, const float* __restrict__ running, float* __restrict__ save) {
+  const int l = blockIdx.x, c = threadIdx.x;
+  if (c < tab.C[l]) {
+    const float mean = running[l * 32 + c];
+    const float var = running[(14 + l) * 32 + c];
+    const float invstd = (float)(1.0 / sqrt((double)var + BN_EPS));
+    const float sc = tab.gamma[l][c] * invstd;
+    float* o = save + l * 4 * 32;
+    o[c] = mean; o[32 + c] = invstd; o[64 + c] = sc; o[96 + c] = tab.beta[l][c] - mean * sc;
+  }
+}
+int ava_bn_eval_all(const float* const* gamma, const float* const* beta, const int* C, const float* running, float* save,
+                    hipStream_t st) {
+  BnEvalTable tab;
+  for (int l = 0; l < 14; ++l) { tab.gamma[l] = gamma[l]; tab.beta[l] = beta[l]; tab.C[l] = C[l]; }
+  hipLaunchKernelGGL(bn_eval_all_kernel, dim3(14), dim3(32), 0, st, tab, running, save);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
 }
 
 // y7 [B][256][32] -> out [B][32*256]
@@ -212,19 +252,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* 
   }
 }
 
+int ava_bn_stats_ex(const float* x, int64_t n, int C, float* partials, int* nparts, const BnFuse* bn, ava_stream_t s);
 extern "C" int ava_bn_stats(const float* x, int64_t n, int C, float* partials, int* nparts, ava_stream_t s) {
+  return ava_bn_stats_ex(x, n, C, partials, nparts, nullptr, s);
+}
+int ava_bn_stats_ex(const float* x, int64_t n, int C, float* partials, int* nparts, const BnFuse* bn, ava_stream_t s) {
   if (x == nullptr || partials == nullptr || n <= 0) return AVA_EINVAL;
+  BnFuse fuse;
+  if (bn != nullptr) fuse = *bn; else memset(&fuse, 0, sizeof(fuse));
   int64_t work = C == 1 ? n / 4 : n;
   int grid = (int)((work + 256 * 8 - 1) / (256 * 8));
   if (grid < 1) grid = 1;
   if (grid > 1024) grid = 1024;
   hipStream_t st = to_stream(s);
   switch (C) {
-    case 1: hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
-    case 8: hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
-    case 16: hipLaunchKernelGGL(bn_stats_kernel<16>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
-    case 24: hipLaunchKernelGGL(bn_stats_kernel<24>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
-    case 32: hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 1: hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
+    case 8: hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
+    case 16: hipLaunchKernelGGL(bn_stats_kernel<16>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
+    case 24: hipLaunchKernelGGL(bn_stats_kernel<24>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
+    case 32: hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
     default: return AVA_EINVAL;
   }
   AVA_CHECK_LAUNCH();
@@ -255,9 +301,12 @@ extern "C" int ava_bn_finalize_bwd(const float* partials, int nparts, int64_t n,
 }
 
 // internal (model.hip)
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, hipStream_t st) {
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, const BnFuse* bn,
+                           hipStream_t st) {
   const int grid = B < 256 ? B : 256;
-  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B);
+  BnFuse fuse;
+  if (bn != nullptr) fuse = *bn; else memset(&fuse, 0, sizeof(fuse));
+  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B, fuse);
   AVA_CHECK_LAUNCH();
   *nparts = grid;
   return AVA_OK;

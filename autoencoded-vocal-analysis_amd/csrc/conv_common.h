@@ -1,6 +1,7 @@
 // Shared pieces of the VALU (conv.hip) and matrix-core (conv_mfma.hip) 3x3 gather convolutions.
 #pragma once
 #include "common.h"
+#include "bn_fuse.h"
 
 enum { MODE_S1 = 0, MODE_DOWN = 1, MODE_UP = 2 };
 enum { PRO_BN = 0, PRO_BWD = 1, PRO_ID = 2 };
@@ -24,6 +25,7 @@ struct ConvArgs {
   int relu;
   float prec;
   int tiles_y, tiles_x, ntiles;
+  BnFuse bn; // optional fused BatchNorm finalisation by the last workgroup (bn.counter == nullptr: off)
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };
 

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     a.partials[(size_t)blockIdx.x * 2 * COUT + t] =
         (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]);
   }
+  bn_fused_finalize(a.bn, a.partials, gridDim.x, reinterpret_cast<double*>(smem));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,13 +1,22 @@
 // Whole-path driver: VAE.forward / loss.backward() / Adam.step of ava/models/vae.py:273-353 as a
 // fixed sequence of kernel launches on one HIP stream, over a caller-provided workspace.
 // Host-only bookkeeping lives in `ava_model`; nothing here allocates device memory or synchronises.
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <map>
 #include "conv_common.h"
 
 // internal entry points of the other translation units
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, hipStream_t st);
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, const BnFuse* bn,
+                           hipStream_t st);
+int ava_bn_stats_ex(const float* x, int64_t n, int C, float* partials, int* nparts, const BnFuse* bn, ava_stream_t s);
+int ava_bn_eval_all(const float* const* gamma, const float* const* beta, const int* C, const float* running, float* save,
+                    hipStream_t st);
+int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
+                   const float* G, const float* bias, float* out, float* out2, const float* epi_x,
+                   const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
+                   int Cout, int mode, int pro, int epi, int relu, float prec, const BnFuse* bn, ava_stream_t s);
 int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st);
 int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
@@ -113,6 +122,7 @@ struct ava_model {
   size_t gemm_ws_bytes;
   float* loss_dev;          // 4 floats scratch when the caller passes none
   int* status_dev;
+  int* bn_counters;         // [32] tickets of the fused BatchNorm finalisations (zero between launches)
   float* eps_w_last;
   float* eps_d_last;        // copies of the noise of the last forward (needed by backward)
   int sse_parts;
@@ -196,6 +206,7 @@ static void carve(ava_model* m, void* ws, size_t* total) {
   m->gemm_ws = c.take(m->gemm_ws_bytes / sizeof(float) + 64);
   m->loss_dev = c.take(64);
   m->status_dev = reinterpret_cast<int*>(c.take(64));
+  m->bn_counters = reinterpret_cast<int*>(c.take(64));
   m->eps_w_last = c.take(B);
   m->eps_d_last = c.take(B * z);
   *total = c.off;
@@ -241,6 +252,8 @@ extern "C" int ava_model_create(ava_model** out, int z_dim, int max_batch, float
   if (need > workspace_bytes) { delete m; return AVA_EWORKSPACE; }
   m->lastB = 0;
   m->sse_parts = 0;
+  // the only device write outside a stream: the ticket counters start at zero (every launch leaves them at zero)
+  if (hipMemset(m->bn_counters, 0, 64 * sizeof(int)) != hipSuccess) { delete m; return AVA_ELAUNCH; }
   const size_t B = max_batch;
   for (int l = 1; l < NCONV; ++l) {
     char nm[16];
@@ -348,12 +361,61 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st) {
   return AVA_OK;
 }
 
-static int finalize_bn(ava_model* m, int l, int nparts, int64_t n, int train, hipStream_t st) {
+// fused finalisation descriptors: forward statistics of BatchNorm l (n elements per channel) / its backward sums
+static BnFuse fuse_fwd(ava_model* m, int l, int64_t n) {
   const ConvLayer& L = kLayers[l];
-  struct M { ava_model* m; hipStream_t st; ~M() { mark(m, CAT_BN, st); } } _mk{m, st};
-  return ava_bn_finalize(m->bn_part, nparts, n, L.cin, PP(m, L.pg), PP(m, L.pbeta), m->bn_running + l * 32,
-                         m->bn_running + (NCONV + l) * 32, m->bn_batches + l, train, bn_mean(m, l), bn_invstd(m, l),
-                         bn_scale(m, l), bn_shift(m, l), st);
+  BnFuse f;
+  memset(&f, 0, sizeof(f));
+  f.counter = m->bn_counters + l;
+  f.mode = 1; f.C = L.cin; f.n = (double)n;
+  f.gamma = PP(m, L.pg); f.beta = PP(m, L.pbeta);
+  f.running_mean = m->bn_running + l * 32; f.running_var = m->bn_running + (NCONV + l) * 32;
+  f.num_batches = m->bn_batches + l;
+  f.mean = bn_mean(m, l); f.invstd = bn_invstd(m, l); f.scale = bn_scale(m, l); f.shift = bn_shift(m, l);
+  return f;
+}
+static BnFuse fuse_bwd(ava_model* m, int l, int64_t n) {
+  const ConvLayer& L = kLayers[l];
+  BnFuse f;
+  memset(&f, 0, sizeof(f));
+  f.counter = m->bn_counters + 16 + l;
+  f.mode = 2; f.C = L.cin; f.n = (double)n;
+  f.gamma = PP(m, L.pg);
+  f.mean = bn_mean(m, l); f.invstd = bn_invstd(m, l);
+  f.dgamma = GG(m, L.pg); f.dbeta = GG(m, L.pbeta);
+  f.A = bn_A(m, l); f.Bc = bn_B(m, l); f.Cc = bn_C(m, l);
+  return f;
+}
+// The fused (last-workgroup) finalisation is correct but SLOWER on this part: its agent-scope release fence
+// writes back the whole XCD L2, which is full of the kernel's own freshly written activations, once per
+// workgroup (+0.6 ms/step measured, profiles/r01).  Kept behind AVA_BN_FUSE=1; the default is one tiny
+// finalise launch after each producer.
+static bool bn_fuse_enabled() {
+  static int cached = -1;
+  if (cached < 0) { const char* e = getenv("AVA_BN_FUSE"); cached = (e != nullptr && atoi(e) != 0) ? 1 : 0; }
+  return cached == 1;
+}
+static int finalize_fwd(ava_model* m, int l, int nparts, int64_t n, hipStream_t st) {
+  const ConvLayer& L = kLayers[l];
+  const int rc = ava_bn_finalize(m->bn_part, nparts, n, L.cin, PP(m, L.pg), PP(m, L.pbeta), m->bn_running + l * 32,
+                                 m->bn_running + (NCONV + l) * 32, m->bn_batches + l, 1, bn_mean(m, l), bn_invstd(m, l),
+                                 bn_scale(m, l), bn_shift(m, l), st);
+  mark(m, CAT_BN, st);
+  return rc;
+}
+static int finalize_bwd(ava_model* m, int l, int nparts, int64_t n, hipStream_t st) {
+  const ConvLayer& L = kLayers[l];
+  const int rc = ava_bn_finalize_bwd(m->bn_part, nparts, n, L.cin, PP(m, L.pg), bn_mean(m, l), bn_invstd(m, l),
+                                     GG(m, L.pg), GG(m, L.pbeta), bn_A(m, l), bn_B(m, l), bn_C(m, l), st);
+  mark(m, CAT_BN, st);
+  return rc;
+}
+static int bn_eval_all(ava_model* m, hipStream_t st) {
+  const float* gamma[NCONV]; const float* beta[NCONV]; int C[NCONV];
+  for (int l = 0; l < NCONV; ++l) { gamma[l] = PP(m, kLayers[l].pg); beta[l] = PP(m, kLayers[l].pbeta); C[l] = kLayers[l].cin; }
+  const int rc = ava_bn_eval_all(gamma, beta, C, m->bn_running, m->bn_save, st);
+  mark(m, CAT_BN, st);
+  return rc;
 }
 
 static int gemm(ava_model* m, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
@@ -370,20 +432,27 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
                            int last_act, hipStream_t st) {
   const int z = m->z;
   int nparts = 0;
-  if (train) { TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, st)); mark(m, CAT_BN, st); }
-  TRY(finalize_bn(m, 0, nparts, (int64_t)B * 16384, train, st));
+  if (train) {
+    const bool fuse = bn_fuse_enabled();
+    const BnFuse f0 = fuse_fwd(m, 0, (int64_t)B * 16384);
+    TRY(ava_bn_stats_ex(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, fuse ? &f0 : nullptr, st));
+    mark(m, CAT_BN, st);
+    if (!fuse) TRY(finalize_fwd(m, 0, nparts, (int64_t)B * 16384, st));
+  } else {
+    TRY(bn_eval_all(m, st));       // all 14 layers from the running statistics (also serves the decoder)
+  }
   for (int l = 0; l < 7; ++l) {
     const ConvLayer& L = kLayers[l];
     const float* in = l == 0 ? x : m->X[l];
     float* out = l == 6 ? m->y7 : m->X[l + 1];
-    TRY(ava_conv3x3(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nullptr,
-                    nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
-                    0.f, st));
+    const bool stats = train && l < 6, fuse = stats && bn_fuse_enabled();
+    const BnFuse fn = stats ? fuse_fwd(m, l + 1, (int64_t)B * L.ho * L.ho) : BnFuse{};
+    TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nullptr,
+                       nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
+                       0.f, fuse ? &fn : nullptr, st));
     mark(m, CAT_CONV_FWD, st);
-    if (l < 6) {
-      const int np = ava_conv_grid(B, L.ho, L.ho, L.mode);
-      TRY(finalize_bn(m, l + 1, np, (int64_t)B * L.ho * L.ho, train, st));
-    }
+    if (stats && !fuse)
+      TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, L.ho, L.ho, L.mode), (int64_t)B * L.ho * L.ho, st));
   }
   TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, st));
   mark(m, CAT_LAYOUT, st);
@@ -406,20 +475,23 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
   TRY(gemm(m, m->h6, 0, PP(m, FC7), 0, PP(m, FC7 + 1), m->h7, 0, nullptr, nullptr, B, 1024, 256, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, 8192, 1024, 1, 1, ACT_RELU, st));
   int nparts = 0;
-  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, &nparts, st));
+  const BnFuse f7 = train ? fuse_fwd(m, 7, (int64_t)B * 256) : BnFuse{};
+  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, &nparts, (train && bn_fuse_enabled()) ? &f7 : nullptr, st));
   mark(m, CAT_LAYOUT, st);
-  TRY(finalize_bn(m, 7, nparts, (int64_t)B * 256, train, st));
+  if (train && !bn_fuse_enabled()) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * 256, st));
   for (int l = 7; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
     const bool last = l == NCONV - 1;
     float* out = last ? xrec : m->X[l + 1];
-    TRY(ava_conv3x3(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
-                    last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi,
-                    L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, st));
+    const bool stats = train && !last, fuse = stats && bn_fuse_enabled();
+    const BnFuse fn = stats ? fuse_fwd(m, l + 1, (int64_t)B * L.ho * L.ho) : BnFuse{};
+    TRY(ava_conv3x3_ex(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
+                       last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi,
+                       L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, fuse ? &fn : nullptr, st));
     mark(m, CAT_CONV_FWD, st);
-    const int np = ava_conv_grid(B, L.ho, L.ho, L.mode);
-    if (!last) TRY(finalize_bn(m, l + 1, np, (int64_t)B * L.ho * L.ho, train, st));
-    else m->sse_parts = np;
+    if (stats && !fuse)
+      TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, L.ho, L.ho, L.mode), (int64_t)B * L.ho * L.ho, st));
+    if (last) m->sse_parts = ava_conv_grid(B, L.ho, L.ho, L.mode);
   }
   return AVA_OK;
 }
@@ -460,6 +532,7 @@ extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, flo
   if (m == nullptr || z == nullptr || x_rec == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
   hipStream_t st = to_stream(s);
   TRY(pack_weights(m, false, st));
+  if (!bn_train) TRY(bn_eval_all(m, st));
   return decoder_forward(m, z, nullptr, B, bn_train, x_rec, st);
 }
 
@@ -475,13 +548,12 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   mark(m, CAT_CONV_WGRAD, st);
   // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
   const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
-  TRY(ava_conv3x3(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
-                  m->bn_part, B, L.ho, L.ho, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f, st));
+  const BnFuse fb = fuse_bwd(m, l, (int64_t)B * L.hi * L.hi);
+  TRY(ava_conv3x3_ex(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
+                     m->bn_part, B, L.ho, L.ho, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f,
+                     bn_fuse_enabled() ? &fb : nullptr, st));
   mark(m, CAT_CONV_BWD_DATA, st);
-  const int np = ava_conv_grid(B, L.hi, L.hi, bmode);
-  TRY(ava_bn_finalize_bwd(m->bn_part, np, (int64_t)B * L.hi * L.hi, L.cin, PP(m, L.pg), bn_mean(m, l),
-                          bn_invstd(m, l), GG(m, L.pg), GG(m, L.pbeta), bn_A(m, l), bn_B(m, l), bn_C(m, l), st));
-  mark(m, CAT_BN, st);
+  if (!bn_fuse_enabled()) TRY(finalize_bwd(m, l, ava_conv_grid(B, L.hi, L.hi, bmode), (int64_t)B * L.hi * L.hi, st));
   return AVA_OK;
 }
 

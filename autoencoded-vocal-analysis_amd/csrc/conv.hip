@@ -394,6 +394,8 @@ int ava_conv_wgrad_reduce_all(const WgradReduceTable& tab, int total_blocks, hip
 // ------------------------------------------------------------------------------------------------
 int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st);
 int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);
+int ava_conv3x3_thin(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st);
+int ava_conv3x3_wgrad_thin(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);
 
 // AVA_CONV_IMPL=valu forces the version-0 VALU kernels everywhere (A/B comparisons, debugging)
 static bool use_mfma() {
@@ -495,6 +497,10 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
     const int rc = ava_conv3x3_mfma(a, grid, Cin, Cout, mode, pro, epi, st);
     if (rc != AVA_EINVAL) return rc;       // AVA_EINVAL: no matrix-core instantiation for this shape
   }
+  if (use_mfma()) {                        // single-channel layers at 128x128: dedicated VALU kernels
+    const int rc = ava_conv3x3_thin(a, grid, Cin, Cout, mode, pro, epi, st);
+    if (rc != AVA_EINVAL) return rc;
+  }
 #define AVA_CONV_CASE(ci, co, md, tww) \
   if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_conv_pe<ci, co, md, tww>(a, grid, pro, epi, st);
   // encoder forward / decoder backward-data shapes
@@ -553,7 +559,9 @@ extern "C" int ava_conv3x3_wgrad(const float* x, const float* xa, const float* x
   const int tw = tile_w(a.Wo);
   hipStream_t st = to_stream(s);
   if (use_mfma()) {
-    const int rc = ava_conv3x3_wgrad_mfma(a, grid, Cin, Cout, mode, dy_pro, st);
+    int rc = ava_conv3x3_wgrad_mfma(a, grid, Cin, Cout, mode, dy_pro, st);
+    if (rc != AVA_EINVAL) return rc;
+    rc = ava_conv3x3_wgrad_thin(a, grid, Cin, Cout, mode, dy_pro, st);
     if (rc != AVA_EINVAL) return rc;
   }
 #define AVA_WG_CASE(ci, co, md, tww)                                                          \

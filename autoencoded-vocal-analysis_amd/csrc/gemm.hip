@@ -12,6 +12,7 @@
 // are copied with 16-byte writes.  The next K tile is prefetched into registers while the current
 // one is multiplied.  Small-MN / large-K products are split along K into partial slabs that a
 // second kernel sums (fixed order: deterministic) and finishes with bias + activation.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,15 +40,108 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, bool A_KMAJ, bool B_KMAJ>
+#define AVA_OPAQUE4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+
+// One operand tile (BT rows/cols x BK) global -> registers.  Straight-line code: every lane always loads from a
+// clamped (valid) address and out-of-range elements are zeroed with selects when they are written to LDS -- with the loads under exec-masked
+// branches hipcc serialises them behind s_waitcnt vmcnt(N) (1334 instructions and 51 waits per K step in the
+// first version of this kernel).  VEC: 16-byte loads legal (leading dimension, base pointer and the relevant
+// extent are multiples of 4); otherwise four scalar loads with their own clamps.
+template <int BT, int BK, bool KMAJ, bool VEC>
+struct OperandLoader {
+  static constexpr int N = BT * BK / 4 / 256;
+  float4 r[N];
+  int off[N];       // element offset of this thread's vector inside the matrix for k0 = 0 (row/col clamped)
+  unsigned okrow;   // bit i: row/col of vector i is inside the matrix
+  unsigned okk;     // bit i: K position of vector i (current registers) is inside this split's K range (VEC path)
+  int kk[N];        // KMAJ: k offset (4*kq) of vector i ; MMAJ: k row of vector i
+
+  __device__ __forceinline__ void init(int t0, int extent, int ld) {
+    okrow = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int v = threadIdx.x + 256 * i;
+      if (KMAJ) {
+        const int row = v / (BK / 4), kq = v % (BK / 4);
+        const int g = t0 + row;
+        if (g < extent) okrow |= 1u << i;
+        off[i] = min(g, extent - 1) * ld;
+        kk[i] = 4 * kq;
+      } else {
+        const int k = v / (BT / 4), m4 = v % (BT / 4);
+        const int g = t0 + 4 * m4;
+        if (g < extent) okrow |= 1u << i;           // VEC: extent % 4 == 0, so the whole vector is in or out
+        off[i] = VEC ? min(g, extent - 4) : g;
+        kk[i] = k;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int extent, int k0, int kend, int K) {
+    okk = VEC ? 0u : 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float4 x;
+      if (KMAJ) {
+        const int gk = k0 + kk[i];
+        if (VEC) {
+          x = *reinterpret_cast<const float4*>(base + off[i] + min(gk, K - 4));
+          if (gk < kend) okk |= 1u << i;              // zeroing happens in store(): see the struct comment
+        } else {
+          const float* p = base + off[i];
+          const bool ok = (okrow >> i) & 1u;
+          x.x = (ok && gk + 0 < kend) ? p[min(gk + 0, K - 1)] : 0.f;
+          x.y = (ok && gk + 1 < kend) ? p[min(gk + 1, K - 1)] : 0.f;
+          x.z = (ok && gk + 2 < kend) ? p[min(gk + 2, K - 1)] : 0.f;
+          x.w = (ok && gk + 3 < kend) ? p[min(gk + 3, K - 1)] : 0.f;
+        }
+      } else {
+        const int gk = k0 + kk[i];
+        const float* p = base + (size_t)min(gk, K - 1) * ld;
+        if (VEC) {
+          x = *reinterpret_cast<const float4*>(p + off[i]);
+          if (gk < kend) okk |= 1u << i;
+        } else {
+          const int g = off[i];
+          const bool okk = gk < kend;
+          x.x = (okk && g + 0 < extent) ? p[min(g + 0, extent - 1)] : 0.f;
+          x.y = (okk && g + 1 < extent) ? p[min(g + 1, extent - 1)] : 0.f;
+          x.z = (okk && g + 2 < extent) ? p[min(g + 2, extent - 1)] : 0.f;
+          x.w = (okk && g + 3 < extent) ? p[min(g + 3, extent - 1)] : 0.f;
+        }
+      }
+      r[i] = x;
+    }
+  }
+
+  // registers -> LDS tile [BK][LD] (k-major in LDS; a k-major source is transposed here)
+  template <int LD>
+  __device__ __forceinline__ void store(float* __restrict__ S) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int v = threadIdx.x + 256 * i;
+      float4 x = r[i];
+      if (VEC && !((okrow & okk) >> i & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);   // the select lives here, far from
+      if (KMAJ) {                                                                   // the load, so the load stays unconditional
+        const int row = v / (BK / 4), kq = v % (BK / 4);
+        S[(4 * kq + 0) * LD + row] = x.x;
+        S[(4 * kq + 1) * LD + row] = x.y;
+        S[(4 * kq + 2) * LD + row] = x.z;
+        S[(4 * kq + 3) * LD + row] = x.w;
+      } else {
+        const int k = v / (BT / 4), m4 = v % (BT / 4);
+        *reinterpret_cast<float4*>(&S[k * LD + 4 * m4]) = x;
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, int BK, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
-  constexpr int BK = 16;
   constexpr int LDA_S = BM + (A_KMAJ ? 2 : 4);
   constexpr int LDB_S = BN + (B_KMAJ ? 2 : 4);
   constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;      // 32x32 MFMA tiles per wave
-  constexpr int NA = BM * BK / 4 / 256;          // float4 loads per thread for A (2 or 1)
-  constexpr int NB = BN * BK / 4 / 256;
   __shared__ __align__(16) float As2[2][BK * LDA_S];
   __shared__ __align__(16) float Bs2[2][BK * LDB_S];
 
@@ -66,142 +160,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[NA], rb[NB];
-
-  // ---- global -> register loads of one K tile ------------------------------------------------
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int v = t + i * 256;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (A_KMAJ) {
-        const int m = v >> 2, kq = v & 3;
-        const int gm = m0 + m, gk = k0 + 4 * kq;
-        if (gm < g.M) {
-          const float* p = g.A + (size_t)gm * g.lda + gk;
-          if (g.vec_a && gk + 3 < kend) x = *reinterpret_cast<const float4*>(p);
-          else {
-            if (gk + 0 < kend) x.x = p[0];
-            if (gk + 1 < kend) x.y = p[1];
-            if (gk + 2 < kend) x.z = p[2];
-            if (gk + 3 < kend) x.w = p[3];
-          }
-        }
-      } else {
-        const int k = v / (BM / 4), m4 = v % (BM / 4);
-        const int gk = k0 + k, gm = m0 + 4 * m4;
-        if (gk < kend) {
-          const float* p = g.A + (size_t)gk * g.lda + gm;
-          if (g.vec_a && gm + 3 < g.M) x = *reinterpret_cast<const float4*>(p);
-          else {
-            if (gm + 0 < g.M) x.x = p[0];
-            if (gm + 1 < g.M) x.y = p[1];
-            if (gm + 2 < g.M) x.z = p[2];
-            if (gm + 3 < g.M) x.w = p[3];
-          }
-        }
-      }
-      ra[i] = x;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int v = t + i * 256;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (B_KMAJ) {
-        const int n = v >> 2, kq = v & 3;
-        const int gn = n0 + n, gk = k0 + 4 * kq;
-        if (gn < g.N) {
-          const float* p = g.B + (size_t)gn * g.ldb + gk;
-          if (g.vec_b && gk + 3 < kend) x = *reinterpret_cast<const float4*>(p);
-          else {
-            if (gk + 0 < kend) x.x = p[0];
-            if (gk + 1 < kend) x.y = p[1];
-            if (gk + 2 < kend) x.z = p[2];
-            if (gk + 3 < kend) x.w = p[3];
-          }
-        }
-      } else {
-        const int k = v / (BN / 4), n4 = v % (BN / 4);
-        const int gk = k0 + k, gn = n0 + 4 * n4;
-        if (gk < kend) {
-          const float* p = g.B + (size_t)gk * g.ldb + gn;
-          if (g.vec_b && gn + 3 < g.N) x = *reinterpret_cast<const float4*>(p);
-          else {
-            if (gn + 0 < g.N) x.x = p[0];
-            if (gn + 1 < g.N) x.y = p[1];
-            if (gn + 2 < g.N) x.z = p[2];
-            if (gn + 3 < g.N) x.w = p[3];
-          }
-        }
-      }
-      rb[i] = x;
-    }
-  };
-  auto store_tile = [&](int buf) {
-    float* As = As2[buf];
-    float* Bs = Bs2[buf];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int v = t + i * 256;
-      if (A_KMAJ) {
-        const int m = v >> 2, kq = v & 3;
-        As[(4 * kq + 0) * LDA_S + m] = ra[i].x;
-        As[(4 * kq + 1) * LDA_S + m] = ra[i].y;
-        As[(4 * kq + 2) * LDA_S + m] = ra[i].z;
-        As[(4 * kq + 3) * LDA_S + m] = ra[i].w;
-      } else {
-        const int k = v / (BM / 4), m4 = v % (BM / 4);
-        *reinterpret_cast<float4*>(&As[k * LDA_S + 4 * m4]) = ra[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int v = t + i * 256;
-      if (B_KMAJ) {
-        const int n = v >> 2, kq = v & 3;
-        Bs[(4 * kq + 0) * LDB_S + n] = rb[i].x;
-        Bs[(4 * kq + 1) * LDB_S + n] = rb[i].y;
-        Bs[(4 * kq + 2) * LDB_S + n] = rb[i].z;
-        Bs[(4 * kq + 3) * LDB_S + n] = rb[i].w;
-      } else {
-        const int k = v / (BN / 4), n4 = v % (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[k * LDB_S + 4 * n4]) = rb[i];
-      }
-    }
-  };
+  OperandLoader<BM, BK, A_KMAJ, VEC> la;
+  OperandLoader<BN, BK, B_KMAJ, VEC> lb;
+  la.init(m0, g.M, g.lda);
+  lb.init(n0, g.N, g.ldb);
 
   float csum = 0.f;   // column sum of A (bias gradient), thread t < BM owns column t
   const bool do_colsum = g.colsum != nullptr && blockIdx.x == 0;
 
   // software pipeline: tile k+1 travels global -> registers while tile k is multiplied out of LDS buffer
   // (k & 1); it is written to the other buffer after the MFMAs, one barrier per K step.
-  if (kbeg < kend) { load_tile(kbeg); store_tile(0); }
+  if (kbeg < kend) {
+    la.load(g.A, g.lda, g.M, kbeg, kend, g.K);
+    lb.load(g.B, g.ldb, g.N, kbeg, kend, g.K);
+    la.template store<LDA_S>(As2[0]);
+    lb.template store<LDB_S>(Bs2[0]);
+  }
   __syncthreads();
   int cur = 0;
+  const int kq = lane >> 5, li = lane & 31;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
-    if (more) load_tile(k0 + BK);
+    if (more) {
+      la.load(g.A, g.lda, g.M, k0 + BK, kend, g.K);
+      lb.load(g.B, g.ldb, g.N, k0 + BK, kend, g.K);
+    }
     const float* As = As2[cur];
     const float* Bs = Bs2[cur];
     if (do_colsum && t < BM) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) csum += As[k * LDA_S + t];
     }
-    const int kq = lane >> 5, li = lane & 31;
+    // fragments of k-pair kk+2 are fetched from LDS before the MFMAs of k-pair kk are issued
+    float af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = As[kq * LDA_S + wm * WM + i * 32 + li];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = Bs[kq * LDB_S + wn * WN + j * 32 + li];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float af[TM], bf[TN];
+      const int c = (kk >> 1) & 1, nx = c ^ 1;
+      if (kk + 2 < BK) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[(kk + kq) * LDA_S + wm * WM + i * 32 + li];
+        for (int i = 0; i < TM; ++i) af[nx][i] = As[(kk + 2 + kq) * LDA_S + wm * WM + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + kq) * LDB_S + wn * WN + j * 32 + li];
+        for (int j = 0; j < TN; ++j) bf[nx][j] = Bs[(kk + 2 + kq) * LDB_S + wn * WN + j * 32 + li];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(cur ^ 1);
+    if (more) {
+      la.template store<LDA_S>(As2[cur ^ 1]);
+      lb.template store<LDB_S>(Bs2[cur ^ 1]);
+    }
     __syncthreads();
     cur ^= 1;
   }
@@ -273,6 +287,7 @@ static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
   }
+  { const char* e = getenv("AVA_GEMM_SPLITS"); if (e && tiles < 384) { s = atoi(e); if (s > K / 16) s = K / 16; if (s < 1) s = 1; } }
   int kl = ceil_div(ceil_div(K, s), 16) * 16;
   s = ceil_div(K, kl);
   *splits = s;
@@ -285,12 +300,12 @@ extern "C" size_t ava_gemm_workspace_bytes(int M, int N, int K) {
   return splits > 1 ? ((size_t)splits * M * N + (size_t)splits * M) * sizeof(float) : 0;
 }
 
-template <int BM>
+template <int BM, int BK, bool VEC>
 static void launch_gemm(const GemmArgs& g, int a_k, int b_k, dim3 grid, hipStream_t st) {
-  if (a_k && b_k) hipLaunchKernelGGL((gemm_kernel<BM, BM, true, true>), grid, dim3(256), 0, st, g);
-  else if (a_k && !b_k) hipLaunchKernelGGL((gemm_kernel<BM, BM, true, false>), grid, dim3(256), 0, st, g);
-  else if (!a_k && b_k) hipLaunchKernelGGL((gemm_kernel<BM, BM, false, true>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_kernel<BM, BM, false, false>), grid, dim3(256), 0, st, g);
+  if (a_k && b_k) hipLaunchKernelGGL((gemm_kernel<BM, BM, true, true, BK, VEC>), grid, dim3(256), 0, st, g);
+  else if (a_k && !b_k) hipLaunchKernelGGL((gemm_kernel<BM, BM, true, false, BK, VEC>), grid, dim3(256), 0, st, g);
+  else if (!a_k && b_k) hipLaunchKernelGGL((gemm_kernel<BM, BM, false, true, BK, VEC>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_kernel<BM, BM, false, false, BK, VEC>), grid, dim3(256), 0, st, g);
 }
 
 extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
@@ -308,12 +323,24 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   g.ldb = ldb > 0 ? ldb : (b_kmajor ? K : N);
   g.ldc = ldc > 0 ? ldc : N;
   g.klen = klen; g.splits = splits; g.act = act;
-  g.vec_a = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  g.vec_b = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  // 16-byte loads: leading dimensions / base pointers 16-byte aligned, K % 4 == 0 for k-major operands,
+  // M (N) % 4 == 0 for m-major (n-major) ones; anything else takes the scalar-load instantiation
+  g.vec_a = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (a_kmajor ? K % 4 == 0 && K >= 4 : M % 4 == 0 && M >= 4);
+  g.vec_b = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (b_kmajor ? K % 4 == 0 && K >= 4 : N % 4 == 0 && N >= 4);
+  const bool vec = g.vec_a && g.vec_b;
   hipStream_t st = to_stream(s);
   dim3 grid(ceil_div(N, bm), ceil_div(M, bm), splits);
-  if (bm == 128) launch_gemm<128>(g, a_kmajor, b_kmajor, grid, st);
-  else launch_gemm<64>(g, a_kmajor, b_kmajor, grid, st);
+  static int bk32 = -1;
+  if (bk32 < 0) { const char* e = getenv("AVA_GEMM_BK"); bk32 = (e && atoi(e) == 16) ? 0 : 1; }
+  if (!vec) {
+    if (bm == 128) launch_gemm<128, 16, false>(g, a_kmajor, b_kmajor, grid, st);
+    else launch_gemm<64, 16, false>(g, a_kmajor, b_kmajor, grid, st);
+  } else if (bm == 128) {
+    if (bk32 && klen % 32 == 0) launch_gemm<128, 32, true>(g, a_kmajor, b_kmajor, grid, st);
+    else launch_gemm<128, 16, true>(g, a_kmajor, b_kmajor, grid, st);
+  } else {
+    launch_gemm<64, 16, true>(g, a_kmajor, b_kmajor, grid, st);
+  }
   AVA_CHECK_LAUNCH();
   if (splits > 1) {
     const size_t mn = (size_t)M * N;

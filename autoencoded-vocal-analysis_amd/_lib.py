@@ -47,7 +47,7 @@ SIGNATURES = {
     "ava_workspace_bytes": (_sz, [_i, _i]),
     "ava_model_create": (_i, [C.POINTER(_p), _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz]),
     "ava_model_destroy": (None, [_p]),
-    "ava_forward": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p]),
+    "ava_forward": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ava_backward": (_i, [_p, _p, _i, _p]),
     "ava_adam_step": (_i, [_p, _d, _d, _d, _d, _i, _p]),
     "ava_encode": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),

@@ -147,24 +147,42 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
 }
 
 // ---- NCHW-flatten <-> NHWC hand-offs (per sample: 32 channels x 256 pixels) --------------------------
+// One workgroup handles a quarter sample: 32 channels x 64 pixels (2048 floats) through a padded LDS tile,
+// so 4*B workgroups keep every CU busy (one workgroup per sample left 3/4 of the waves idle: 20 us -> ~5 us).
+// NCHW element (c, p) of sample b: b*8192 + c*256 + p ; NHWC element: b*8192 + p*32 + c.
+#define QPIX 64
+__device__ __forceinline__ void load_nchw_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q) {
+  for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
+    const int c = i / QPIX, p = i % QPIX;                    // 64 consecutive pixels of one channel: coalesced
+    tile[c][p] = src[(size_t)b * 8192 + c * 256 + q * QPIX + p];
+  }
+}
+__device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q) {
+  for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
+    const int p = i >> 5, c = i & 31;                        // the quarter is one contiguous 8 KB range
+    tile[c][p] = src[(size_t)b * 8192 + (q * QPIX) * 32 + i];
+  }
+}
+
 // f8 [B][32*256] (c*256+p) -> out [B][256][32], plus per-channel {sum, sum^2} partials for bn8
 __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                  float* __restrict__ partials, int B,
                                                                  const BnFuse fuse) {
-  __shared__ float tile[32][257];
+  __shared__ float tile[32][QPIX + 1];
   __shared__ float red[8][64];
   __shared__ double fuse_scratch[260];
   const int t = threadIdx.x;
   float s1 = 0.f, s2 = 0.f;                 // thread -> channel t&31, 8 threads per channel
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
+    const int b = w >> 2, q = w & 3;
     __syncthreads();
-    for (int i = t; i < 8192; i += 256) tile[i >> 8][i & 255] = in[(size_t)b * 8192 + i];
+    load_nchw_quarter(tile, in, b, q);
     __syncthreads();
-    for (int i = t; i < 8192; i += 256) {
-      const int p = i >> 5, c = i & 31;
+    for (int i = t; i < 32 * QPIX; i += 256) {
+      const int p = i >> 5, c = i & 31;     // c == t & 31 for every i of this thread
       const float v = tile[c][p];
-      out[(size_t)b * 8192 + i] = v;
-      s1 += v;                              // c == t&31 for every i of this thread
+      out[(size_t)b * 8192 + (q * QPIX) * 32 + i] = v;
+      s1 += v;
       s2 = fmaf(v, v, s2);
     }
   }
@@ -178,6 +196,60 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
     partials[(size_t)blockIdx.x * 64 + t] = s;
   }
   bn_fused_finalize(fuse, partials, gridDim.x, fuse_scratch);
+}
+
+// y7 [B][256][32] -> out [B][32*256]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B) {
+  __shared__ float tile[32][QPIX + 1];
+  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
+    const int b = w >> 2, q = w & 3;
+    __syncthreads();
+    load_nhwc_quarter(tile, in, b, q);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
+      const int c = i / QPIX, p = i % QPIX;
+      out[(size_t)b * 8192 + c * 256 + q * QPIX + p] = tile[c][p];
+    }
+  }
+}
+
+// dU7 (NHWC) = (y7 > 0) ? dy7 (NCHW-flatten, from fc1's backward) : 0       (ReLU of vae.py:223)
+__global__ __launch_bounds__(256) void relu_mask_to_nhwc_kernel(const float* __restrict__ dy_nchw,
+                                                                const float* __restrict__ y_nhwc,
+                                                                float* __restrict__ du_nhwc, int B) {
+  __shared__ float tile[32][QPIX + 1];
+  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
+    const int b = w >> 2, q = w & 3;
+    __syncthreads();
+    load_nchw_quarter(tile, dy_nchw, b, q);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
+      const size_t o = (size_t)b * 8192 + (q * QPIX) * 32 + i;
+      du_nhwc[o] = y_nhwc[o] > 0.f ? tile[i & 31][i >> 5] : 0.f;
+    }
+  }
+}
+
+// dF8 (NCHW-flatten) = (f8 > 0) ? A[c]*g + Bc[c]*f8 + Cc[c] : 0 ; g = dXhat8 (NHWC)   (bn8 backward + ReLU of fc8)
+__global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* __restrict__ g_nhwc,
+                                                                   const float* __restrict__ f8_nchw,
+                                                                   const float* __restrict__ A,
+                                                                   const float* __restrict__ Bc,
+                                                                   const float* __restrict__ Cc,
+                                                                   float* __restrict__ out_nchw, int B) {
+  __shared__ float tile[32][QPIX + 1];
+  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
+    const int b = w >> 2, q = w & 3;
+    __syncthreads();
+    load_nhwc_quarter(tile, g_nhwc, b, q);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
+      const int c = i / QPIX, p = i % QPIX;
+      const size_t o = (size_t)b * 8192 + c * 256 + q * QPIX + p;
+      const float f = f8_nchw[o];
+      out_nchw[o] = f > 0.f ? fmaf(A[c], tile[c][p], fmaf(Bc[c], f, Cc[c])) : 0.f;
+    }
+  }
 }
 
 // eval mode (module.eval()): scale/shift of all 14 BatchNorm layers from their running statistics, one launch
@@ -200,56 +272,6 @@ int ava_bn_eval_all(const float* const* gamma, const float* const* beta, const i
   hipLaunchKernelGGL(bn_eval_all_kernel, dim3(14), dim3(32), 0, st, tab, running, save);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
-}
-
-// y7 [B][256][32] -> out [B][32*256]
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B) {
-  __shared__ float tile[32][257];
-  const int t = threadIdx.x;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    __syncthreads();
-    for (int i = t; i < 8192; i += 256) tile[i & 31][i >> 5] = in[(size_t)b * 8192 + i];
-    __syncthreads();
-    for (int i = t; i < 8192; i += 256) out[(size_t)b * 8192 + i] = tile[i >> 8][i & 255];
-  }
-}
-
-// dU7 (NHWC) = (y7 > 0) ? dy7 (NCHW-flatten, from fc1's backward) : 0       (ReLU of vae.py:223)
-__global__ __launch_bounds__(256) void relu_mask_to_nhwc_kernel(const float* __restrict__ dy_nchw,
-                                                                const float* __restrict__ y_nhwc,
-                                                                float* __restrict__ du_nhwc, int B) {
-  __shared__ float tile[32][257];
-  const int t = threadIdx.x;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    __syncthreads();
-    for (int i = t; i < 8192; i += 256) tile[i >> 8][i & 255] = dy_nchw[(size_t)b * 8192 + i];
-    __syncthreads();
-    for (int i = t; i < 8192; i += 256) {
-      const float y = y_nhwc[(size_t)b * 8192 + i];
-      du_nhwc[(size_t)b * 8192 + i] = y > 0.f ? tile[i & 31][i >> 5] : 0.f;
-    }
-  }
-}
-
-// dF8 (NCHW-flatten) = (f8 > 0) ? A[c]*g + Bc[c]*f8 + Cc[c] : 0 ; g = dXhat8 (NHWC)   (bn8 backward + ReLU of fc8)
-__global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* __restrict__ g_nhwc,
-                                                                   const float* __restrict__ f8_nchw,
-                                                                   const float* __restrict__ A,
-                                                                   const float* __restrict__ Bc,
-                                                                   const float* __restrict__ Cc,
-                                                                   float* __restrict__ out_nchw, int B) {
-  __shared__ float tile[32][257];
-  const int t = threadIdx.x;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    __syncthreads();
-    for (int i = t; i < 8192; i += 256) tile[i & 31][i >> 5] = g_nhwc[(size_t)b * 8192 + i];
-    __syncthreads();
-    for (int i = t; i < 8192; i += 256) {
-      const int c = i >> 8;
-      const float f = f8_nchw[(size_t)b * 8192 + i];
-      out_nchw[(size_t)b * 8192 + i] = f > 0.f ? fmaf(A[c], tile[c][i & 255], fmaf(Bc[c], f, Cc[c])) : 0.f;
-    }
-  }
 }
 
 int ava_bn_stats_ex(const float* x, int64_t n, int C, float* partials, int* nparts, const BnFuse* bn, ava_stream_t s);
@@ -303,7 +325,7 @@ extern "C" int ava_bn_finalize_bwd(const float* partials, int nparts, int64_t n,
 // internal (model.hip)
 int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, const BnFuse* bn,
                            hipStream_t st) {
-  const int grid = B < 256 ? B : 256;
+  const int grid = 4 * B < 1024 ? 4 * B : 1024;
   BnFuse fuse;
   if (bn != nullptr) fuse = *bn; else memset(&fuse, 0, sizeof(fuse));
   hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B, fuse);
@@ -312,18 +334,18 @@ int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, 
   return AVA_OK;
 }
 int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st) {
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, st, in, out, B);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(4 * B < 2048 ? 4 * B : 2048), dim3(256), 0, st, in, out, B);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st) {
-  hipLaunchKernelGGL(relu_mask_to_nhwc_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, st, dy_nchw, y_nhwc, du, B);
+  hipLaunchKernelGGL(relu_mask_to_nhwc_kernel, dim3(4 * B < 2048 ? 4 * B : 2048), dim3(256), 0, st, dy_nchw, y_nhwc, du, B);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
                              float* out, int B, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel, dim3(B < 1024 ? B : 1024), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B);
+  hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel, dim3(4 * B < 2048 ? 4 * B : 2048), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -22,7 +22,7 @@ int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, 
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
                              float* out, int B, hipStream_t st);
 int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
-                              int zdim, float prec, float* loss_out, hipStream_t st);
+                              int zdim, float prec, float* loss_out, double* loss_accum, hipStream_t st);
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_EXP = 2 };
 
@@ -123,8 +123,8 @@ struct ava_model {
   float* loss_dev;          // 4 floats scratch when the caller passes none
   int* status_dev;
   int* bn_counters;         // [32] tickets of the fused BatchNorm finalisations (zero between launches)
-  float* eps_w_last;
-  float* eps_d_last;        // copies of the noise of the last forward (needed by backward)
+  const float* eps_w_last;
+  const float* eps_d_last;  // noise of the last forward (caller-owned; needed again by backward)
   int sse_parts;
   int lastB;
   Prof prof;
@@ -207,8 +207,6 @@ static void carve(ava_model* m, void* ws, size_t* total) {
   m->loss_dev = c.take(64);
   m->status_dev = reinterpret_cast<int*>(c.take(64));
   m->bn_counters = reinterpret_cast<int*>(c.take(64));
-  m->eps_w_last = c.take(B);
-  m->eps_d_last = c.take(B * z);
   *total = c.off;
 }
 
@@ -497,23 +495,20 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
 }
 
 extern "C" int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d, int bn_train,
-                           float* loss_out, int* status_out, ava_stream_t s) {
+                           float* loss_out, double* loss_accum, int* status_out, ava_stream_t s) {
   if (m == nullptr || x == nullptr || eps_w == nullptr || eps_d == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
   hipStream_t st = to_stream(s);
   const int z = m->z;
   TRY(pack_weights(m, true, st));
   TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st));
-  if (status_out != nullptr) { if (hipMemsetAsync(status_out, 0, sizeof(int), st) != hipSuccess) return AVA_ELAUNCH; }
   mark(m, CAT_LAYOUT, st);
   TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
-  if (eps_w != m->eps_w_last) {
-    if (hipMemcpyAsync(m->eps_w_last, eps_w, sizeof(float) * B, hipMemcpyDeviceToDevice, st) != hipSuccess) return AVA_ELAUNCH;
-    if (hipMemcpyAsync(m->eps_d_last, eps_d, sizeof(float) * B * z, hipMemcpyDeviceToDevice, st) != hipSuccess) return AVA_ELAUNCH;
-  }
+  m->eps_w_last = eps_w;          // backward reads the same noise: the caller keeps it alive until then
+  m->eps_d_last = eps_d;
   mark(m, CAT_LATENT_LOSS, st);
   TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st));
   TRY(ava_elbo_finalize_strided(m->lat_sums, B, m->bn_part, m->sse_parts, 2, z, m->prec,
-                                loss_out != nullptr ? loss_out : m->loss_dev, st));
+                                loss_out != nullptr ? loss_out : m->loss_dev, loss_accum, st));
   mark(m, CAT_LATENT_LOSS, st);
   m->lastB = B;
   return AVA_OK;

@@ -265,14 +265,16 @@ class VAE(nn.Module):
         return self._eps[:B], self._eps[B:n].view(B, self.z_dim)
 
     # ------------------------------------------------------------------ device-side step pieces
-    def _forward_device(self, x, need_grad):
+    def _forward_device(self, x, need_grad, accumulate=False):
         """Runs ava_forward; returns the 0-dim loss view (device).  BatchNorm mode follows
-        ``self.training`` exactly like nn.BatchNorm2d does in the reference."""
+        ``self.training`` exactly like nn.BatchNorm2d does in the reference.  ``accumulate`` adds the
+        loss to ``self._loss_acc`` on the device (the epoch loops' running sum)."""
         B = x.shape[0]
         self._ensure(B)
         ew, ed = self._noise(B)
         rc = _lib.load().ava_forward(self._handle, x.data_ptr(), B, ew.data_ptr(), ed.data_ptr(),
                                      1 if self.training else 0, self._loss_buf.data_ptr(),
+                                     self._loss_acc.data_ptr() if accumulate else None,
                                      self._status.data_ptr(), _lib.stream())
         _lib.check(rc, "ava_forward")
         self._last_x = x
@@ -286,6 +288,7 @@ class VAE(nn.Module):
 
     def _check_status(self):
         if int(self._status.item()) != 0:
+            self._status.zero_()
             # LowRankMultivariateNormal's argument validation (vae.py:312) raises the same type
             raise ValueError("Expected parameter cov_diag to be positive (d = exp(.) under/overflowed)")
 
@@ -351,8 +354,7 @@ class VAE(nn.Module):
         for batch_idx, data in enumerate(train_loader):
             self.optimizer.zero_grad()
             data = self._prep_x(data)
-            loss = self._forward_device(data, need_grad=True)
-            self._loss_acc += loss
+            self._forward_device(data, need_grad=True, accumulate=True)
             self._backward_device(data)
             self.optimizer.step()
         self._check_status()
@@ -369,7 +371,7 @@ class VAE(nn.Module):
         with torch.no_grad():
             for i, data in enumerate(test_loader):
                 data = self._prep_x(data)
-                self._loss_acc += self._forward_device(data, need_grad=False)
+                self._forward_device(data, need_grad=False, accumulate=True)
         self._check_status()
         test_loss = float(self._loss_acc.item()) / len(test_loader.dataset)
         print('Test loss: {:.4f}'.format(test_loss))

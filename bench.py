@@ -51,8 +51,7 @@ def parse():
 def one_step(model, x):
     """The body of VAE.train_epoch's loop (vae.py:347-353)."""
     model.optimizer.zero_grad()
-    loss = model._forward_device(x, need_grad=True)
-    model._loss_acc += loss
+    model._forward_device(x, need_grad=True, accumulate=True)
     model._backward_device(x)
     model.optimizer.step()
 

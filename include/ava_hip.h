@@ -57,10 +57,14 @@ void ava_model_destroy(ava_model* m);
  *   x [B,128,128]; eps_w [B], eps_d [B,z]: the two normal draws of rsample in reference order.
  *   bn_train: 1 = batch statistics + running-stat update (module.train()), 0 = running stats.
  *   loss_out (device, 4 floats): {-ELBO, sum z^2, SSE, sum entropy}.
- *   status_out (device int): set to 1 when some d is not > 0 (reference raises ValueError).
+ *   loss_accum (device double, may be NULL): -ELBO is also added to it (the epoch loops' running sum,
+ *     vae.py:351,382, kept on the device so that no step needs a host sync).
+ *   status_out (device int, may be NULL): OR-ed with 1 when some d is not > 0 (reference raises ValueError);
+ *     sticky -- the caller clears it after reading.
+ * x, eps_w, eps_d must stay valid until ava_backward has run.
  * Leaves every intermediate needed by ava_backward in the workspace. */
 int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d,
-                int bn_train, float* loss_out, int* status_out, ava_stream_t s);
+                int bn_train, float* loss_out, double* loss_accum, int* status_out, ava_stream_t s);
 /* loss.backward() (vae.py:352) for the forward that just ran: fills the gradient arena
  * (overwrites: the reference zero_grad()s before every step, vae.py:348). */
 int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);

@@ -137,7 +137,7 @@ struct OperandLoader {
 };
 
 template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, int BK, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int split) {
   constexpr int LDA_S = BM + (A_KMAJ ? 2 : 4);
   constexpr int LDB_S = BN + (B_KMAJ ? 2 : 4);
   constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
@@ -147,8 +147,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int split = blockIdx.z;
+  const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = split * g.klen;
   const int kend = min(g.K, kbeg + g.klen);
 
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   lb.init(n0, g.N, g.ldb);
 
   float csum = 0.f;   // column sum of A (bias gradient), thread t < BM owns column t
-  const bool do_colsum = g.colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = g.colsum != nullptr && bx == 0;
 
   // software pipeline: tile k+1 travels global -> registers while tile k is multiplied out of LDS buffer
   // (k & 1); it is written to the other buffer after the MFMAs, one barrier per K step.
@@ -250,6 +249,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     if (fin) g.colsum[m0 + t] = csum;
     else g.C[(size_t)g.splits * g.M * g.N + (size_t)split * g.M + m0 + t] = csum;   // partial, behind the slabs
   }
+}
+
+template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, int BK, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+  gemm_body<BM, BN, A_KMAJ, B_KMAJ, BK, VEC>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// several independent small products (same operand layouts, no split-K) in ONE launch: blockIdx.z selects the
+// problem, workgroups outside a problem's tile range exit at once.  Used for the three 64->z heads and for all
+// the small weight-gradient products of the fully connected layers (8 launches -> 1).
+#define AVA_GEMM_GROUP_MAX 8
+struct GemmGroup {
+  GemmArgs g[AVA_GEMM_GROUP_MAX];
+};
+template <int BM, bool A_KMAJ, bool B_KMAJ, bool VEC>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmGroup grp) {
+  const GemmArgs& g = grp.g[blockIdx.z];
+  if ((int)blockIdx.x * BM >= g.N || (int)blockIdx.y * BM >= g.M) return;
+  gemm_body<BM, BM, A_KMAJ, B_KMAJ, 16, VEC>(g, blockIdx.x, blockIdx.y, 0);
 }
 
 // sum the split-K slabs in a fixed order, add bias, activation
@@ -350,5 +368,46 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
                        mask, C, colsum, M, N, g.ldc, splits, act);
     AVA_CHECK_LAUNCH();
   }
+  return AVA_OK;
+}
+
+// internal (model.hip): n <= 8 products with identical operand layouts in one launch (64x64 tiles, no split-K)
+struct AvaGemmProblem {
+  const float* A; int lda; const float* B; int ldb; const float* bias; float* C; int ldc; const float* mask;
+  float* colsum; int M, N, K; int act;
+};
+int ava_gemm_grouped(const AvaGemmProblem* p, int n, int a_kmajor, int b_kmajor, hipStream_t st) {
+  if (n < 1 || n > AVA_GEMM_GROUP_MAX) return AVA_EINVAL;
+  GemmGroup grp;
+  bool vec = true;
+  int tx = 1, ty = 1;
+  for (int i = 0; i < n; ++i) {
+    GemmArgs& g = grp.g[i];
+    if (p[i].A == nullptr || p[i].B == nullptr || p[i].C == nullptr || p[i].M <= 0 || p[i].N <= 0 || p[i].K <= 0)
+      return AVA_EINVAL;
+    g.A = p[i].A; g.B = p[i].B; g.bias = p[i].bias; g.C = p[i].C; g.colsum = p[i].colsum; g.mask = p[i].mask;
+    g.M = p[i].M; g.N = p[i].N; g.K = p[i].K;
+    g.lda = p[i].lda > 0 ? p[i].lda : (a_kmajor ? g.K : g.M);
+    g.ldb = p[i].ldb > 0 ? p[i].ldb : (b_kmajor ? g.K : g.N);
+    g.ldc = p[i].ldc > 0 ? p[i].ldc : g.N;
+    g.klen = ceil_div(g.K, 16) * 16; g.splits = 1; g.act = p[i].act;
+    g.vec_a = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
+              (a_kmajor ? g.K % 4 == 0 && g.K >= 4 : g.M % 4 == 0 && g.M >= 4);
+    g.vec_b = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&
+              (b_kmajor ? g.K % 4 == 0 && g.K >= 4 : g.N % 4 == 0 && g.N >= 4);
+    vec = vec && g.vec_a && g.vec_b;
+    tx = tx > ceil_div(g.N, 64) ? tx : ceil_div(g.N, 64);
+    ty = ty > ceil_div(g.M, 64) ? ty : ceil_div(g.M, 64);
+  }
+  const dim3 grid(tx, ty, n);
+#define AVA_GG(AK, BK_)                                                                                          \
+  if (vec) hipLaunchKernelGGL((gemm_grouped_kernel<64, AK, BK_, true>), grid, dim3(256), 0, st, grp);            \
+  else hipLaunchKernelGGL((gemm_grouped_kernel<64, AK, BK_, false>), grid, dim3(256), 0, st, grp);
+  if (a_kmajor && b_kmajor) { AVA_GG(true, true) }
+  else if (a_kmajor && !b_kmajor) { AVA_GG(true, false) }
+  else if (!a_kmajor && b_kmajor) { AVA_GG(false, true) }
+  else { AVA_GG(false, false) }
+#undef AVA_GG
+  AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -422,6 +422,17 @@ static int gemm(ava_model* m, const float* A, int lda, const float* B, int ldb, 
   return ava_gemm(A, lda, B, ldb, bias, C, ldc, mask, colsum, M, N, K, ak, bk, act, m->gemm_ws, m->gemm_ws_bytes, st);
 }
 
+struct AvaGemmProblem {
+  const float* A; int lda; const float* B; int ldb; const float* bias; float* C; int ldc; const float* mask;
+  float* colsum; int M, N, K; int act;
+};
+int ava_gemm_grouped(const AvaGemmProblem* p, int n, int a_kmajor, int b_kmajor, hipStream_t st);
+static int gemm_group(ava_model* m, const AvaGemmProblem* p, int n, int ak, int bk, hipStream_t st) {
+  const int rc = ava_gemm_grouped(p, n, ak, bk, st);
+  mark(m, CAT_GEMM, st);
+  return rc;
+}
+
 // parameter indices of the fully connected layers
 enum { FC1 = 28, FC2 = 30, FC31 = 32, FC32 = 34, FC33 = 36, FC41 = 38, FC42 = 40, FC43 = 42, FC5 = 44, FC6 = 46,
        FC7 = 48, FC8 = 50 };
@@ -458,10 +469,12 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
   TRY(gemm(m, m->h1, 0, PP(m, FC2), 0, PP(m, FC2 + 1), m->h2, 0, nullptr, nullptr, B, 256, 1024, 1, 1, ACT_RELU, st));
   // fc31|fc32|fc33 as one [192,256] layer (arena keeps the three weights, then the three biases, contiguous)
   TRY(gemm(m, m->h2, 0, PP(m, FC31), 0, PP(m, FC31 + 1), m->h3, 0, nullptr, nullptr, B, 192, 256, 1, 1, ACT_RELU, st));
-  TRY(gemm(m, m->h3 + 0, 192, PP(m, FC41), 0, PP(m, FC41 + 1), mu, 0, nullptr, nullptr, B, z, 64, 1, 1, ACT_NONE, st));
-  TRY(gemm(m, m->h3 + 64, 192, PP(m, FC42), 0, PP(m, FC42 + 1), u, 0, nullptr, nullptr, B, z, 64, 1, 1, ACT_NONE, st));
-  TRY(gemm(m, m->h3 + 128, 192, PP(m, FC43), 0, PP(m, FC43 + 1), logd_or_d, 0, nullptr, nullptr, B, z, 64, 1, 1,
-           last_act, st));
+  // the three 64 -> z heads (mu, u, log d) on the 64-wide slices of h3: one grouped launch
+  const AvaGemmProblem heads[3] = {
+      {m->h3 + 0, 192, PP(m, FC41), 0, PP(m, FC41 + 1), mu, 0, nullptr, nullptr, B, z, 64, ACT_NONE},
+      {m->h3 + 64, 192, PP(m, FC42), 0, PP(m, FC42 + 1), u, 0, nullptr, nullptr, B, z, 64, ACT_NONE},
+      {m->h3 + 128, 192, PP(m, FC43), 0, PP(m, FC43 + 1), logd_or_d, 0, nullptr, nullptr, B, z, 64, last_act}};
+  TRY(gemm_group(m, heads, 3, 1, 1, st));
   return AVA_OK;
 }
 
@@ -570,33 +583,38 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
   TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, st));
   mark(m, CAT_LAYOUT, st);
-  // ---- decoder fully connected: dW = dY^T X (+ db), dX = (dY W) masked by the producer's ReLU ----
+  // ---- fully connected layers.  dX = (dY W) masked by the producer's ReLU runs as a chain; the weight
+  // gradients dW = dY^T X (+ db = column sums) only need buffers that stay valid, so the two big ones are
+  // issued in place and the eight small ones are collected into ONE grouped launch at the end. ----
   TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), 8192, 1024, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dF8, 0, PP(m, FC8), 0, nullptr, m->dh7, 0, m->h7, nullptr, B, 1024, 8192, 1, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh7, 0, m->h6, 0, nullptr, GG(m, FC7), 0, nullptr, GG(m, FC7 + 1), 1024, 256, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh7, 0, PP(m, FC7), 0, nullptr, m->dh6, 0, m->h6, nullptr, B, 256, 1024, 1, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh6, 0, m->h5, 0, nullptr, GG(m, FC6), 0, nullptr, GG(m, FC6 + 1), 256, 64, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh6, 0, PP(m, FC6), 0, nullptr, m->dh5, 0, m->h5, nullptr, B, 64, 256, 1, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh5, 0, m->zs, 0, nullptr, GG(m, FC5), 0, nullptr, GG(m, FC5 + 1), 64, z, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh5, 0, PP(m, FC5), 0, nullptr, m->dz, 0, nullptr, nullptr, B, z, 64, 1, 0, ACT_NONE, st));
   // ---- latent block ----
   TRY(ava_latent_bwd(m->zs, m->dz, m->u, m->d, m->eps_w_last, m->eps_d_last, m->dmu, m->du, m->dlogd, B, z, st));
   mark(m, CAT_LATENT_LOSS, st);
-  // ---- heads: fc41/42/43 (64 -> z) on the three 64-wide slices of h3 ----
-  const float* dheads[3] = {m->dmu, m->du, m->dlogd};
-  const int fc4[3] = {FC41, FC42, FC43};
-  for (int i = 0; i < 3; ++i) {
-    TRY(gemm(m, dheads[i], 0, m->h3 + 64 * i, 192, nullptr, GG(m, fc4[i]), 0, nullptr, GG(m, fc4[i] + 1), z, 64, B, 0,
-             0, ACT_NONE, st));
-    TRY(gemm(m, dheads[i], 0, PP(m, fc4[i]), 0, nullptr, m->dh3 + 64 * i, 192, m->h3 + 64 * i, nullptr, B, 64, z, 1, 0,
-             ACT_NONE, st));
-  }
-  TRY(gemm(m, m->dh3, 0, m->h2, 0, nullptr, GG(m, FC31), 0, nullptr, GG(m, FC31 + 1), 192, 256, B, 0, 0, ACT_NONE, st));
+  // ---- heads: dX of fc41/42/43 into the three 64-wide slices of dh3 (masked by h3's ReLU), one launch ----
+  const AvaGemmProblem hdx[3] = {
+      {m->dmu, 0, PP(m, FC41), 0, nullptr, m->dh3 + 0, 192, m->h3 + 0, nullptr, B, 64, z, ACT_NONE},
+      {m->du, 0, PP(m, FC42), 0, nullptr, m->dh3 + 64, 192, m->h3 + 64, nullptr, B, 64, z, ACT_NONE},
+      {m->dlogd, 0, PP(m, FC43), 0, nullptr, m->dh3 + 128, 192, m->h3 + 128, nullptr, B, 64, z, ACT_NONE}};
+  TRY(gemm_group(m, hdx, 3, 1, 0, st));
   TRY(gemm(m, m->dh3, 0, PP(m, FC31), 0, nullptr, m->dh2, 0, m->h2, nullptr, B, 256, 192, 1, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh2, 0, m->h1, 0, nullptr, GG(m, FC2), 0, nullptr, GG(m, FC2 + 1), 256, 1024, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh2, 0, PP(m, FC2), 0, nullptr, m->dh1, 0, m->h1, nullptr, B, 1024, 256, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh1, 0, m->y7t, 0, nullptr, GG(m, FC1), 0, nullptr, GG(m, FC1 + 1), 1024, 8192, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, nullptr, nullptr, B, 8192, 1024, 1, 0, ACT_NONE, st));
+  // ---- the eight small weight gradients (K = batch): fc7, fc6, fc5, fc41/42/43, fc31|32|33, fc2 ----
+  const AvaGemmProblem dws[8] = {
+      {m->dh7, 0, m->h6, 0, nullptr, GG(m, FC7), 0, nullptr, GG(m, FC7 + 1), 1024, 256, B, ACT_NONE},
+      {m->dh6, 0, m->h5, 0, nullptr, GG(m, FC6), 0, nullptr, GG(m, FC6 + 1), 256, 64, B, ACT_NONE},
+      {m->dh5, 0, m->zs, 0, nullptr, GG(m, FC5), 0, nullptr, GG(m, FC5 + 1), 64, z, B, ACT_NONE},
+      {m->dmu, 0, m->h3 + 0, 192, nullptr, GG(m, FC41), 0, nullptr, GG(m, FC41 + 1), z, 64, B, ACT_NONE},
+      {m->du, 0, m->h3 + 64, 192, nullptr, GG(m, FC42), 0, nullptr, GG(m, FC42 + 1), z, 64, B, ACT_NONE},
+      {m->dlogd, 0, m->h3 + 128, 192, nullptr, GG(m, FC43), 0, nullptr, GG(m, FC43 + 1), z, 64, B, ACT_NONE},
+      {m->dh3, 0, m->h2, 0, nullptr, GG(m, FC31), 0, nullptr, GG(m, FC31 + 1), 192, 256, B, ACT_NONE},
+      {m->dh2, 0, m->h1, 0, nullptr, GG(m, FC2), 0, nullptr, GG(m, FC2 + 1), 256, 1024, B, ACT_NONE}};
+  TRY(gemm_group(m, dws, 8, 0, 0, st));
   // ---- encoder convolutions ----
   gcur = m->gA; gnext = m->gB;
   TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, st));             // dU_7 (ReLU of conv7)

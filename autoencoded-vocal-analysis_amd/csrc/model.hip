@@ -565,10 +565,54 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   return AVA_OK;
 }
 
+// weight/bias gradient reductions of conv layers [l0, l1) in one launch
+static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
+  WgradReduceTable tab;
+  int blocks = 0, n = 0;
+  for (int l = l0; l < l1; ++l, ++n) {
+    const ConvLayer& L = kLayers[l];
+    tab.e[n].partials = m->wg_part[l];
+    tab.e[n].dw = GG(m, L.pw);
+    tab.e[n].dbias = GG(m, L.pb);
+    tab.e[n].nparts = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+    tab.e[n].cin = L.cin; tab.e[n].cout = L.cout;
+    tab.e[n].kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
+    tab.e[n].block0 = blocks;
+    blocks += ceil_div(9 * L.cin * L.cout + L.cout, 32);
+  }
+  tab.n = n;
+  TRY(ava_conv_wgrad_reduce_all(tab, blocks, st));
+  mark(m, CAT_CONV_WGRAD, st);
+  return AVA_OK;
+}
+
+// Gradient buckets for the data-parallel all-reduce, in the order backward completes them:
+//   bucket 0 = [fc8.weight .. end of arena)  (fc8, convt1..7, bn8..14: ~33.6 MB) -- complete after part 0
+//   bucket 1 = [0 .. fc8.weight)             (conv1..7, bn1..7, fc1..fc7)         -- complete after part 1
+extern "C" int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count) {
+  if (m == nullptr || offset == nullptr || count == nullptr || bucket < 0 || bucket > 1) return AVA_EINVAL;
+  const int64_t split = m->tab[50].off;      // fc8.weight
+  if (bucket == 0) { *offset = split; *count = m->arena - split; }
+  else { *offset = 0; *count = split; }
+  return AVA_OK;
+}
+
+static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st);
+static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st);
+
 extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s) {
   if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr) return AVA_EINVAL;
-  hipStream_t st = to_stream(s);
-  const int z = m->z;
+  TRY(backward_part0(m, x, B, to_stream(s)));
+  return backward_part1(m, x, B, to_stream(s));
+}
+// part 0: decoder convolutions, bn8, fc8's weight gradient (everything in gradient bucket 0);
+// part 1: the remaining fully connected layers, the latent block and the encoder (bucket 1).
+extern "C" int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s) {
+  if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr || part < 0 || part > 1) return AVA_EINVAL;
+  return part == 0 ? backward_part0(m, x, B, to_stream(s)) : backward_part1(m, x, B, to_stream(s));
+}
+
+static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st) {
   // ---- decoder convolutions, last to first ----
   float* gcur = m->gA;
   float* gnext = m->gB;
@@ -583,10 +627,19 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
   TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, st));
   mark(m, CAT_LAYOUT, st);
+  TRY(reduce_wgrads(m, 7, NCONV, B, st));
+  TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), 8192, 1024, B, 0, 0, ACT_NONE, st));
+  return AVA_OK;
+}
+
+static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
+  const int z = m->z;
+  float* gcur = m->gA;
+  float* gnext = m->gB;
+  mark(m, -1, st);
   // ---- fully connected layers.  dX = (dY W) masked by the producer's ReLU runs as a chain; the weight
   // gradients dW = dY^T X (+ db = column sums) only need buffers that stay valid, so the two big ones are
   // issued in place and the eight small ones are collected into ONE grouped launch at the end. ----
-  TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), 8192, 1024, B, 0, 0, ACT_NONE, st));
   TRY(gemm(m, m->dF8, 0, PP(m, FC8), 0, nullptr, m->dh7, 0, m->h7, nullptr, B, 1024, 8192, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh7, 0, PP(m, FC7), 0, nullptr, m->dh6, 0, m->h6, nullptr, B, 256, 1024, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh6, 0, PP(m, FC6), 0, nullptr, m->dh5, 0, m->h5, nullptr, B, 64, 256, 1, 0, ACT_NONE, st));
@@ -626,24 +679,7 @@ extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s)
                             l == 0 ? nullptr : gnext, B, st));
     float* t = gcur; gcur = gnext; gnext = t;
   }
-  // ---- all 14 weight/bias gradient reductions in one launch ----
-  WgradReduceTable tab;
-  int blocks = 0;
-  for (int l = 0; l < NCONV; ++l) {
-    const ConvLayer& L = kLayers[l];
-    tab.e[l].partials = m->wg_part[l];
-    tab.e[l].dw = GG(m, L.pw);
-    tab.e[l].dbias = GG(m, L.pb);
-    tab.e[l].nparts = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
-    tab.e[l].cin = L.cin; tab.e[l].cout = L.cout;
-    tab.e[l].kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
-    tab.e[l].block0 = blocks;
-    blocks += ceil_div(9 * L.cin * L.cout + L.cout, 32);
-  }
-  tab.n = NCONV;
-  TRY(ava_conv_wgrad_reduce_all(tab, blocks, st));
-  mark(m, CAT_CONV_WGRAD, st);
-  return AVA_OK;
+  return reduce_wgrads(m, 0, 7, B, st);      // encoder weight/bias gradients
 }
 
 extern "C" int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step,

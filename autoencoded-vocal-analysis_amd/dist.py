@@ -35,6 +35,22 @@ def allreduce_gradients(flat_grads):
     return flat_grads
 
 
+def allreduce_gradients_async(flat_slice):
+    """Enqueue the SUM all-reduce of one gradient bucket on the communication stream (it starts once the
+    kernels already enqueued on the current stream have produced the bucket) and return the work handle;
+    compute enqueued afterwards overlaps with it."""
+    if not active():
+        return None
+    return td.all_reduce(flat_slice, op=td.ReduceOp.SUM, async_op=True)
+
+
+def wait_all(handles):
+    """Make the current stream (and, for CPU backends, the host) wait for the given all-reduces."""
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
 def broadcast_parameters(model, src=0):
     """Identical weights / BatchNorm buffers / Adam state on every rank."""
     if active():

@@ -282,9 +282,20 @@ class VAE(nn.Module):
         return self._loss_buf[0]
 
     def _backward_device(self, x):
-        rc = _lib.load().ava_backward(self._handle, x.data_ptr(), x.shape[0], _lib.stream())
-        _lib.check(rc, "ava_backward")
-        _dist.allreduce_gradients(self._grads)
+        lib = _lib.load()
+        if not _dist.active():
+            _lib.check(lib.ava_backward(self._handle, x.data_ptr(), x.shape[0], _lib.stream()), "ava_backward")
+            return
+        # data parallel: the decoder half of the gradient arena (fc8 + convT + bn8..14, ~half of the bytes) is
+        # all-reduced while the encoder half of backward is still running; the rest follows at the end
+        pending = []
+        for part in (0, 1):
+            _lib.check(lib.ava_backward_part(self._handle, x.data_ptr(), x.shape[0], part, _lib.stream()),
+                       "ava_backward_part")
+            off, cnt = ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(lib.ava_grad_bucket(self._handle, part, ctypes.byref(off), ctypes.byref(cnt)), "ava_grad_bucket")
+            pending.append(_dist.allreduce_gradients_async(self._grads[off.value:off.value + cnt.value]))
+        _dist.wait_all(pending)
 
     def _check_status(self):
         if int(self._status.item()) != 0:

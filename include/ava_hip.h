@@ -68,6 +68,11 @@ int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const f
 /* loss.backward() (vae.py:352) for the forward that just ran: fills the gradient arena
  * (overwrites: the reference zero_grad()s before every step, vae.py:348). */
 int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);
+/* The same backward in two halves, so that a data-parallel caller can all-reduce the first half's gradients
+ * (bucket 0: fc8, convt1..7, bn8..14 -- contiguous tail of the arena) while the second half still runs.
+ * ava_grad_bucket returns the arena range (floats) that is complete after part `bucket`. */
+int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s);
+int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count);
 /* torch.optim.Adam.step (torch/optim/adam.py:414-547), one fused pass over the four arenas.
  * `step` is the 1-based count after increment. */
 int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step, ava_stream_t s);

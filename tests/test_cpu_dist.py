@@ -33,7 +33,10 @@ def _worker(rank, world, port, q):
         flat = torch.zeros(total)
         for s in layout.param_specs(z):
             flat[offs[s.name]:offs[s.name] + s.numel] = P[s.name].grad.reshape(-1)
-        adist.allreduce_gradients(flat)                       # SUM, not mean (the loss is a batch sum)
+        # two buckets, asynchronously, exactly like VAE._backward_device does under data parallelism
+        split = offs["fc8.weight"]
+        pending = [adist.allreduce_gradients_async(flat[split:]), adist.allreduce_gradients_async(flat[:split])]
+        adist.wait_all(pending)                               # SUM, not mean (the loss is a batch sum)
         norms = {s.name: float(flat[offs[s.name]:offs[s.name] + s.numel].double().norm()) for s in layout.param_specs(z)}
         gl = adist.global_loss(out["loss"].detach().double(), z, 10.0, 1)
         n = adist.global_dataset_len(B)

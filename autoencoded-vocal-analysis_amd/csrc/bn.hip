@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
   __syncthreads();
   if (threadIdx.x < 2 * C)
-    partials[(size_t)blockIdx.x * 2 * C + threadIdx.x] =
-        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    bn_partial_store(fuse, partials + (size_t)blockIdx.x * 2 * C + threadIdx.x,
+                     (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
   bn_fused_finalize(fuse, partials, gridDim.x, fuse_scratch);
 }
 
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k][t];
-    partials[(size_t)blockIdx.x * 64 + t] = s;
+    bn_partial_store(fuse, partials + (size_t)blockIdx.x * 64 + t, s);
   }
   bn_fused_finalize(fuse, partials, gridDim.x, fuse_scratch);
 }

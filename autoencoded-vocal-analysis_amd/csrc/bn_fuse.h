@@ -2,12 +2,15 @@
 // workgroup to publish its partial row reduces all rows (fp64, fixed order -> deterministic) and writes
 // the per-channel coefficients the next kernel's prologue consumes.  Removes 28 tiny launches per step.
 //
-// Hand-off protocol (cdna_hip_programming.md, Guideline 16, counter form): every storing wave drains its
-// stores (s_waitcnt vmcnt(0)), workgroup barrier, lane 0 does an agent-scope RELEASE fence, drains again,
-// then a relaxed agent-scope fetch_add on the ticket counter; the workgroup that draws the last ticket does
-// an agent-scope ACQUIRE fence, barrier, and only then reads the other workgroups' rows with plain loads.
-// Placement independent (no assumption on dispatch order or XCD).  The counter is zero on entry (zeroed
-// once at model creation) and the last arriver resets it for the next launch on the stream.
+// Hand-off protocol (cdna_hip_programming.md, Guideline 16 / "In-launch split-K reduction", write-through
+// form): the partial row is stored with agent-scope (sc1, write-through) stores -- see bn_partial_store --,
+// every storing wave drains them (s_waitcnt vmcnt(0)), workgroup barrier, lane 0 does a relaxed agent-scope
+// fetch_add on the ticket counter; the workgroup that draws the last ticket does an agent-scope ACQUIRE
+// fence, barrier, and only then reads the other workgroups' rows with plain loads.  No release fence: the
+// first version had one per workgroup and each of them wrote back the whole XCD L2, which is full of the
+// kernel's own freshly written activations (+0.6 ms/step).  Placement independent (no assumption on
+// dispatch order or XCD).  The counter is zero on entry (zeroed once at model creation) and the last
+// arriver resets it for the next launch on the stream.
 #pragma once
 #include "common.h"
 
@@ -34,6 +37,12 @@ struct BnFuse {
   float* Bc;
   float* Cc;
 };
+
+// store one element of a partial row: write-through when a fused finalisation will read it in this launch
+__device__ __forceinline__ void bn_partial_store(const BnFuse& f, float* p, float v) {
+  if (f.counter != nullptr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
 
 // forward statistics -> mean / invstd / scale / shift (+ running statistics update); c < C
 __device__ __forceinline__ void bn_fwd_channel(const BnFuse& f, int c, double s1, double s2) {
@@ -75,8 +84,6 @@ __device__ __forceinline__ void bn_fused_finalize(const BnFuse& f, const float* 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial-row stores have left
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ticket = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == (int)gridDim.x - 1;
     if (last) {

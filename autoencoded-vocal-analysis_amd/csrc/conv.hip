@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
   }
   __syncthreads();
   if (t < 2 * COUT && a.partials != nullptr)
-    a.partials[(size_t)blockIdx.x * 2 * COUT + t] =
-        (red[t] + red[2 * COUT + t]) + (red[4 * COUT + t] + red[6 * COUT + t]);
+    bn_partial_store(a.bn, a.partials + (size_t)blockIdx.x * 2 * COUT + t,
+                     (red[t] + red[2 * COUT + t]) + (red[4 * COUT + t] + red[6 * COUT + t]));
   if (EPI != EPI_SSE) bn_fused_finalize(a.bn, a.partials, gridDim.x, reinterpret_cast<double*>(smem));
 }
 

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC> f2;
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC> f3;
   constexpr int SP = MODE == MODE_DOWN ? 2 : 1;            // input pixels per output pixel along x
-  f0.init(a.G, lane, SP * n * CIN);
+  if (!(a.dbg & 8)) f0.init(a.G, lane, SP * n * CIN);
   if (NCLS > 1) { f1.init(a.G, lane, n * CIN); f2.init(a.G, lane, n * CIN); f3.init(a.G, lane, n * CIN); }
   // output offset (floats) of this lane inside a 16-pixel group: pixel n (every 2nd pixel for UP), channels 4kg..
   const int lane_out = (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     }
   }
 
+  if (a.dbg & 16) return;
   // ---- per-workgroup partial statistics: reduce over the 16 pixel lanes, then over the 4 waves ----
   __syncthreads();
 #pragma unroll
@@ -281,8 +282,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
   if (t < 2 * COUT && a.partials != nullptr) {
     const int which = t / COUT, co = t - which * COUT;
     const int idx = which * 16 * MT + co;
-    a.partials[(size_t)blockIdx.x * 2 * COUT + t] =
-        (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]);
+    bn_partial_store(a.bn, a.partials + (size_t)blockIdx.x * 2 * COUT + t,
+                     (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]));
   }
   bn_fused_finalize(a.bn, a.partials, gridDim.x, reinterpret_cast<double*>(smem));
 }

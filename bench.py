@@ -137,8 +137,21 @@ def main():
     launches = {c: cnt[i] // args.steps for i, c in enumerate(CATS)}
     conv_ms = sum(per_step[c] for c in CONV_FAMILY)
     achieved = B * A_CONV_BYTES / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+    # HBM bytes of the same kernels from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
+    # this command; tools/pmc_traffic.py) -- counters cannot be read from inside this process, so the committed summary of
+    # the latest pass is quoted; null when there is none for this batch size
+    traffic, traffic_src = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[::-1]:
+        try:
+            t = json.load(open(path))
+            if B == 256 and world == 1:
+                traffic, traffic_src = t["conv_family_bytes_per_step"], os.path.relpath(path, ROOT)
+            break
+        except Exception:
+            pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv+convT+BatchNorm kernels, forward+backward (SURVEY 8d aggregate)",
                 "algorithmic_bytes_per_step": B * A_CONV_BYTES, "conv_family_ms_per_step": round(conv_ms, 4),
                 "ms_per_step_by_category": {k: round(v, 4) for k, v in per_step.items()},

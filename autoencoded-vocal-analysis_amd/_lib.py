@@ -65,6 +65,8 @@ SIGNATURES = {
     "ava_conv3x3": (_i, [_p] * 13 + [_i] * 9 + [_f, _p]),
     "ava_conv3x3_wgrad": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "ava_conv_wgrad_grid": (_i, [_i, _i, _i, _i]),
+    "ava_conv_fused_grid": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ava_conv3x3_bwd_fused": (_i, [_p] * 14 + [_i] * 7 + [_p]),
     "ava_conv_wgrad_reduce": (_i, [_p, _i, _p, _p, _i, _i, _i, _p]),
     "ava_bn_stats": (_i, [_p, _i64, _i, _p, C.POINTER(_i), _p]),
     "ava_bn_finalize": (_i, [_p, _i, _i64, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),

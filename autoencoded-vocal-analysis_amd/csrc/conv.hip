@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
   }
   const float* __restrict__ Gw = a.G;
 
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
     const int b = tl / (a.tiles_y * a.tiles_x);
     const int rem = tl - b * (a.tiles_y * a.tiles_x);
     const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
   const int slice = SL > 1 ? t / NBLK : 0;
   const bool active = SL > 1 ? (t < NBLK * SL) : true;
 
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
     const int b = tl / (a.tiles_y * a.tiles_x);
     const int rem = tl - b * (a.tiles_y * a.tiles_x);
     const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;

@@ -171,6 +171,29 @@ struct TileStager {
   }
 };
 
+// XCD-aware walk over a persistent workgroup's tile list.  Workgroups are dispatched round-robin over the 8 XCDs
+// (workgroup w runs on XCD w % 8), each with its own L2; handing every XCD one contiguous eighth of the tile list
+// keeps the tiles that share halo rows (neighbours inside one image) in the same L2 instead of fetching the halo
+// from HBM once per XCD.  Falls back to the plain strided walk when the grid or tile count is not a multiple of 8.
+struct TileWalk {
+  int cur, end, step;
+  __device__ __forceinline__ explicit TileWalk(int ntiles) {
+    const int g = (int)gridDim.x, w = (int)blockIdx.x;
+    if (((g | ntiles) & 7) == 0) {
+      const int chunk = ntiles >> 3, xcd = w & 7;
+      cur = xcd * chunk + (w >> 3);
+      end = (xcd + 1) * chunk;
+      step = g >> 3;
+    } else {
+      cur = w; end = ntiles; step = g;
+    }
+  }
+  __device__ __forceinline__ bool valid() const { return cur < end; }
+  __device__ __forceinline__ bool has_next() const { return cur + step < end; }
+  __device__ __forceinline__ int next() const { return cur + step; }
+  __device__ __forceinline__ void advance() { cur += step; }
+};
+
 struct WgradArgs {
   const float* x;      // raw layer input [B,Hi,Wi,CIN]; prologue 0 with xa, xb
   const float* xa;

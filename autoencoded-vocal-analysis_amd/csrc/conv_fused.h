@@ -1,0 +1,26 @@
+// Fused backward (data gradient + BatchNorm-backward sums + weight/bias-gradient partials) of one conv layer.
+#pragma once
+#include "conv_common.h"
+
+struct FusedArgs {
+  const float* x;        // raw layer input [B,Hi,Wi,CI]; BatchNorm scale/shift xa, xb (x_n = xa*x + xb)
+  const float* xa;
+  const float* xb;
+  const float* dy;       // upstream gradient [B,Ho,Wo,CO]; with dy2 (saved activation) and da, db, dc: PRO_BWD
+  const float* dy2;
+  const float* da;
+  const float* db;
+  const float* dc;
+  const float* Gb;       // backward-data weights in gather layout (pack kinds 3..6)
+  float* dx;             // [B,Hi,Wi,CI] gradient w.r.t. the BatchNorm output
+  const float* mean;     // batch statistics of x (BatchNorm-backward sums)
+  const float* invstd;
+  float* bn_partials;    // [grid][2*CI]
+  float* wg_partials;    // [grid][9*CI*CO + CO]
+  int B, Hi, Wi, Ho, Wo;
+  int tiles_y, tiles_x, ntiles;
+};
+
+// 0 when (Cin, Cout, mode, size) has no fused instantiation
+int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode);
+int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);

@@ -1,0 +1,407 @@
+// Fused backward of one conv / convT layer on the matrix cores (gfx950, exact fp32 v_mfma_f32_16x16x4_f32).
+//
+// The separate kernels of conv_mfma.hip read the upstream gradient twice: the backward-data kernel stages
+// dU = relu'(y) * BatchNorm-backward(g) to convolve it with the flipped weights, and the weight-gradient kernel
+// stages the same dU again to correlate it with the layer input.  Here ONE workgroup stages, per tile,
+//   * the dU window (with the halo the data gradient needs; prologue PRO_BWD or PRO_ID applied on the way in), and
+//   * the layer-input window x_n = BatchNorm(x) (with the halo the weight gradient needs, zero padded),
+// and runs both implicit GEMMs off those two LDS tiles:
+//   dx[p][ci]        = sum_{tap,co} dU[p (+) tap][co] * Gb[tap][co][ci]      (+ sum dx, sum dx*xhat for BatchNorm l)
+//   dG[tap][ci][co] += sum_{p in tile interior} x_n[p (+) tap][ci] * dU[p][co],   db[co] += sum_p dU[p][co]
+// so g, y and x are fetched from HBM once per layer instead of twice (reference: autograd's conv backward,
+// ava/models/vae.py:347-353 loss.backward()).  Tiles are indexed in the LOW-resolution space of the layer
+// (S1: both tensors; stride-2 conv: the dU side; stride-2 convT: the x side).
+#include <stdlib.h>
+#include "conv_mfma.h"
+#include "conv_fused.h"
+
+template <int LMODE, int TW, int TH>
+struct FGeom {
+  // x window [XR x XC], dU window [DR x DC], dU interior [DIH x DIW] at offset (DOFF, DOFF), dx region [OH x OW]
+  static constexpr int XR = LMODE == MODE_S1 ? TH + 2 : (LMODE == MODE_DOWN ? 2 * TH + 1 : TH + 1);
+  static constexpr int XC = LMODE == MODE_S1 ? TW + 2 : (LMODE == MODE_DOWN ? 2 * TW + 1 : TW + 1);
+  static constexpr int DR = LMODE == MODE_S1 ? TH + 2 : (LMODE == MODE_DOWN ? TH + 1 : 2 * TH + 1);
+  static constexpr int DC = LMODE == MODE_S1 ? TW + 2 : (LMODE == MODE_DOWN ? TW + 1 : 2 * TW + 1);
+  static constexpr int DOFF = LMODE == MODE_DOWN ? 0 : 1;
+  static constexpr int OH = LMODE == MODE_DOWN ? 2 * TH : TH;
+  static constexpr int OW = LMODE == MODE_DOWN ? 2 * TW : TW;
+};
+
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const FusedArgs a) {
+  using FG = FGeom<LMODE, TW, TH>;
+  constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
+  constexpr int BMODE = LMODE == MODE_S1 ? MODE_S1 : (LMODE == MODE_DOWN ? MODE_UP : MODE_DOWN);   // gather pattern of dx
+  constexpr int MT = (CI + 15) / 16;        // dx channel tiles
+  constexpr int NT = (CO + 15) / 16;        // dG column tiles
+  constexpr int NW = 9 * CI * CO;
+  constexpr int BCLS = n_classes<BMODE>(), WCLS = n_classes<LMODE>();
+  extern __shared__ __align__(16) float smem[];
+  float* xt = smem;                          // [XR*XC*CI]   BatchNorm(x), zero padded
+  float* dut = xt + XR * XC * CI;            // [DR*DC*CO]   dU, zero outside the image (+16 floats of zero pad)
+  float* cx = dut + DR * DC * CO + 16;       // [3][32]
+  float* cd = cx + 96;                       // [3][32]
+  float* red = cd + 96;                      // [4][32*MT]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = lane & 15, kg = lane >> 4;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
+    cx[t] = (sx != nullptr && c < CI) ? sx[c] : 0.f;
+    cd[t] = (sd != nullptr && c < CO) ? sd[c] : 0.f;
+  }
+  if (t < 16) dut[DR * DC * CO + t] = 0.f;
+
+  // ---- backward-data fragments: the flipped/packed weights stay in registers for the whole kernel ----
+  constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
+  ClassFrag<CO, CI, BMODE, 0, DC> f0;
+  ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC> f1;
+  ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 2 : 0), DC> f2;
+  ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 3 : 0), DC> f3;
+  f0.init(a.Gb, lane, SPB * n * CO);
+  if (BCLS > 1) { f1.init(a.Gb, lane, n * CO); f2.init(a.Gb, lane, n * CO); f3.init(a.Gb, lane, n * CO); }
+  const int lane_out = (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
+  float emean[MT][4], einv[MT][4], s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = 16 * mt + 4 * kg + r;
+      emean[mt][r] = ci < CI ? a.mean[ci] : 0.f;
+      einv[mt][r] = ci < CI ? a.invstd[ci] : 0.f;
+      s1[mt][r] = s2[mt][r] = 0.f;
+      asm volatile("" ::"v"(emean[mt][r]), "v"(einv[mt][r]));      // retire before the tile loop (see ClassFrag::init)
+    }
+
+  // ---- weight-gradient accumulators (persist over all tiles of this workgroup) ----
+  WClass<CI, CO, LMODE, 0, XC> w0;
+  WClass<CI, CO, LMODE, (WCLS > 1 ? 1 : 0), XC> w1;
+  WClass<CI, CO, LMODE, (WCLS > 1 ? 2 : 0), XC> w2;
+  WClass<CI, CO, LMODE, (WCLS > 1 ? 3 : 0), XC> w3;
+  w0.init(lane);
+  if (WCLS > 1) { w1.init(lane); w2.init(lane); w3.init(lane); }
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  // tile -> image, low-resolution origin, window origins
+  auto origin = [&](int tl, int& b, int& y0, int& x0) {
+    b = tl / (a.tiles_y * a.tiles_x);
+    const int rem = tl - b * (a.tiles_y * a.tiles_x);
+    y0 = (rem / a.tiles_x) * TH;
+    x0 = (rem % a.tiles_x) * TW;
+  };
+  auto x_origin = [&](int y0, int x0, int& gy, int& gx) {
+    if (LMODE == MODE_S1) { gy = y0 - 1; gx = x0 - 1; }
+    else if (LMODE == MODE_DOWN) { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
+    else { gy = y0; gx = x0; }
+  };
+  auto d_origin = [&](int y0, int x0, int& gy, int& gx) {
+    if (LMODE == MODE_S1) { gy = y0 - 1; gx = x0 - 1; }
+    else if (LMODE == MODE_DOWN) { gy = y0; gx = x0; }
+    else { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
+  };
+  TileStager<CI, PRO_BN, XR, XC> sx;
+  TileStager<CO, DYPRO, DR, DC> sd;
+  sx.init();
+  sd.init();
+  auto prefetch = [&](int tl) {
+    int b, y0, x0, gy, gx;
+    origin(tl, b, y0, x0);
+    x_origin(y0, x0, gy, gx);
+    sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy, gx);
+    d_origin(y0, x0, gy, gx);
+    sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
+  };
+
+  // pixel groups of the dx region: 16 consecutive pixels of a row (UP pattern: of one parity class)
+  constexpr int CB = FG::OW / (BMODE == MODE_UP ? 32 : 16);          // column blocks
+  constexpr int GROUPS = BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB;
+  constexpr int GPW = GROUPS / 4;
+  static_assert(GROUPS % 4 == 0 && (BMODE != MODE_UP || GPW % 4 == 0), "tile must split evenly over the 4 waves");
+  // offset (floats, relative to the dx region's first pixel) and LDS pixel base of group g
+  auto group_out = [&](int g) -> int {
+    if (BMODE == MODE_UP) {
+      const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
+      return ((2 * r + (cls >> 1)) * a.Wi + 32 * cb + (cls & 1)) * CI;
+    }
+    return ((g / CB) * a.Wi + 16 * (g % CB)) * CI;
+  };
+
+  // raw x at this lane's dx pixels (BatchNorm-backward sums).  Loaded one tile ahead, AFTER the tile's data-gradient
+  // phase has consumed the previous values: the lines were requested by the window prefetch a moment earlier, so
+  // this hits L2, and the loads ride under the weight-gradient phase.
+  avaf4 ex[GPW * MT];
+  auto load_ex = [&](int tl) {
+    int b, y0, x0;
+    origin(tl, b, y0, x0);
+    const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+    const float* __restrict__ xb = a.x + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb4 = 16 * mt + 4 * kg;
+        // lanes whose 4-channel slot lies beyond CI re-read slot 0: stays in bounds
+        ex[gi * MT + mt] = *reinterpret_cast<const avaf4*>(
+            xb + group_out(wave * GPW + gi) + (cb4 < CI ? lane_out + 16 * mt : lane_out - 4 * kg));
+      }
+  };
+
+  TileWalk walk(a.ntiles);
+  if (walk.valid()) { prefetch(walk.cur); load_ex(walk.cur); }
+  for (; walk.valid(); walk.advance()) {
+    int b, y0, x0;
+    origin(walk.cur, b, y0, x0);
+    __syncthreads();                       // previous tile fully consumed (and cx/cd visible on the first pass)
+    sx.store(xt, cx);
+    sd.store(dut, cd);
+    __syncthreads();
+    const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+    const size_t tile_pix = ((size_t)b * a.Hi + oy0) * a.Wi + ox0;
+    float* __restrict__ obase = a.dx + tile_pix * CI;
+    if (walk.has_next()) prefetch(walk.next());      // stays in flight during both matrix-core phases below
+
+    // ---- phase 1: data gradient of the tile + BatchNorm-backward sums ----
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int g = wave * GPW + gi;
+      f32x4 acc[2][MT];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (BMODE == MODE_UP) {
+        const int cls = gi & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;   // GPW % 4 == 0: cls is compile-time
+        const float* px = dut + (r * DC + 16 * cb) * CO;
+        if (cls == 0) f0.run(px, acc);
+        else if (cls == 1) f1.run(px, acc);
+        else if (cls == 2) f2.run(px, acc);
+        else f3.run(px, acc);
+      } else {
+        constexpr int S = BMODE == MODE_S1 ? 1 : 2;
+        f0.run(dut + (S * (g / CB) * DC + S * 16 * (g % CB)) * CO, acc);
+      }
+      const int gout = group_out(g) + lane_out;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb4 = 16 * mt + 4 * kg;
+        if (cb4 < CI) {
+          const f32x4 v = acc[0][mt] + acc[1][mt];
+          const avaf4 xr = ex[gi * MT + mt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xh = (xr[r] - emean[mt][r]) * einv[mt][r];
+            s1[mt][r] += v[r];
+            s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+          }
+          *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+
+    if (walk.has_next()) load_ex(walk.next());
+
+    // ---- phase 2: weight / bias gradient over the tile's interior dU pixels ----
+    if (LMODE == MODE_UP) {
+      // x-space rows r = wave + 4 rr, columns c = 4 s + kg; the four output-parity classes of each x pixel
+#pragma unroll 1
+      for (int rr = 0; rr < TH / 4; ++rr) {
+        const int r = wave + 4 * rr;
+#pragma unroll 1
+        for (int s = 0; s < TW / 4; ++s) {
+          const int c = 4 * s + kg;
+          const float* xa = xt + (r * XC + c) * CI;
+#pragma unroll
+          for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            const float* bp = dut + ((2 * r + py + DOFF) * DC + 2 * c + px + DOFF) * CO + n;
+            float bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (16 * nt + n < CO) ? bf[nt] : 0.f; }
+            if (cls == 0) w0.step(xa, bf);
+            else if (cls == 1) w1.step(xa, bf);
+            else if (cls == 2) w2.step(xa, bf);
+            else w3.step(xa, bf);
+          }
+        }
+      }
+    } else {
+      constexpr int S = LMODE == MODE_S1 ? 1 : 2;
+      constexpr int RPW = TH / 4;                 // dU rows per wave
+#pragma unroll 1
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int ty = wave * RPW + rr;
+#pragma unroll 1
+        for (int s = 0; s < TW / 4; ++s) {
+          const int x = 4 * s + kg;
+          const float* bp = dut + ((ty + DOFF) * DC + x + DOFF) * CO + n;
+          float bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (16 * nt + n < CO) ? bf[nt] : 0.f; }
+          w0.step(xt + ((S * ty) * XC + S * x) * CI, bf);
+        }
+      }
+    }
+  }
+
+  // ---- BatchNorm-backward partial sums: over the 16 pixel lanes, then over the 4 waves (fixed order) ----
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v1 = s1[mt][r], v2 = s2[mt][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+      if (n == 0) {
+        const int ci = 16 * mt + 4 * kg + r;
+        red[wave * 32 * MT + ci] = v1;
+        red[wave * 32 * MT + 16 * MT + ci] = v2;
+      }
+    }
+  __syncthreads();
+  if (t < 2 * CI) {
+    const int which = t / CI, ci = t - which * CI;
+    const int idx = which * 16 * MT + ci;
+    a.bn_partials[(size_t)blockIdx.x * 2 * CI + t] =
+        (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]);
+  }
+  __syncthreads();
+
+  // ---- weight-gradient partial row: the four waves summed through LDS in a fixed order ----
+  float* wacc = smem;                             // [NW + CO], aliases the tiles (all reads are done)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] += __shfl_xor(bsum[nt], 16, 64);
+    bsum[nt] += __shfl_xor(bsum[nt], 32, 64);
+  }
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      w0.flush(wacc, lane, w == 0);
+      if (WCLS > 1) { w1.flush(wacc, lane, w == 0); w2.flush(wacc, lane, w == 0); w3.flush(wacc, lane, w == 0); }
+      if (kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = 16 * nt + n;
+          if (co < CO) wacc[NW + co] = (w == 0) ? bsum[nt] : wacc[NW + co] + bsum[nt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* prow = a.wg_partials + (size_t)blockIdx.x * (NW + CO);
+  for (int e = t; e < NW + CO; e += 256) prow[e] = wacc[e];
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
+static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
+  using FG = FGeom<LMODE, TW, TH>;
+  constexpr int MT = (CI + 15) / 16;
+  const size_t tiles_f = (size_t)FG::XR * FG::XC * CI + FG::DR * FG::DC * CO + 16 + 192 + 4 * 32 * MT;
+  const size_t red_f = (size_t)9 * CI * CO + CO;
+  const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AVA_ELAUNCH;
+    attr_set = true;
+  }
+  FusedArgs b = a;
+  const int hl = LMODE == MODE_DOWN ? a.Ho : a.Hi, wl = LMODE == MODE_DOWN ? a.Wo : a.Wi;   // low-resolution side
+  if (hl % TH != 0 || wl % TW != 0) return AVA_EINVAL;
+  b.tiles_y = hl / TH;
+  b.tiles_x = wl / TW;
+  b.ntiles = a.B * b.tiles_y * b.tiles_x;
+  if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
+  hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(256), lds, st, b);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+// shapes with a fused instantiation: (cin, cout, mode, variant) -> low-resolution tile, occupancy hint.
+// Variant 0 is the one the model driver runs; the others are kept for tools/fused_bench.py (AVA_FUSED_VAR=n).
+#define AVA_FUSED_SHAPES(X)        \
+  X(8, 8, MODE_DOWN, 0, 32, 4, 2)  \
+  X(8, 8, MODE_DOWN, 1, 16, 4, 2)  \
+  X(8, 8, MODE_DOWN, 2, 16, 4, 3)  \
+  X(8, 16, MODE_S1, 0, 32, 8, 2)   \
+  X(8, 16, MODE_S1, 1, 16, 8, 2)   \
+  X(8, 16, MODE_S1, 2, 32, 4, 2)   \
+  X(16, 16, MODE_DOWN, 0, 16, 4, 2) \
+  X(16, 16, MODE_DOWN, 1, 32, 4, 2) \
+  X(16, 16, MODE_DOWN, 2, 16, 8, 2) \
+  X(16, 16, MODE_UP, 0, 32, 4, 2)  \
+  X(16, 16, MODE_UP, 1, 16, 4, 2)  \
+  X(16, 16, MODE_UP, 2, 16, 4, 3)  \
+  X(16, 8, MODE_S1, 0, 32, 8, 2)   \
+  X(16, 8, MODE_S1, 1, 16, 8, 2)   \
+  X(16, 8, MODE_S1, 2, 32, 4, 2)   \
+  X(8, 8, MODE_UP, 0, 32, 4, 2)    \
+  X(8, 8, MODE_UP, 1, 16, 4, 3)    \
+  X(8, 8, MODE_UP, 2, 32, 4, 3)
+
+static int fused_variant() {
+  static const int v = [] { const char* e = getenv("AVA_FUSED_VAR"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+static bool fused_tile(int Cin, int Cout, int mode, int* tw, int* th) {
+  const int var = fused_variant();
+#define X(ci, co, md, vr, tww, thh, mw) if (Cin == ci && Cout == co && mode == md && var == vr) { *tw = tww; *th = thh; return true; }
+  AVA_FUSED_SHAPES(X)
+#undef X
+  return false;
+}
+
+// number of workgroups (= partial rows of both outputs) of the fused kernel, 0 when the shape has none
+int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
+  int tw, th;
+  if (!fused_tile(Cin, Cout, mode, &tw, &th)) return 0;
+  const int hl = mode == MODE_DOWN ? Hi / 2 : Hi, wl = mode == MODE_DOWN ? Wi / 2 : Wi;
+  if (hl % th != 0 || wl % tw != 0) return 0;
+  const int nt = B * (hl / th) * (wl / tw);
+  return nt < 512 ? nt : 512;
+}
+
+int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
+  const int grid = ava_conv_fused_grid_for(a.B, a.Hi, a.Wi, Cin, Cout, mode);
+  if (grid <= 0) return AVA_EINVAL;
+  const int var = fused_variant();
+#define X(ci, co, md, vr, tww, thh, mw)                                                            \
+  if (Cin == ci && Cout == co && mode == md && var == vr) {                                         \
+    if (dy_pro == PRO_BWD) return launch_fused<ci, co, md, PRO_BWD, tww, thh, mw>(a, grid, st);     \
+    if (dy_pro == PRO_ID) return launch_fused<ci, co, md, PRO_ID, tww, thh, mw>(a, grid, st);       \
+    return AVA_EINVAL;                                                                              \
+  }
+  AVA_FUSED_SHAPES(X)
+#undef X
+  return AVA_EINVAL;
+}
+
+extern "C" int ava_conv_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
+  return ava_conv_fused_grid_for(B, Hi, Wi, Cin, Cout, mode);
+}
+
+extern "C" int ava_conv3x3_bwd_fused(const float* x, const float* xa, const float* xb, const float* dy, const float* dy2,
+                                     const float* da, const float* db, const float* dc, const float* Gb, float* dx,
+                                     const float* mean, const float* invstd, float* bn_partials, float* wg_partials,
+                                     int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro, ava_stream_t s) {
+  if (x == nullptr || xa == nullptr || xb == nullptr || dy == nullptr || Gb == nullptr || dx == nullptr ||
+      mean == nullptr || invstd == nullptr || bn_partials == nullptr || wg_partials == nullptr || B < 1)
+    return AVA_EINVAL;
+  if (dy_pro == PRO_BWD && (dy2 == nullptr || da == nullptr || db == nullptr || dc == nullptr)) return AVA_EINVAL;
+  FusedArgs a;
+  a.x = x; a.xa = xa; a.xb = xb; a.dy = dy; a.dy2 = dy2; a.da = da; a.db = db; a.dc = dc; a.Gb = Gb; a.dx = dx;
+  a.mean = mean; a.invstd = invstd; a.bn_partials = bn_partials; a.wg_partials = wg_partials;
+  a.B = B; a.Hi = Hi; a.Wi = Wi;
+  a.Ho = mode == MODE_S1 ? Hi : (mode == MODE_DOWN ? Hi / 2 : Hi * 2);
+  a.Wo = mode == MODE_S1 ? Wi : (mode == MODE_DOWN ? Wi / 2 : Wi * 2);
+  a.tiles_y = a.tiles_x = a.ntiles = 0;
+  return ava_conv3x3_bwd_fused_launch(a, Cin, Cout, mode, dy_pro, to_stream(s));
+}

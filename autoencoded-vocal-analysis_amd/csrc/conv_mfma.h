@@ -1,0 +1,161 @@
+// Building blocks shared by the matrix-core convolution kernels (conv_mfma.hip: forward / backward-data and
+// weight-gradient kernels; conv_fused.hip: the fused backward kernel): tap sets of the three gather patterns,
+// the per-lane weight fragments of the implicit GEMM (ClassFrag) and the weight-gradient accumulators (WClass).
+#pragma once
+#include "conv_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- tap sets ------------------------------------------------------------------------------------
+// S1 / DOWN: one class with all 9 taps.  UP: class = (oy&1)*2 + (ox&1); a tap (ky,kx) exists for
+// oy parity py iff (py ? ky != 1 : ky == 1), same for kx.
+template <int MODE> __host__ __device__ constexpr int n_classes() { return MODE == MODE_UP ? 4 : 1; }
+template <int MODE> __host__ __device__ constexpr int n_taps(int cls) {
+  return MODE != MODE_UP ? 9 : (cls == 0 ? 1 : (cls == 3 ? 4 : 2));
+}
+// t-th tap of a class -> (ky, kx)
+template <int MODE> __host__ __device__ constexpr int tap_ky(int cls, int t) {
+  if (MODE != MODE_UP) return t / 3;
+  const int py = cls >> 1, px = cls & 1;
+  const int nkx = px ? 2 : 1;
+  const int iy = t / nkx;
+  return py ? 2 * iy : 1;
+}
+template <int MODE> __host__ __device__ constexpr int tap_kx(int cls, int t) {
+  if (MODE != MODE_UP) return t % 3;
+  const int px = cls & 1;
+  const int nkx = px ? 2 : 1;
+  const int ix = t % nkx;
+  return px ? 2 * ix : 1;
+}
+
+// per-lane, per-class constants: LDS offsets of the chunk reads and the A (weight) fragments
+template <int CIN, int COUT, int MODE, int CLS, int IC>
+struct ClassFrag {
+  static constexpr int KTOT = n_taps<MODE>(CLS) * CIN;
+  static constexpr int NCH = (KTOT + 15) / 16;
+  static constexpr int MT = (COUT + 15) / 16;
+  int off[NCH];
+  float w[NCH][4][MT];
+
+  // lane_base: LDS offset (floats) of this lane's pixel inside a 16-pixel group (n * CIN * stride)
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base) {
+    const int m = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = 16 * c + 4 * kg;
+      const bool valid = k < KTOT;
+      const int t = valid ? k / CIN : 0;
+      const int ci = valid ? k - t * CIN : 0;
+      int ky = 0, kx = 0;
+      // (ky,kx) of the t-th tap of this class; t is lane dependent only through kg (<= 4 values)
+#pragma unroll
+      for (int tt = 0; tt < n_taps<MODE>(CLS); ++tt)
+        if (tt == t) { ky = tap_ky<MODE>(CLS, tt); kx = tap_kx<MODE>(CLS, tt); }
+      int dr, dc;
+      if (MODE == MODE_UP) { dr = ky == 0 ? 1 : 0; dc = kx == 0 ? 1 : 0; }
+      else { dr = ky; dc = kx; }
+      off[c] = lane_base + (dr * IC + dc) * CIN + ci;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int co = 16 * mt + m;
+          w[c][j][mt] = (valid && co < COUT) ? G[((ky * 3 + kx) * CIN + ci + j) * COUT + co] : 0.f;
+        }
+    }
+    // Retire the weight loads HERE.  Left pending, their first use sits inside the tile loop and hipcc's
+    // conservative loop handling turns it into s_waitcnt vmcnt(0) there, which also drains the next tile's
+    // prefetch (vmcnt retires in order) and serialises memory against the matrix cores.
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(w[c][j][mt]));
+  }
+
+  // acc[2][MT] += over all chunks; px = LDS address of this lane's pixel (tap (0,0), channel 0)
+  __device__ __forceinline__ void run(const float* __restrict__ px, f32x4 (&acc)[2][MT]) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 b = *reinterpret_cast<const float4*>(px + off[c]);
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[j & 1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][j][mt], bv[j], acc[j & 1][mt], 0, 0, 0);
+    }
+  }
+};
+
+// ---- weight-gradient accumulators: M = (tap, ci) rows, N = cout, K = pixels (see conv_mfma.hip) ----
+template <int CIN, int COUT, int MODE, int CLS, int IC>
+struct WClass {
+  static constexpr int KROWS = n_taps<MODE>(CLS) * CIN;
+  static constexpr int MTK = (KROWS + 15) / 16;
+  static constexpr int NT = (COUT + 15) / 16;
+  int offA[MTK];
+  f32x4 acc[MTK][NT];
+
+  __device__ __forceinline__ static void tap_of_row(int mm, int& tapg, int& ci, int& dr, int& dc) {
+    const int t = mm / CIN;
+    ci = mm - t * CIN;
+    int ky = 0, kx = 0;
+#pragma unroll
+    for (int tt = 0; tt < n_taps<MODE>(CLS); ++tt)
+      if (tt == t) { ky = tap_ky<MODE>(CLS, tt); kx = tap_kx<MODE>(CLS, tt); }
+    tapg = ky * 3 + kx;
+    if (MODE == MODE_UP) { dr = ky == 0 ? 1 : 0; dc = kx == 0 ? 1 : 0; }
+    else { dr = ky; dc = kx; }
+  }
+
+  __device__ __forceinline__ void init(int lane) {
+    const int m = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt) {
+      const int mm = 16 * mt + m;
+      int tapg, ci, dr, dc;
+      tap_of_row(mm < KROWS ? mm : 0, tapg, ci, dr, dc);
+      offA[mt] = (dr * IC + dc) * CIN + ci;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  __device__ __forceinline__ void step(const float* __restrict__ xa, const float (&bf)[NT]) {
+    float af[MTK];
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt) af[mt] = xa[offA[mt]];
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+  }
+
+  // add (or store, first == true) this wave's accumulators into the LDS row in gather layout
+  __device__ __forceinline__ void flush(float* __restrict__ wacc, int lane, bool first) const {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MTK; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = 16 * mt + 4 * kg + r;
+        if (mm < KROWS) {
+          int tapg, ci, dr, dc;
+          tap_of_row(mm, tapg, ci, dr, dc);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = 16 * nt + n;
+            if (co < COUT) {
+              float* p = wacc + (tapg * CIN + ci) * COUT + co;
+              *p = first ? acc[mt][nt][r] : *p + acc[mt][nt][r];
+            }
+          }
+        }
+      }
+  }
+};
+

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
 #pragma unroll
   for (int co = 0; co < 8; ++co) s1[co] = s2[co] = 0.f;
   const int tiles_y = a.Ho / THIN_TH;
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
     thin_stage1<PRO>(tile, a.in, a.in2, ca, cb, cc, b, a.Hi, oy0 - 1);
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256) void thin_8to1_kernel(const ConvArgs a) {
   TileStager<8, PRO, THIN_IR, THIN_IC> stg;
   stg.init();
   const int tiles_y = a.Ho / THIN_TH;
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
     stg.load(a.in, a.in2, b, a.Hi, a.Wi, oy0 - 1, -1);
@@ -219,7 +221,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_1to8_kernel(const WgradArgs a)
     dc[co] = DYPRO == PRO_BWD ? a.dc[co] : 0.f;
   }
   const int tiles_y = a.Ho / THIN_TH;
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
     thin_stage1<PRO_BN>(tile, a.x, nullptr, xa, xb, 0.f, b, a.Hi, oy0 - 1);
@@ -289,7 +292,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_8to1_kernel(const WgradArgs a)
   TileStager<8, PRO_BN, THIN_IR, THIN_IC> stg;
   stg.init();
   const int tiles_y = a.Ho / THIN_TH;
-  for (int tl = blockIdx.x; tl < a.ntiles; tl += gridDim.x) {
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
     stg.load(a.x, nullptr, b, a.Hi, a.Wi, oy0 - 1, -1);

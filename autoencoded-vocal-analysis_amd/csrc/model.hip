@@ -6,6 +6,7 @@
 #include <string>
 #include <map>
 #include "conv_common.h"
+#include "conv_fused.h"
 
 // internal entry points of the other translation units
 int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, const BnFuse* bn,
@@ -170,7 +171,9 @@ static size_t max_gemm_ws(int z, int B) {
 
 static size_t wgrad_part_floats(int B, int l) {
   const ConvLayer& L = kLayers[l];
-  const int grid = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+  int grid = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+  const int fg = ava_conv_fused_grid_for(B, L.hi, L.hi, L.cin, L.cout, L.mode);     // fused backward kernel's rows
+  if (fg > grid) grid = fg;
   return (size_t)grid * (9 * L.cin * L.cout + L.cout);
 }
 
@@ -545,11 +548,33 @@ extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, flo
 }
 
 // ---- all 14 weight-gradient reductions are issued per layer (partials buffer is shared) --------------
+// workgroups (= partial rows) of layer l's fused backward kernel; 0: the layer runs the separate kernels
+static int fused_grid(int l, int B) {
+  static const bool on = [] { const char* e = getenv("AVA_CONV_FUSED"); return e == nullptr || atoi(e) != 0; }();
+  if (!on || bn_fuse_enabled() || l == 0) return 0;
+  const ConvLayer& L = kLayers[l];
+  return ava_conv_fused_grid_for(B, L.hi, L.hi, L.cin, L.cout, L.mode);
+}
+
 static int conv_layer_backward(ava_model* m, int l, const float* x0, const float* gin, const float* gin2,
                                const float* ca, const float* cb, const float* cc, int pro, float* gout, int B,
                                hipStream_t st) {
   const ConvLayer& L = kLayers[l];
   const float* X = l == 0 ? x0 : m->X[l];
+  // layers with a fused kernel: data gradient, BatchNorm-backward sums and weight/bias partials from one pass
+  const int fgrid = fused_grid(l, B);
+  if (fgrid > 0 && gout != nullptr) {
+    FusedArgs a;
+    a.x = X; a.xa = bn_scale(m, l); a.xb = bn_shift(m, l);
+    a.dy = gin; a.dy2 = gin2; a.da = ca; a.db = cb; a.dc = cc;
+    a.Gb = m->Gb[l]; a.dx = gout; a.mean = bn_mean(m, l); a.invstd = bn_invstd(m, l);
+    a.bn_partials = m->bn_part; a.wg_partials = m->wg_part[l];
+    a.B = B; a.Hi = L.hi; a.Wi = L.hi; a.Ho = L.ho; a.Wo = L.ho;
+    a.tiles_y = a.tiles_x = a.ntiles = 0;
+    TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
+    mark(m, CAT_CONV_BWD_DATA, st);
+    return finalize_bwd(m, l, fgrid, (int64_t)B * L.hi * L.hi, st);
+  }
   // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
   TRY(ava_conv3x3_wgrad(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], B, L.hi, L.hi, L.cin,
                         L.cout, L.mode, pro, st));
@@ -574,7 +599,8 @@ static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
     tab.e[n].partials = m->wg_part[l];
     tab.e[n].dw = GG(m, L.pw);
     tab.e[n].dbias = GG(m, L.pb);
-    tab.e[n].nparts = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+    const int fg = fused_grid(l, B);
+    tab.e[n].nparts = fg > 0 ? fg : ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
     tab.e[n].cin = L.cin; tab.e[n].cout = L.cout;
     tab.e[n].kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
     tab.e[n].block0 = blocks;

@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--z-dim", type=int, default=32)
     ap.add_argument("--pool", type=int, default=8, help="distinct device-resident batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=6)
     return ap.parse_args()
 
 
@@ -61,7 +61,7 @@ def cpu_baseline(batch, z_dim, steps):
     from ava_amd import synthetic as syn
     from oracle import vae_oracle as O
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(cores, 16)     # fastest of 8/16/32/64/128 on the 2x64-core EPYC 9575F box (tools/cpu_threads.py)
     torch.set_num_threads(threads)
     P = O.to_params(syn.fixture_parameters(z_dim), requires_grad=True)
     running = O.fresh_running_stats()

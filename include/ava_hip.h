@@ -128,6 +128,18 @@ int ava_conv3x3_wgrad(const float* x, const float* xa, const float* xb,
                       float* partials, int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro,
                       ava_stream_t s);
 int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode);
+/* Fused backward of one layer (autograd's conv backward behind loss.backward(), ava/models/vae.py:349): ONE pass over
+ * x, dy (and dy2) produces what ava_conv3x3(pro 1|2, epi 1) in the backward-data pattern and ava_conv3x3_wgrad produce
+ * separately -- dx = gradient w.r.t. the BatchNorm output [B,Hi,Wi,Cin], bn_partials [grid][2*Cin] = {sum dx,
+ * sum dx*xhat} with xhat = (x - mean)*invstd, wg_partials [grid][9*Cin*Cout + Cout].  Gb = backward-data weights
+ * (pack kinds 3..6).  grid = ava_conv_fused_grid(...); 0 means the shape has no fused instantiation (the layers
+ * with 8 or 16 channels on both sides have one) and ava_conv3x3_bwd_fused returns AVA_EINVAL for it. */
+int ava_conv_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode);
+int ava_conv3x3_bwd_fused(const float* x, const float* xa, const float* xb,
+                          const float* dy, const float* dy2, const float* da, const float* db_, const float* dc,
+                          const float* Gb, float* dx, const float* mean, const float* invstd,
+                          float* bn_partials, float* wg_partials,
+                          int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro, ava_stream_t s);
 /* reduce the per-workgroup partials and scatter into the reference weight layout
  * (kind as in ava_pack_conv_weight, 0..2 only) */
 int ava_conv_wgrad_reduce(const float* partials, int nparts, float* dw, float* dbias,

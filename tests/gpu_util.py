@@ -74,6 +74,26 @@ def wgrad(x, xa, xb, dy, cin, cout, mode, dy_pro, B, hi, dy2=None, da=None, db=N
     return dw, dbias
 
 
+def bwd_fused(x, xa, xb, dy, Gb, mean, invstd, cin, cout, mode, dy_pro, B, hi, dy2=None, da=None, db=None, dc=None,
+              kind=0):
+    """fused backward: (dx, bn partial sums [2*cin] as float64, dw, dbias) or None when the shape has no instantiation"""
+    lib = _lib.load()
+    grid = lib.ava_conv_fused_grid(B, hi, hi, cin, cout, mode)
+    if grid <= 0:
+        return None
+    dx = torch.empty(B, hi, hi, cin, device="cuda")
+    bnp = torch.zeros(grid, 2 * cin, device="cuda")
+    wgp = torch.zeros(grid, 9 * cin * cout + cout, device="cuda")
+    rc = lib.ava_conv3x3_bwd_fused(p(x), p(xa), p(xb), p(dy), p(dy2), p(da), p(db), p(dc), p(Gb), p(dx), p(mean),
+                                   p(invstd), p(bnp), p(wgp), B, hi, hi, cin, cout, mode, dy_pro, stream())
+    _lib.check(rc, "ava_conv3x3_bwd_fused")
+    dw = torch.empty(9 * cin * cout, device="cuda")
+    dbias = torch.empty(cout, device="cuda")
+    _lib.check(lib.ava_conv_wgrad_reduce(p(wgp), grid, p(dw), p(dbias), cin, cout, kind, stream()), "reduce")
+    torch.cuda.synchronize()
+    return dx, bnp.double().sum(dim=0).cpu(), dw, dbias
+
+
 def gemm(A, B, M, N, K, a_k, b_k, bias=None, act=0, mask=None, colsum=False, lda=0, ldb=0, ldc=0, C=None):
     lib = _lib.load()
     nbytes = lib.ava_gemm_workspace_bytes(M, N, K)

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from gpu_util import (LAYERS, MODE_S1, MODE_DOWN, MODE_UP, PRO_BN, PRO_BWD, PRO_ID, EPI_FWD, EPI_BWD, EPI_SSE, dev,
+from gpu_util import (bwd_fused, LAYERS, MODE_S1, MODE_DOWN, MODE_UP, PRO_BN, PRO_BWD, PRO_ID, EPI_FWD, EPI_BWD, EPI_SSE, dev,
                       pack, conv3x3, wgrad, gemm, rel, nhwc, out_size, p, stream)
 from ava_amd import _lib, synthetic as syn
 from oracle import vae_oracle as O
@@ -104,6 +104,18 @@ def test_conv_backward_data_and_wgrad(layer):
     dw2, dbias2 = wgrad(dev(nhwc(x)), dev(scale), dev(shift), dev(nhwc(dU)), cin, cout, mode, PRO_ID, B, hi,
                         kind=kind_f)
     assert rel(dw2.cpu(), wr.grad.reshape(-1)) < TOL and rel(dbias2.cpu(), br.grad) < TOL
+    # ---- fused backward (one pass over x, g, y): same four results ----
+    for pro, dy_t, extra in ((PRO_BWD, gn, dict(dy2=dev(nhwc(y)), da=dev(A), db=dev(Bc), dc=dev(Cc))), (PRO_ID, dU, {})):
+        res = bwd_fused(dev(nhwc(x)), dev(scale), dev(shift), dev(nhwc(dy_t)), Gb, dev(mean), dev(invstd), cin, cout,
+                        mode, pro, B, hi, kind=kind_f, **extra)
+        if res is None:
+            assert cin not in (8, 16) or cout not in (8, 16)      # every 8/16-channel layer has a fused kernel
+            continue
+        fdx, fsums, fdw, fdb = res
+        assert rel(fdx.cpu(), nhwc(xhat.grad)) < TOL
+        assert float((fsums[:cin] - xhat.grad.sum(dim=(0, 2, 3))).abs().max() / scale_ref) < 1e-5
+        assert float((fsums[cin:] - (xhat.grad * xn).sum(dim=(0, 2, 3))).abs().max() / scale_ref) < 1e-5
+        assert rel(fdw.cpu(), wr.grad.reshape(-1)) < TOL and rel(fdb.cpu(), br.grad) < TOL
 
 
 def test_convt7_sse_epilogue():

@@ -106,7 +106,7 @@ __device__ __forceinline__ avaf4 ava_load_f4_async(const float* p) {
 template <int N>
 __device__ __forceinline__ void ava_wait_vm0(avaf4 (&r)[N]) {}
 
-template <int CIN, int PRO, int R, int C>
+template <int CIN, int PRO, int R, int C, bool PLANES = false>
 struct TileStager {
   static_assert(CIN % 4 == 0, "vector staging needs a multiple of 4 channels");
   static constexpr int Q = CIN / 4;
@@ -166,7 +166,10 @@ struct TileStager {
       avaf4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = ok ? prologue<PRO>(x[e], y[e], ca[e], ca[32 + e], ca[64 + e]) : 0.f;
-      if ((live >> i) & 1u) *reinterpret_cast<avaf4*>(lds + 4 * idx) = o;
+      // PLANES: channel quad q of every pixel in its own [R*C][4] plane, so lanes that walk along x read 16-byte
+      // slots 16 bytes apart (conflict-free ds_read_b128) instead of CIN*4 bytes apart
+      const int dst = PLANES ? ((idx % Q) * (R * C) + idx / Q) : idx;
+      if ((live >> i) & 1u) *reinterpret_cast<avaf4*>(lds + 4 * dst) = o;
     }
   }
 };

@@ -12,7 +12,7 @@ struct FusedArgs {
   const float* db;
   const float* dc;
   const float* Gb;       // backward-data weights in gather layout (pack kinds 3..6)
-  float* dx;             // [B,Hi,Wi,CI] gradient w.r.t. the BatchNorm output
+  float* dx;             // [B,Hi,Wi,CI] gradient w.r.t. the BatchNorm output (may be null for the 1 -> 8 layer: sums only)
   const float* mean;     // batch statistics of x (BatchNorm-backward sums)
   const float* invstd;
   float* bn_partials;    // [grid][2*CI]
@@ -24,3 +24,7 @@ struct FusedArgs {
 // 0 when (Cin, Cout, mode, size) has no fused instantiation
 int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode);
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);
+
+// conv1 (1 -> 8 channels at 128 x 128): VALU kernel in conv_thin.hip
+int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode);
+int ava_thin_bwd_fused_launch(const FusedArgs& a, int grid, int dy_pro, hipStream_t st);

@@ -361,6 +361,8 @@ static bool fused_tile(int Cin, int Cout, int mode, int* tw, int* th) {
 
 // number of workgroups (= partial rows of both outputs) of the fused kernel, 0 when the shape has none
 int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
+  const int thin = ava_thin_fused_grid(B, Hi, Wi, Cin, Cout, mode);
+  if (thin > 0) return thin;
   int tw, th;
   if (!fused_tile(Cin, Cout, mode, &tw, &th)) return 0;
   const int hl = mode == MODE_DOWN ? Hi / 2 : Hi, wl = mode == MODE_DOWN ? Wi / 2 : Wi;
@@ -372,6 +374,8 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
   const int grid = ava_conv_fused_grid_for(a.B, a.Hi, a.Wi, Cin, Cout, mode);
   if (grid <= 0) return AVA_EINVAL;
+  if (Cin == 1) return ava_thin_bwd_fused_launch(a, grid, dy_pro, st);
+  if (a.dx == nullptr) return AVA_EINVAL;
   const int var = fused_variant();
 #define X(ci, co, md, vr, tww, thh, mw)                                                            \
   if (Cin == ci && Cout == co && mode == md && var == vr) {                                         \
@@ -392,7 +396,7 @@ extern "C" int ava_conv3x3_bwd_fused(const float* x, const float* xa, const floa
                                      const float* da, const float* db, const float* dc, const float* Gb, float* dx,
                                      const float* mean, const float* invstd, float* bn_partials, float* wg_partials,
                                      int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro, ava_stream_t s) {
-  if (x == nullptr || xa == nullptr || xb == nullptr || dy == nullptr || Gb == nullptr || dx == nullptr ||
+  if (x == nullptr || xa == nullptr || xb == nullptr || dy == nullptr || Gb == nullptr || (dx == nullptr && Cin != 1) ||
       mean == nullptr || invstd == nullptr || bn_partials == nullptr || wg_partials == nullptr || B < 1)
     return AVA_EINVAL;
   if (dy_pro == PRO_BWD && (dy2 == nullptr || da == nullptr || db == nullptr || dc == nullptr)) return AVA_EINVAL;

@@ -7,11 +7,15 @@
 // applied (zero padding after BatchNorm), outputs leave as 16-byte stores.  Same ConvArgs / WgradArgs /
 // partial-row conventions as conv.hip.
 #include "conv_common.h"
+#include "conv_fused.h"
 
 #define THIN_W 128          // image width handled (Wo == Wi == 128)
 #define THIN_TH 8           // tile: 8 rows x 128 columns
 #define THIN_IR (THIN_TH + 2)
 #define THIN_IC (THIN_W + 2)
+#ifndef THIN_PLANES
+#define THIN_PLANES 0     // 1: two [10][130][4] channel planes instead of [10][130][8]
+#endif
 
 // sum N per-thread values over the workgroup: wave shuffles, then one LDS exchange (lds: [4][N] floats);
 // result i is written to out[i] by thread i.  Fixed order -> deterministic.
@@ -28,6 +32,20 @@ __device__ __forceinline__ void thin_block_reduce(const float (&v)[N], float* ld
   if (threadIdx.x < N && out != nullptr)
     out[threadIdx.x] = (lds[threadIdx.x] + lds[N + threadIdx.x]) + (lds[2 * N + threadIdx.x] + lds[3 * N + threadIdx.x]);
 }
+
+// The 72 wave-uniform weights of a thin layer, fetched ONCE into scalar registers.  Left as G[...] reads inside
+// the tile loop they cannot be hoisted (hipcc must assume the output stores alias them) and turn into 18
+// vector loads per tile and thread plus 72 VGPRs.
+__device__ __forceinline__ float ava_uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+struct ThinWeights {
+  float w[72];
+  __device__ __forceinline__ explicit ThinWeights(const float* __restrict__ G) {
+#pragma unroll
+    for (int i = 0; i < 72; ++i) w[i] = ava_uniform(G[i]);
+  }
+};
 
 // stage a 1-channel [10 x 130] window (origin row gy0, column -1) with the prologue applied
 template <int PRO>
@@ -55,7 +73,15 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
   __shared__ float red[4 * 16];
   const int t = threadIdx.x, ty0 = (t >> 7) * 4, x = t & 127;      // pixels (ty0 + p, x), p = 0..3
   const float ca = a.pa ? a.pa[0] : 0.f, cb = a.pb ? a.pb[0] : 0.f, cc = a.pc ? a.pc[0] : 0.f;
-  const float* __restrict__ G = a.G;                 // [9][1][8]
+  const ThinWeights W(a.G);                          // [9][1][8]
+  float bias[8], emean[8], einv[8];                  // wave-uniform epilogue constants, read once (scalar registers)
+#pragma unroll
+  for (int co = 0; co < 8; ++co) {
+    bias[co] = EPI == EPI_FWD ? ava_uniform(a.bias[co]) : 0.f;
+    emean[co] = EPI == EPI_BWD ? ava_uniform(a.epi_mean[co]) : 0.f;
+    einv[co] = EPI == EPI_BWD ? ava_uniform(a.epi_invstd[co]) : 0.f;
+  }
+  const bool relu = a.relu != 0;
   float s1[8], s2[8];
 #pragma unroll
   for (int co = 0; co < 8; ++co) s1[co] = s2[co] = 0.f;
@@ -80,7 +106,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int co = 0; co < 8; ++co) {
-          const float w = G[(ky * 3 + kx) * 8 + co];
+          const float w = W.w[(ky * 3 + kx) * 8 + co];
 #pragma unroll
           for (int p = 0; p < 4; ++p) acc[p][co] = fmaf(in[p + ky], w, acc[p][co]);
         }
@@ -92,8 +118,8 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
       if (EPI == EPI_FWD) {
 #pragma unroll
         for (int co = 0; co < 8; ++co) {
-          float v = acc[p][co] + a.bias[co];
-          if (a.relu) v = fmaxf(v, 0.f);
+          float v = acc[p][co] + bias[co];
+          if (relu) v = fmaxf(v, 0.f);
           acc[p][co] = v;
           s1[co] += v;
           s2[co] = fmaf(v, v, s2[co]);
@@ -104,7 +130,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
         const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
         for (int co = 0; co < 8; ++co) {
-          const float xh = (xv[co] - a.epi_mean[co]) * a.epi_invstd[co];
+          const float xh = (xv[co] - emean[co]) * einv[co];
           s1[co] += acc[p][co];
           s2[co] = fmaf(acc[p][co], xh, s2[co]);
         }
@@ -126,7 +152,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
 // 8 -> 1 channels: convt7 forward (PRO_BN, EPI_SSE), conv1 backward-data (PRO_BWD / PRO_ID, EPI_BWD)
 // ---------------------------------------------------------------------------------------------------------
 template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void thin_8to1_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* tile = smem;                                   // [10][130][8]
   float* coef = smem + THIN_IR * THIN_IC * 8;           // [3][32]
@@ -137,9 +163,11 @@ __global__ __launch_bounds__(256) void thin_8to1_kernel(const ConvArgs a) {
     const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
     coef[t] = (src != nullptr && c < 8) ? src[c] : 0.f;
   }
-  const float* __restrict__ G = a.G;                    // [9][8][1]
+  const ThinWeights W(a.G);                             // [9][8][1]
+  const float bias0 = EPI == EPI_SSE ? ava_uniform(a.bias[0]) : 0.f;
+  const float em0 = EPI == EPI_BWD ? ava_uniform(a.epi_mean[0]) : 0.f, ei0 = EPI == EPI_BWD ? ava_uniform(a.epi_invstd[0]) : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  TileStager<8, PRO, THIN_IR, THIN_IC> stg;
+  TileStager<8, PRO, THIN_IR, THIN_IC, (THIN_PLANES != 0)> stg;
   stg.init();
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
@@ -151,25 +179,28 @@ __global__ __launch_bounds__(256) void thin_8to1_kernel(const ConvArgs a) {
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = 0; kx < 3; ++kx) {
+      // one tap column at a time: without the fence hipcc hoists all 36 LDS vectors of the tile (144 VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const float* px = tile + ((ty0 + j) * THIN_IC + x + kx) * 8;
+        const float* px = tile + ((ty0 + j) * THIN_IC + x + kx) * (THIN_PLANES ? 4 : 8);
         const float4 u = *reinterpret_cast<const float4*>(px);
-        const float4 w4 = *reinterpret_cast<const float4*>(px + 4);
+        const float4 w4 = *reinterpret_cast<const float4*>(px + (THIN_PLANES ? THIN_IR * THIN_IC * 4 : 4));
         const float in[8] = {u.x, u.y, u.z, u.w, w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const int p = j - ky;                         // output row fed by input row j through tap ky
           if (p >= 0 && p < 4) {
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci) acc[p] = fmaf(in[ci], G[(ky * 3 + kx) * 8 + ci], acc[p]);
+            for (int ci = 0; ci < 8; ++ci) acc[p] = fmaf(in[ci], W.w[(ky * 3 + kx) * 8 + ci], acc[p]);
           }
         }
       }
+    }
     const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
     if (EPI == EPI_SSE) {
-      const float bias = a.bias[0];
+      const float bias = bias0;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const size_t opix = opix0 + (size_t)p * THIN_W;
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(256) void thin_8to1_kernel(const ConvArgs a) {
         if (a.out != nullptr) a.out[opix] = v;
       }
     } else {
-      const float m = a.epi_mean[0], is = a.epi_invstd[0];
+      const float m = em0, is = ei0;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const size_t opix = opix0 + (size_t)p * THIN_W;
@@ -272,7 +303,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_1to8_kernel(const WgradArgs a)
 
 // convt7: CIN = 8, COUT = 1.  dG[9][8][1], db[1]
 template <int DYPRO>
-__global__ __launch_bounds__(256) void thin_wgrad_8to1_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void thin_wgrad_8to1_kernel(const WgradArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* tile = smem;
   float* coef = smem + THIN_IR * THIN_IC * 8;
@@ -289,7 +320,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_8to1_kernel(const WgradArgs a)
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) acc[k][ci] = 0.f;
-  TileStager<8, PRO_BN, THIN_IR, THIN_IC> stg;
+  TileStager<8, PRO_BN, THIN_IR, THIN_IC, (THIN_PLANES != 0)> stg;
   stg.init();
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
@@ -311,9 +342,9 @@ __global__ __launch_bounds__(256) void thin_wgrad_8to1_kernel(const WgradArgs a)
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const float* px = tile + ((ty0 + j) * THIN_IC + x + kx) * 8;
+        const float* px = tile + ((ty0 + j) * THIN_IC + x + kx) * (THIN_PLANES ? 4 : 8);
         const float4 u = *reinterpret_cast<const float4*>(px);
-        const float4 w4 = *reinterpret_cast<const float4*>(px + 4);
+        const float4 w4 = *reinterpret_cast<const float4*>(px + (THIN_PLANES ? THIN_IR * THIN_IC * 4 : 4));
         const float in[8] = {u.x, u.y, u.z, u.w, w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -332,6 +363,184 @@ __global__ __launch_bounds__(256) void thin_wgrad_8to1_kernel(const WgradArgs a)
     for (int ci = 0; ci < 8; ++ci) sv[k * 8 + ci] = acc[k][ci];
   sv[72] = bacc;
   thin_block_reduce<73>(sv, smem, a.partials + (size_t)blockIdx.x * 73);     // tiles are dead: reuse their LDS
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv1 backward in one pass (CIN = 1, COUT = 8).  The first layer needs no data gradient, only the two
+// BatchNorm-backward sums of it -- and with a single input channel those follow from the weight-gradient
+// correlations, so dU is read ONCE, straight from global memory, and never convolved:
+//     dG'[tap][co] = sum_q xhat0[q + tap] * dU[q][co]        xhat0 = (x - mean) * invstd, zero outside the image
+//     S[tap][co]   = sum_q [q + tap inside the image] dU[q][co]   = T - border rows/columns (+ corners)
+//     dG[tap][co]  = gamma * dG' + beta * S                  (x_n = gamma * xhat + beta inside the image, 0 outside)
+//     sum_p dx[p]        = sum_{tap,co} W[tap][co] * S[tap][co]
+//     sum_p dx[p]*xhat[p] = sum_{tap,co} W[tap][co] * dG'[tap][co]
+// with gamma = xa / invstd, beta = xb + mean * xa recovered from the BatchNorm scale/shift (invstd > 0).
+// All of it is linear in dU, so every workgroup emits ordinary partial rows (bn [2], weight gradient [80]).
+// Replaces thin_8to1_kernel<.., EPI_BWD> + thin_wgrad_1to8_kernel on the model's path.
+// ---------------------------------------------------------------------------------------------------------
+// Thread mapping: lane pair (2x, 2x+1) shares pixel column x; thread (x, h) owns channels 4h..4h+3 of the 8 rows
+// of the tile, so every g / y load is one 16-byte slot per lane, contiguous across the wave.
+template <int DYPRO>
+__global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArgs a) {
+  __shared__ float tile[THIN_IR * THIN_IC];             // xhat0 window
+  __shared__ float red[4][2][44];                       // per wave, per channel half: dG' [9][4], T [4], border sums
+  __shared__ float tot[2][44];
+  __shared__ float ccol[2][2][4], kcor[2][2][2][4];     // [left/right][h], [left/right][top/bottom][h]
+  const int t = threadIdx.x, h = t & 1, x = t >> 1, wave = t >> 6, lane = t & 63;
+  const float mean = ava_uniform(a.mean[0]), invstd = ava_uniform(a.invstd[0]);
+  const float ha = invstd, hb = -mean * invstd;         // xhat = ha * x + hb
+  float acc[9][4], T[4], Rt[4], Rb[4], Cc[4], Kt[4], Kb[4];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) T[c] = Rt[c] = Rb[c] = Cc[c] = Kt[c] = Kb[c] = 0.f;
+  float da[4], db[4], dc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    da[c] = DYPRO == PRO_BWD ? a.da[4 * h + c] : 0.f;
+    db[c] = DYPRO == PRO_BWD ? a.db[4 * h + c] : 0.f;
+    dc[c] = DYPRO == PRO_BWD ? a.dc[4 * h + c] : 0.f;
+  }
+  const bool edge_col = x == 0 || x == THIN_W - 1;
+  const int tiles_y = a.Ho / THIN_TH;
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
+    const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
+    __syncthreads();
+    thin_stage1<PRO_BN>(tile, a.x, nullptr, ha, hb, 0.f, b, a.Hi, oy0 - 1);
+    const size_t o0 = (((size_t)b * a.Ho + oy0) * THIN_W + x) * 8 + 4 * h;
+    float du[THIN_TH][4];
+#pragma unroll
+    for (int p = 0; p < THIN_TH; ++p) {
+      const float4 g = *reinterpret_cast<const float4*>(a.dy + o0 + (size_t)p * THIN_W * 8);
+      float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (DYPRO == PRO_BWD) y = *reinterpret_cast<const float4*>(a.dy2 + o0 + (size_t)p * THIN_W * 8);
+      du[p][0] = prologue<DYPRO>(g.x, y.x, da[0], db[0], dc[0]);
+      du[p][1] = prologue<DYPRO>(g.y, y.y, da[1], db[1], dc[1]);
+      du[p][2] = prologue<DYPRO>(g.z, y.z, da[2], db[2], dc[2]);
+      du[p][3] = prologue<DYPRO>(g.w, y.w, da[3], db[3], dc[3]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) T[c] += du[p][c];
+    }
+    // border sums: image row 0 is row 0 of an image's first tile, row H-1 is row 7 of its last tile (wave-uniform)
+    if (oy0 == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { Rt[c] += du[0][c]; Kt[c] += edge_col ? du[0][c] : 0.f; }
+    }
+    if (oy0 + THIN_TH == a.Ho) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { Rb[c] += du[THIN_TH - 1][c]; Kb[c] += edge_col ? du[THIN_TH - 1][c] : 0.f; }
+    }
+    if (edge_col) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < THIN_TH; ++p) s += du[p][c];
+        Cc[c] += s;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float in[THIN_IR];
+#pragma unroll
+      for (int j = 0; j < THIN_IR; ++j) in[j] = tile[j * THIN_IC + x + kx];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int p = 0; p < THIN_TH; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[ky * 3 + kx][c] = fmaf(in[p + ky], du[p][c], acc[ky * 3 + kx][c]);
+    }
+  }
+  // ---- workgroup totals per channel half (lanes of equal parity), fixed order ----
+  float sv[44];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sv[k * 4 + c] = acc[k][c];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { sv[36 + c] = T[c]; sv[40 + c] = Rt[c]; }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 44; ++i) {
+    float v = sv[i];
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane < 2) red[wave][lane][i] = v;
+  }
+  float rb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v = Rb[c];
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    rb[c] = v;
+  }
+  __shared__ float rbot[4][2][4];
+  if (lane < 2) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rbot[wave][lane][c] = rb[c];
+  }
+  if (edge_col) {
+    const int side = x == 0 ? 0 : 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ccol[side][h][c] = Cc[c]; kcor[side][0][h][c] = Kt[c]; kcor[side][1][h][c] = Kb[c]; }
+  }
+  __syncthreads();
+  if (t < 88) {
+    const int hh = t / 44, i = t - 44 * hh;
+    tot[hh][i] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);
+  }
+  __syncthreads();
+  float* scratch = &red[0][0][0];                        // [2][72] products for the two BatchNorm sums (red is dead)
+  if (t < 72) {
+    const int tap = t >> 3, co = t & 7, hh = co >> 2, c = co & 3, ky = tap / 3, kx = tap - 3 * ky;
+    float S = tot[hh][36 + c];
+    if (ky == 0) S -= tot[hh][40 + c];
+    if (ky == 2) S -= (rbot[0][hh][c] + rbot[1][hh][c]) + (rbot[2][hh][c] + rbot[3][hh][c]);
+    if (kx == 0) S -= ccol[0][hh][c];
+    if (kx == 2) S -= ccol[1][hh][c];
+    if (ky == 0 && kx == 0) S += kcor[0][0][hh][c];
+    if (ky == 0 && kx == 2) S += kcor[1][0][hh][c];
+    if (ky == 2 && kx == 0) S += kcor[0][1][hh][c];
+    if (ky == 2 && kx == 2) S += kcor[1][1][hh][c];
+    const float xa = a.xa[0], xb = a.xb[0];
+    const float gamma = xa / invstd, beta = fmaf(mean, xa, xb);
+    const float dgp = tot[hh][tap * 4 + c];
+    a.wg_partials[(size_t)blockIdx.x * 80 + t] = fmaf(gamma, dgp, beta * S);
+    const float w = a.Gb[(8 - tap) * 8 + co];            // forward weight W[tap][co] out of the flipped backward pack
+    scratch[t] = w * S;
+    scratch[72 + t] = w * dgp;
+  } else {
+    if (t < 80) a.wg_partials[(size_t)blockIdx.x * 80 + t] = tot[(t - 72) >> 2][36 + ((t - 72) & 3)];   // bias gradient = T
+  }
+  __syncthreads();
+  if (t < 2) {
+    float s = 0.f;
+    for (int i = 0; i < 72; ++i) s += scratch[72 * t + i];
+    a.bn_partials[(size_t)blockIdx.x * 2 + t] = s;
+  }
+}
+
+int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
+  if (Cin != 1 || Cout != 8 || mode != MODE_S1 || Wi != THIN_W || Hi % THIN_TH != 0) return 0;
+  const int nt = B * (Hi / THIN_TH);
+  return nt < 1024 ? nt : 1024;
+}
+
+int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int dy_pro, hipStream_t st) {
+  FusedArgs a = a0;
+  a.ntiles = a.B * (a.Ho / THIN_TH);
+  if (a.dx != nullptr) return AVA_EINVAL;                // this layer's data gradient is never formed
+  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
+  else if (dy_pro == PRO_ID) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
+  else return AVA_EINVAL;
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -551,7 +551,7 @@ extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, flo
 // workgroups (= partial rows) of layer l's fused backward kernel; 0: the layer runs the separate kernels
 static int fused_grid(int l, int B) {
   static const bool on = [] { const char* e = getenv("AVA_CONV_FUSED"); return e == nullptr || atoi(e) != 0; }();
-  if (!on || bn_fuse_enabled() || l == 0) return 0;
+  if (!on || bn_fuse_enabled()) return 0;
   const ConvLayer& L = kLayers[l];
   return ava_conv_fused_grid_for(B, L.hi, L.hi, L.cin, L.cout, L.mode);
 }
@@ -563,7 +563,7 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   const float* X = l == 0 ? x0 : m->X[l];
   // layers with a fused kernel: data gradient, BatchNorm-backward sums and weight/bias partials from one pass
   const int fgrid = fused_grid(l, B);
-  if (fgrid > 0 && gout != nullptr) {
+  if (fgrid > 0 && (gout != nullptr || l == 0)) {
     FusedArgs a;
     a.x = X; a.xa = bn_scale(m, l); a.xb = bn_shift(m, l);
     a.dy = gin; a.dy2 = gin2; a.da = ca; a.db = cb; a.dc = cc;

@@ -133,7 +133,8 @@ int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode);
  * separately -- dx = gradient w.r.t. the BatchNorm output [B,Hi,Wi,Cin], bn_partials [grid][2*Cin] = {sum dx,
  * sum dx*xhat} with xhat = (x - mean)*invstd, wg_partials [grid][9*Cin*Cout + Cout].  Gb = backward-data weights
  * (pack kinds 3..6).  grid = ava_conv_fused_grid(...); 0 means the shape has no fused instantiation (the layers
- * with 8 or 16 channels on both sides have one) and ava_conv3x3_bwd_fused returns AVA_EINVAL for it. */
+ * with 8 or 16 channels on both sides and the 1 -> 8 layer have one) and ava_conv3x3_bwd_fused returns AVA_EINVAL
+ * for it.  The 1 -> 8 layer (first layer: nothing upstream) never forms dx: pass dx = NULL, the sums are exact. */
 int ava_conv_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode);
 int ava_conv3x3_bwd_fused(const float* x, const float* xa, const float* xb,
                           const float* dy, const float* dy2, const float* da, const float* db_, const float* dc,

@@ -81,7 +81,7 @@ def bwd_fused(x, xa, xb, dy, Gb, mean, invstd, cin, cout, mode, dy_pro, B, hi, d
     grid = lib.ava_conv_fused_grid(B, hi, hi, cin, cout, mode)
     if grid <= 0:
         return None
-    dx = torch.empty(B, hi, hi, cin, device="cuda")
+    dx = torch.empty(B, hi, hi, cin, device="cuda") if cin > 1 else None     # the 1 -> 8 layer forms no data gradient
     bnp = torch.zeros(grid, 2 * cin, device="cuda")
     wgp = torch.zeros(grid, 9 * cin * cout + cout, device="cuda")
     rc = lib.ava_conv3x3_bwd_fused(p(x), p(xa), p(xb), p(dy), p(dy2), p(da), p(db), p(dc), p(Gb), p(dx), p(mean),

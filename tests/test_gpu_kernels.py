@@ -109,10 +109,10 @@ def test_conv_backward_data_and_wgrad(layer):
         res = bwd_fused(dev(nhwc(x)), dev(scale), dev(shift), dev(nhwc(dy_t)), Gb, dev(mean), dev(invstd), cin, cout,
                         mode, pro, B, hi, kind=kind_f, **extra)
         if res is None:
-            assert cin not in (8, 16) or cout not in (8, 16)      # every 8/16-channel layer has a fused kernel
+            assert cin not in (1, 8, 16) or cout not in (8, 16)   # conv1 and every 8/16-channel layer have a fused kernel
             continue
         fdx, fsums, fdw, fdb = res
-        assert rel(fdx.cpu(), nhwc(xhat.grad)) < TOL
+        assert fdx is None or rel(fdx.cpu(), nhwc(xhat.grad)) < TOL
         assert float((fsums[:cin] - xhat.grad.sum(dim=(0, 2, 3))).abs().max() / scale_ref) < 1e-5
         assert float((fsums[cin:] - (xhat.grad * xn).sum(dim=(0, 2, 3))).abs().max() / scale_ref) < 1e-5
         assert rel(fdw.cpu(), wr.grad.reshape(-1)) < TOL and rel(fdb.cpu(), br.grad) < TOL

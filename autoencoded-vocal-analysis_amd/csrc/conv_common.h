@@ -5,7 +5,7 @@
 
 enum { MODE_S1 = 0, MODE_DOWN = 1, MODE_UP = 2 };
 enum { PRO_BN = 0, PRO_BWD = 1, PRO_ID = 2 };
-enum { EPI_FWD = 0, EPI_BWD = 1, EPI_SSE = 2 };
+enum { EPI_FWD = 0, EPI_BWD = 1, EPI_SSE = 2, EPI_NONE = 3 };   // EPI_NONE: store only (internal)
 
 struct ConvArgs {
   const float* in;

@@ -25,6 +25,6 @@ struct FusedArgs {
 int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode);
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);
 
-// conv1 (1 -> 8 channels at 128 x 128): VALU kernel in conv_thin.hip
+// conv1 (1 -> 8) and convt7 (8 -> 1) at 128 x 128: VALU kernels in conv_thin.hip
 int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode);
-int ava_thin_bwd_fused_launch(const FusedArgs& a, int grid, int dy_pro, hipStream_t st);
+int ava_thin_bwd_fused_launch(const FusedArgs& a, int grid, int Cin, int dy_pro, hipStream_t st);

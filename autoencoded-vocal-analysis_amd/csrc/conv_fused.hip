@@ -374,7 +374,7 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
   const int grid = ava_conv_fused_grid_for(a.B, a.Hi, a.Wi, Cin, Cout, mode);
   if (grid <= 0) return AVA_EINVAL;
-  if (Cin == 1) return ava_thin_bwd_fused_launch(a, grid, dy_pro, st);
+  if (Cin == 1 || Cout == 1) return ava_thin_bwd_fused_launch(a, grid, Cin, dy_pro, st);
   if (a.dx == nullptr) return AVA_EINVAL;
   const int var = fused_variant();
 #define X(ci, co, md, vr, tww, thh, mw)                                                            \

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
           s1[co] += v;
           s2[co] = fmaf(v, v, s2[co]);
         }
-      } else {
+      } else if (EPI == EPI_BWD) {
         const float4 xa = *reinterpret_cast<const float4*>(a.epi_x + (opix + p) * 8);
         const float4 xb = *reinterpret_cast<const float4*>(a.epi_x + (opix + p) * 8 + 4);
         const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
       }
     }
   }
+  if (EPI == EPI_NONE) return;
   float sv[16];
 #pragma unroll
   for (int co = 0; co < 8; ++co) { sv[co] = s1[co]; sv[8 + co] = s2[co]; }
@@ -526,19 +527,168 @@ __global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArg
   }
 }
 
-int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
-  if (Cin != 1 || Cout != 8 || mode != MODE_S1 || Wi != THIN_W || Hi % THIN_TH != 0) return 0;
-  const int nt = B * (Hi / THIN_TH);
-  return nt < 1024 ? nt : 1024;
+// ---------------------------------------------------------------------------------------------------------
+// convt7 backward (CIN = 8, COUT = 1; dU = the 1-channel seed gradient or PRO_BWD of it).  Same identity as conv1:
+// with xhat0 = (x - mean) * invstd zero padded,  dG'[tap][ci] = sum_p xhat0[p + tap][ci] * dU[p]  gives
+//   dG[tap][ci] = gamma_ci dG' + beta_ci S[tap],   sum_q dx[q][ci] = sum_tap G[tap][ci] S[tap],
+//   sum_q dx[q][ci] xhat[q][ci] = sum_tap G[tap][ci] dG'[tap][ci]
+// (S[tap] = sum of dU over the pixels whose tap lands inside the image), so the data-gradient kernel
+// (thin_1to8_kernel<.., EPI_NONE>) only has to write dx and never reads x; this kernel reads x once.
+// ---------------------------------------------------------------------------------------------------------
+template <int DYPRO>
+__global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const FusedArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float* tile = smem;                                   // [10][130][8] xhat0
+  float* coef = smem + THIN_IR * THIN_IC * 8;           // [3][32]
+  float* aux = coef + 96;                               // [4] row sums per wave, [4] column sums, [4] corners
+  const int t = threadIdx.x, ty0 = (t >> 7) * 4, x = t & 127, wave = t >> 6, lane = t & 63;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    float v = 0.f;
+    if (c < 8) v = which == 0 ? a.invstd[c] : (which == 1 ? -a.mean[c] * a.invstd[c] : 0.f);
+    coef[t] = v;
+  }
+  const float da = DYPRO == PRO_BWD ? a.da[0] : 0.f, db = DYPRO == PRO_BWD ? a.db[0] : 0.f,
+              dc = DYPRO == PRO_BWD ? a.dc[0] : 0.f;
+  float acc[9][8], T = 0.f, R = 0.f, Cc = 0.f, K = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) acc[k][ci] = 0.f;
+  const bool edge_col = x == 0 || x == THIN_W - 1;
+  TileStager<8, PRO_BN, THIN_IR, THIN_IC, (THIN_PLANES != 0)> stg;
+  stg.init();
+  const int tiles_y = a.Ho / THIN_TH;
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
+    const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
+    __syncthreads();
+    stg.load(a.x, nullptr, b, a.Hi, a.Wi, oy0 - 1, -1);
+    stg.store(tile, coef);
+    __syncthreads();
+    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+    float du[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const size_t opix = opix0 + (size_t)p * THIN_W;
+      du[p] = prologue<DYPRO>(a.dy[opix], DYPRO == PRO_BWD ? a.dy2[opix] : 0.f, da, db, dc);
+    }
+    const float strip = (du[0] + du[1]) + (du[2] + du[3]);
+    T += strip;
+    // border sums; a thread's role is fixed by (ty0, x) -- see thin_bwd_fused_1to8_kernel
+    const bool top = oy0 + ty0 == 0, bottom = oy0 + ty0 + 3 == a.Ho - 1;
+    if (top || bottom) {
+      const float v = top ? du[0] : du[3];
+      R += v;
+      K += edge_col ? v : 0.f;
+    }
+    Cc += edge_col ? strip : 0.f;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float* px = tile + ((ty0 + j) * THIN_IC + x + kx) * (THIN_PLANES ? 4 : 8);
+        const float4 u = *reinterpret_cast<const float4*>(px);
+        const float4 w4 = *reinterpret_cast<const float4*>(px + (THIN_PLANES ? THIN_IR * THIN_IC * 4 : 4));
+        const float in[8] = {u.x, u.y, u.z, u.w, w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int p = j - ky;
+          if (p >= 0 && p < 4) {
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) acc[ky * 3 + kx][ci] = fmaf(in[ci], du[p], acc[ky * 3 + kx][ci]);
+          }
+        }
+      }
+  }
+  float sv[73];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) sv[k * 8 + ci] = acc[k][ci];
+  sv[72] = T;
+  float* tot = smem + 4 * 73;                           // [73] behind the reduction scratch (tiles are dead)
+  thin_block_reduce<73>(sv, smem, tot);
+  const float rw = wave_sum(R);
+  if (lane == 0) aux[wave] = rw;                        // waves 0,1: image row 0;  waves 2,3: image row H-1
+  if (edge_col) {
+    const int role = (t >> 7) * 2 + (x == 0 ? 0 : 1);   // 0: x=0 top half, 1: x=127 top half, 2: x=0 bottom, 3: x=127 bottom
+    aux[4 + role] = Cc;
+    aux[8 + role] = K;
+  }
+  __syncthreads();
+  float* scratch = smem + 512;                          // [2][72]
+  if (t < 72) {
+    const int tap = t >> 3, ci = t & 7, ky = tap / 3, kx = tap - 3 * ky;
+    float S = tot[72];
+    if (ky == 0) S -= aux[0] + aux[1];
+    if (ky == 2) S -= aux[2] + aux[3];
+    if (kx == 0) S -= aux[4] + aux[6];
+    if (kx == 2) S -= aux[5] + aux[7];
+    if (ky == 0 && kx == 0) S += aux[8];
+    if (ky == 0 && kx == 2) S += aux[9];
+    if (ky == 2 && kx == 0) S += aux[10];
+    if (ky == 2 && kx == 2) S += aux[11];
+    const float xa = a.xa[ci], xb = a.xb[ci], mean = a.mean[ci], invstd = a.invstd[ci];
+    const float gamma = xa / invstd, beta = fmaf(mean, xa, xb);
+    const float dgp = tot[t];
+    a.wg_partials[(size_t)blockIdx.x * 73 + t] = fmaf(gamma, dgp, beta * S);
+    const float w = a.Gb[(8 - tap) * 8 + ci];            // forward gather weight G[tap][ci] out of the backward pack
+    scratch[t] = w * S;
+    scratch[72 + t] = w * dgp;
+  } else if (t == 72) {
+    a.wg_partials[(size_t)blockIdx.x * 73 + 72] = tot[72];                    // bias gradient = T
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int which = t >> 3, ci = t & 7;
+    float s = 0.f;
+    for (int tap = 0; tap < 9; ++tap) s += scratch[72 * which + tap * 8 + ci];
+    a.bn_partials[(size_t)blockIdx.x * 16 + t] = s;
+  }
 }
 
-int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int dy_pro, hipStream_t st) {
+int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
+  if (mode != MODE_S1 || Wi != THIN_W || Hi % THIN_TH != 0) return 0;
+  if (!((Cin == 1 && Cout == 8) || (Cin == 8 && Cout == 1))) return 0;
+  const int nt = B * (Hi / THIN_TH);
+  const int cap = Cin == 1 ? 768 : 512;                  // resident workgroups (3 resp. 2 per CU): one wave of them
+  return nt < cap ? nt : cap;
+}
+
+static const size_t kThinStatsLds = (size_t)(THIN_IR * THIN_IC * 8 + 96 + 16) * sizeof(float);
+
+int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro, hipStream_t st) {
   FusedArgs a = a0;
   a.ntiles = a.B * (a.Ho / THIN_TH);
-  if (a.dx != nullptr) return AVA_EINVAL;                // this layer's data gradient is never formed
-  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
-  else if (dy_pro == PRO_ID) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
-  else return AVA_EINVAL;
+  if (dy_pro != PRO_BWD && dy_pro != PRO_ID) return AVA_EINVAL;
+  if (Cin == 1) {
+    if (a.dx != nullptr) return AVA_EINVAL;              // this layer's data gradient is never formed
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
+    AVA_CHECK_LAUNCH();
+    return AVA_OK;
+  }
+  // 8 -> 1: dx by the 1 -> 8 gather kernel (store only), then weight gradient + BatchNorm sums in one pass over x
+  if (a.dx == nullptr) return AVA_EINVAL;
+  ConvArgs c = {};
+  c.in = a.dy; c.in2 = a.dy2; c.pa = a.da; c.pb = a.db; c.pc = a.dc; c.G = a.Gb; c.out = a.dx;
+  c.B = a.B; c.Hi = a.Ho; c.Wi = a.Wo; c.Ho = a.Hi; c.Wo = a.Wi; c.ntiles = a.ntiles;
+  const int dgrid = a.ntiles < 2048 ? a.ntiles : 2048;   // no partial rows: free to use more, lighter workgroups
+  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BWD, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
+  else hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
+  AVA_CHECK_LAUNCH();
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_BWD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_ID>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess)
+      return AVA_ELAUNCH;
+    attr = true;
+  }
+  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_BWD>), dim3(grid), dim3(256), kThinStatsLds, st, a);
+  else hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_ID>), dim3(grid), dim3(256), kThinStatsLds, st, a);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -109,7 +109,7 @@ def test_conv_backward_data_and_wgrad(layer):
         res = bwd_fused(dev(nhwc(x)), dev(scale), dev(shift), dev(nhwc(dy_t)), Gb, dev(mean), dev(invstd), cin, cout,
                         mode, pro, B, hi, kind=kind_f, **extra)
         if res is None:
-            assert cin not in (1, 8, 16) or cout not in (8, 16)   # conv1 and every 8/16-channel layer have a fused kernel
+            assert max(cin, cout) > 16                           # every layer up to 16 channels has a fused kernel
             continue
         fdx, fsums, fdw, fdb = res
         assert fdx is None or rel(fdx.cpu(), nhwc(xhat.grad)) < TOL

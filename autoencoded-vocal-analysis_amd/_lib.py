@@ -65,6 +65,7 @@ SIGNATURES = {
     "ava_conv3x3": (_i, [_p] * 13 + [_i] * 9 + [_f, _p]),
     "ava_conv3x3_wgrad": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "ava_conv_wgrad_grid": (_i, [_i, _i, _i, _i]),
+    "ava_conv_wgrad_rows": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "ava_conv_fused_grid": (_i, [_i, _i, _i, _i, _i, _i]),
     "ava_conv3x3_bwd_fused": (_i, [_p] * 14 + [_i] * 7 + [_p]),
     "ava_conv_wgrad_reduce": (_i, [_p, _i, _p, _p, _i, _i, _i, _p]),

@@ -493,6 +493,7 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
   if (epi != EPI_BWD && bias == nullptr) return AVA_EINVAL;
   if (pro == PRO_BWD && in2 == nullptr) return AVA_EINVAL;
   const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
+  a.part_rows = grid;
   const int tw = tile_w(a.Wo);
   hipStream_t st = to_stream(s);
   if (use_mfma() && epi != EPI_SSE) {
@@ -557,7 +558,7 @@ extern "C" int ava_conv3x3_wgrad(const float* x, const float* xa, const float* x
   a.ntiles = conv_geometry(B, a.Ho, a.Wo, &a.tiles_y, &a.tiles_x);
   if (a.ntiles <= 0 || x == nullptr || dy == nullptr || partials == nullptr) return AVA_EINVAL;
   if (dy_pro == PRO_BWD && dy2 == nullptr) return AVA_EINVAL;
-  const int grid = a.ntiles < 512 ? a.ntiles : 512;
+  const int grid = a.ntiles < 512 ? a.ntiles : 512;   // the matrix-core kernels may launch (= write rows for) fewer
   const int tw = tile_w(a.Wo);
   hipStream_t st = to_stream(s);
   if (use_mfma()) {
@@ -588,6 +589,23 @@ extern "C" int ava_conv3x3_wgrad(const float* x, const float* xa, const float* x
   AVA_WG_CASE(8, 1, MODE_S1, 32)
 #undef AVA_WG_CASE
   return AVA_EINVAL;
+}
+
+// partial rows ava_conv3x3_wgrad writes for this shape (<= ava_conv_wgrad_grid): the matrix-core kernels launch one
+// resident wave of workgroups, which depends on the kernel's occupancy
+extern "C" int ava_conv_wgrad_rows(int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro) {
+  WgradArgs a = {};
+  a.B = B; a.Hi = Hi; a.Wi = Wi;
+  a.Ho = mode == MODE_S1 ? Hi : (mode == MODE_DOWN ? Hi / 2 : Hi * 2);
+  a.Wo = mode == MODE_S1 ? Wi : (mode == MODE_DOWN ? Wi / 2 : Wi * 2);
+  a.ntiles = conv_geometry(B, a.Ho, a.Wo, &a.tiles_y, &a.tiles_x);
+  if (a.ntiles <= 0) return AVA_EINVAL;
+  const int grid = a.ntiles < 512 ? a.ntiles : 512;
+  if (use_mfma()) {
+    const int rows = ava_conv3x3_wgrad_mfma(a, grid, Cin, Cout, mode, dy_pro, nullptr);   // partials == NULL: query
+    if (rows > 0) return rows;
+  }
+  return grid;
 }
 
 extern "C" int ava_pack_conv_weight(const float* w, float* g, int c_first, int c_second, int kind, ava_stream_t s) {

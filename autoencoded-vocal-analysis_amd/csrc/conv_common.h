@@ -26,6 +26,7 @@ struct ConvArgs {
   float prec;
   int tiles_y, tiles_x, ntiles;
   BnFuse bn; // optional fused BatchNorm finalisation by the last workgroup (bn.counter == nullptr: off)
+  int part_rows; // rows of `partials` the caller sized ([ava_conv_grid]); rows beyond the launched grid are zero-filled
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };
 
@@ -173,6 +174,21 @@ struct TileStager {
     }
   }
 };
+
+// Workgroups of one resident wave of a persistent kernel: occupancy (workgroups per CU) x CUs.  A persistent grid
+// larger than that runs in rounds whose last one is partly empty, and pays the per-workgroup set-up (weights into
+// registers, pipeline fill) once per round.
+template <typename K>
+static inline int ava_resident_grid(K kernel, size_t lds_bytes) {
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, lds_bytes) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  return per_cu * cus;
+}
 
 // XCD-aware walk over a persistent workgroup's tile list.  Workgroups are dispatched round-robin over the 8 XCDs
 // (workgroup w runs on XCD w % 8), each with its own L2; handing every XCD one contiguous eighth of the tile list

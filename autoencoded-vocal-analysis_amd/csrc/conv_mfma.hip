@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     const int idx = which * 16 * MT + co;
     bn_partial_store(a.bn, a.partials + (size_t)blockIdx.x * 2 * COUT + t,
                      (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]));
+    for (int r = gridDim.x + blockIdx.x; r < a.part_rows; r += gridDim.x)       // rows of workgroups not launched
+      a.partials[(size_t)r * 2 * COUT + t] = 0.f;
   }
   bn_fused_finalize(a.bn, a.partials, gridDim.x, reinterpret_cast<double*>(smem));
 }
@@ -221,7 +223,11 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid > b.ntiles) return AVA_EINVAL;
-  { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; }
+  // one resident wave of workgroups; the partial rows of the workgroups not launched are zero-filled by the kernel
+  static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>, lds);
+  b.part_rows = grid;
+  if (grid > resident && a.bn.counter == nullptr) grid = resident;
+  { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
   hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
@@ -416,6 +422,9 @@ static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid > b.ntiles) return AVA_EINVAL;
+  static const int resident = ava_resident_grid(&conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>, lds);
+  if (grid > resident) grid = resident;          // one resident wave of workgroups = partial rows written
+  if (a.partials == nullptr) return grid;        // row-count query (ava_conv_wgrad_rows)
   hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;

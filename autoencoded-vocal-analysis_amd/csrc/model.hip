@@ -600,7 +600,7 @@ static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
     tab.e[n].dw = GG(m, L.pw);
     tab.e[n].dbias = GG(m, L.pb);
     const int fg = fused_grid(l, B);
-    tab.e[n].nparts = fg > 0 ? fg : ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
+    tab.e[n].nparts = fg > 0 ? fg : ava_conv_wgrad_rows(B, L.hi, L.hi, L.cin, L.cout, L.mode, l == 13 || l == 6 ? PRO_ID : PRO_BWD);
     tab.e[n].cin = L.cin; tab.e[n].cout = L.cout;
     tab.e[n].kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
     tab.e[n].block0 = blocks;

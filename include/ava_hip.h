@@ -128,6 +128,10 @@ int ava_conv3x3_wgrad(const float* x, const float* xa, const float* xb,
                       float* partials, int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro,
                       ava_stream_t s);
 int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode);
+/* rows of `partials` that ava_conv3x3_wgrad actually writes for this shape (<= ava_conv_wgrad_grid, which sizes the
+ * buffer): the matrix-core kernels launch one resident wave of workgroups.  Reduce exactly this many rows, or zero
+ * the buffer first. */
+int ava_conv_wgrad_rows(int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro);
 /* Fused backward of one layer (autograd's conv backward behind loss.backward(), ava/models/vae.py:349): ONE pass over
  * x, dy (and dy2) produces what ava_conv3x3(pro 1|2, epi 1) in the backward-data pattern and ava_conv3x3_wgrad produce
  * separately -- dx = gradient w.r.t. the BatchNorm output [B,Hi,Wi,Cin], bn_partials [grid][2*Cin] = {sum dx,

@@ -69,7 +69,10 @@ def wgrad(x, xa, xb, dy, cin, cout, mode, dy_pro, B, hi, dy2=None, da=None, db=N
     _lib.check(rc, "ava_conv3x3_wgrad")
     dw = torch.empty(9 * cin * cout, device="cuda")
     dbias = torch.empty(cout, device="cuda")
-    _lib.check(lib.ava_conv_wgrad_reduce(p(partials), grid, p(dw), p(dbias), cin, cout, kind, stream()), "reduce")
+    rows = lib.ava_conv_wgrad_rows(B, hi, hi, cin, cout, mode, dy_pro)      # rows actually written (<= grid)
+    assert 0 < rows <= grid
+    assert float(partials[rows:].abs().sum()) == 0.0
+    _lib.check(lib.ava_conv_wgrad_reduce(p(partials), rows, p(dw), p(dbias), cin, cout, kind, stream()), "reduce")
     torch.cuda.synchronize()
     return dw, dbias
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ava_model_destroy": (None, [_p]),
     "ava_forward": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ava_backward": (_i, [_p, _p, _i, _p]),
+    "ava_backward_num_parts": (_i, []),
     "ava_backward_part": (_i, [_p, _p, _i, _i, _p]),
     "ava_grad_bucket": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "ava_adam_step": (_i, [_p, _d, _d, _d, _d, _i, _p]),

@@ -284,8 +284,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
     }
   }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (size_t)gridDim.x * blockDim.x) {
+    // slabs are summed in index order (deterministic); eight loads are put in flight per batch
     float s = 0.f;
-    for (int p = 0; p < splits; ++p) s += ws[p * mn + i];
+    int p = 0;
+    for (; p + 8 <= splits; p += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(p + u) * mn + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < splits; ++p) s += ws[(size_t)p * mn + i];
     const size_t m = i / N, n = i - m * N;
     if (bias != nullptr) s += bias[n];
     s = apply_act(s, act);
@@ -296,6 +305,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
 
 static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
   *bm = (M >= 128 && N >= 128) ? 128 : 64;
+  // small outputs with a short K (fc2, fc3x, fc6, fc7 and their dX): 64x64 tiles give 4x the workgroups per split,
+  // so fewer, longer splits and a quarter of the slab traffic (measured -3.5 us per product at batch 256)
+  if ((size_t)M * N <= 262144 && K <= 2048) *bm = 64;
   const int tiles = ceil_div(M, *bm) * ceil_div(N, *bm);
   int s = 1;
   if (tiles < 384) {

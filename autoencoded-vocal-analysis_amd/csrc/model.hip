@@ -613,29 +613,38 @@ static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
 }
 
 // Gradient buckets for the data-parallel all-reduce, in the order backward completes them:
-//   bucket 0 = [fc8.weight .. end of arena)  (fc8, convt1..7, bn8..14: ~33.6 MB) -- complete after part 0
-//   bucket 1 = [0 .. fc8.weight)             (conv1..7, bn1..7, fc1..fc7)         -- complete after part 1
+//   bucket 0 = [fc8.weight .. end of arena)   fc8, convt1..7, bn8..14 (33.6 MB)  -- complete after part 0
+//   bucket 1 = [fc1.weight .. fc8.weight)     fc1 .. fc7              (36.0 MB)  -- complete after part 1
+//   bucket 2 = [0 .. fc1.weight)              conv1..7, bn1..7        (84 KB)    -- complete after part 2
+// so the two large all-reduces run under the fully connected and the encoder halves of backward.
+#define AVA_BACKWARD_PARTS 3
+extern "C" int ava_backward_num_parts(void) { return AVA_BACKWARD_PARTS; }
 extern "C" int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count) {
-  if (m == nullptr || offset == nullptr || count == nullptr || bucket < 0 || bucket > 1) return AVA_EINVAL;
-  const int64_t split = m->tab[50].off;      // fc8.weight
-  if (bucket == 0) { *offset = split; *count = m->arena - split; }
-  else { *offset = 0; *count = split; }
+  if (m == nullptr || offset == nullptr || count == nullptr || bucket < 0 || bucket >= AVA_BACKWARD_PARTS) return AVA_EINVAL;
+  const int64_t fc1 = m->tab[28].off, fc8 = m->tab[50].off;      // fc1.weight, fc8.weight
+  if (bucket == 0) { *offset = fc8; *count = m->arena - fc8; }
+  else if (bucket == 1) { *offset = fc1; *count = fc8 - fc1; }
+  else { *offset = 0; *count = fc1; }
   return AVA_OK;
 }
 
 static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st);
 static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st);
+static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st);
 
 extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s) {
   if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr) return AVA_EINVAL;
   TRY(backward_part0(m, x, B, to_stream(s)));
-  return backward_part1(m, x, B, to_stream(s));
+  TRY(backward_part1(m, x, B, to_stream(s)));
+  return backward_part2(m, x, B, to_stream(s));
 }
-// part 0: decoder convolutions, bn8, fc8's weight gradient (everything in gradient bucket 0);
-// part 1: the remaining fully connected layers, the latent block and the encoder (bucket 1).
+// part 0: decoder convolutions, bn8, fc8's weight gradient;  part 1: the fully connected layers and the latent
+// block;  part 2: the encoder convolutions.  Each completes the gradient bucket of the same number.
 extern "C" int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s) {
-  if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr || part < 0 || part > 1) return AVA_EINVAL;
-  return part == 0 ? backward_part0(m, x, B, to_stream(s)) : backward_part1(m, x, B, to_stream(s));
+  if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr || part < 0 || part >= AVA_BACKWARD_PARTS)
+    return AVA_EINVAL;
+  if (part == 0) return backward_part0(m, x, B, to_stream(s));
+  return part == 1 ? backward_part1(m, x, B, to_stream(s)) : backward_part2(m, x, B, to_stream(s));
 }
 
 static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st) {
@@ -660,8 +669,6 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st) {
 
 static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   const int z = m->z;
-  float* gcur = m->gA;
-  float* gnext = m->gB;
   mark(m, -1, st);
   // ---- fully connected layers.  dX = (dY W) masked by the producer's ReLU runs as a chain; the weight
   // gradients dW = dY^T X (+ db = column sums) only need buffers that stay valid, so the two big ones are
@@ -693,9 +700,14 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
       {m->dlogd, 0, m->h3 + 128, 192, nullptr, GG(m, FC43), 0, nullptr, GG(m, FC43 + 1), z, 64, B, ACT_NONE},
       {m->dh3, 0, m->h2, 0, nullptr, GG(m, FC31), 0, nullptr, GG(m, FC31 + 1), 192, 256, B, ACT_NONE},
       {m->dh2, 0, m->h1, 0, nullptr, GG(m, FC2), 0, nullptr, GG(m, FC2 + 1), 256, 1024, B, ACT_NONE}};
-  TRY(gemm_group(m, dws, 8, 0, 0, st));
+  return gemm_group(m, dws, 8, 0, 0, st);
+}
+
+static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st) {
   // ---- encoder convolutions ----
-  gcur = m->gA; gnext = m->gB;
+  float* gcur = m->gA;
+  float* gnext = m->gB;
+  mark(m, -1, st);
   TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, st));             // dU_7 (ReLU of conv7)
   mark(m, CAT_LAYOUT, st);
   TRY(conv_layer_backward(m, 6, x, gcur, nullptr, nullptr, nullptr, nullptr, PRO_ID, gnext, B, st));

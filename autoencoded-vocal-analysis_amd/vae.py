@@ -286,10 +286,10 @@ class VAE(nn.Module):
         if not _dist.active():
             _lib.check(lib.ava_backward(self._handle, x.data_ptr(), x.shape[0], _lib.stream()), "ava_backward")
             return
-        # data parallel: the decoder half of the gradient arena (fc8 + convT + bn8..14, ~half of the bytes) is
-        # all-reduced while the encoder half of backward is still running; the rest follows at the end
+        # data parallel: backward runs in parts; the gradient bucket a part completes (fc8 + decoder, then fc1..fc7,
+        # then the encoder) is all-reduced asynchronously while the next part is still running
         pending = []
-        for part in (0, 1):
+        for part in range(lib.ava_backward_num_parts()):
             _lib.check(lib.ava_backward_part(self._handle, x.data_ptr(), x.shape[0], part, _lib.stream()),
                        "ava_backward_part")
             off, cnt = ctypes.c_int64(), ctypes.c_int64()

@@ -68,9 +68,11 @@ int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const f
 /* loss.backward() (vae.py:352) for the forward that just ran: fills the gradient arena
  * (overwrites: the reference zero_grad()s before every step, vae.py:348). */
 int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);
-/* The same backward in two halves, so that a data-parallel caller can all-reduce the first half's gradients
- * (bucket 0: fc8, convt1..7, bn8..14 -- contiguous tail of the arena) while the second half still runs.
- * ava_grad_bucket returns the arena range (floats) that is complete after part `bucket`. */
+/* The same backward in ava_backward_num_parts() (= 3) consecutive parts, so that a data-parallel caller can
+ * all-reduce each part's gradients while the next part runs.  Part p completes gradient bucket p, a contiguous
+ * range of the arena returned by ava_grad_bucket (floats): bucket 0 = fc8, convt1..7, bn8..14 (tail of the arena),
+ * bucket 1 = fc1..fc7, bucket 2 = conv1..7, bn1..7 (head).  The buckets tile the arena. */
+int ava_backward_num_parts(void);
 int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s);
 int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count);
 /* torch.optim.Adam.step (torch/optim/adam.py:414-547), one fused pass over the four arenas.

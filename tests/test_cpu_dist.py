@@ -33,9 +33,11 @@ def _worker(rank, world, port, q):
         flat = torch.zeros(total)
         for s in layout.param_specs(z):
             flat[offs[s.name]:offs[s.name] + s.numel] = P[s.name].grad.reshape(-1)
-        # two buckets, asynchronously, exactly like VAE._backward_device does under data parallelism
-        split = offs["fc8.weight"]
-        pending = [adist.allreduce_gradients_async(flat[split:]), adist.allreduce_gradients_async(flat[:split])]
+        # three buckets (tail, middle, head of the arena), asynchronously, exactly like VAE._backward_device does
+        # under data parallelism (ava_grad_bucket: fc8 + decoder, fc1..fc7, encoder)
+        s8, s1 = offs["fc8.weight"], offs["fc1.weight"]
+        pending = [adist.allreduce_gradients_async(flat[s8:]), adist.allreduce_gradients_async(flat[s1:s8]),
+                   adist.allreduce_gradients_async(flat[:s1])]
         adist.wait_all(pending)                               # SUM, not mean (the loss is a batch sum)
         norms = {s.name: float(flat[offs[s.name]:offs[s.name] + s.numel].double().norm()) for s in layout.param_specs(z)}
         gl = adist.global_loss(out["loss"].detach().double(), z, 10.0, 1)

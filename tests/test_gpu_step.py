@@ -187,31 +187,37 @@ def test_two_shard_data_parallel_equivalence():
         assert abs(gn - float(G["gradnorm." + s.name])) < (FLIP_TOL if sens else 3e-3) * ref_scale, s.name   # shard 1 has a ReLU flip upstream of conv2 (4e-4 in the oracle)
 
 
-def test_backward_in_two_parts_equals_whole():
-    """ava_backward_part(0) + ava_backward_part(1) (the data-parallel overlap path) == ava_backward, bit for bit,
-    and the two gradient buckets tile the arena."""
+def test_backward_in_parts_equals_whole():
+    """ava_backward_part(0..n-1) (the data-parallel overlap path) == ava_backward, bit for bit, and the gradient
+    buckets tile the arena in the order tail (fc8 + decoder), middle (fc1..fc7), head (encoder)."""
     import ctypes
     from ava_amd import _lib
     lib = _lib.load()
     B, z = 8, 32
     x = torch.from_numpy(syn.spectrograms(B)).cuda()
+    nparts = lib.ava_backward_num_parts()
+    assert nparts == 3
     grads = []
     for split in (False, True):
         model = build_model(z)
         fixed_noise(model, B, z)
         model._forward_device(x, need_grad=True)
         if split:
-            for part in (0, 1):
+            for part in range(nparts):
                 _lib.check(lib.ava_backward_part(model._handle, x.data_ptr(), B, part, _lib.stream()), "part")
         else:
             _lib.check(lib.ava_backward(model._handle, x.data_ptr(), B, _lib.stream()), "whole")
         grads.append(model._grads.clone())
     assert torch.equal(grads[0], grads[1])
-    o0, c0, o1, c1 = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    lib.ava_grad_bucket(model._handle, 0, ctypes.byref(o0), ctypes.byref(c0))
-    lib.ava_grad_bucket(model._handle, 1, ctypes.byref(o1), ctypes.byref(c1))
-    assert o1.value == 0 and o0.value == c1.value and o0.value + c0.value == model._grads.numel()
-    assert o0.value == model._arena_views["fc8.weight"][0]
+    rng = []
+    for b in range(nparts):
+        o, c = ctypes.c_int64(), ctypes.c_int64()
+        assert lib.ava_grad_bucket(model._handle, b, ctypes.byref(o), ctypes.byref(c)) == 0
+        rng.append((o.value, c.value))
+    assert rng[2][0] == 0 and rng[2][1] == rng[1][0] and rng[1][0] + rng[1][1] == rng[0][0]
+    assert rng[0][0] + rng[0][1] == model._grads.numel()
+    assert rng[0][0] == model._arena_views["fc8.weight"][0] and rng[1][0] == model._arena_views["fc1.weight"][0]
+    assert lib.ava_grad_bucket(model._handle, nparts, ctypes.byref(o), ctypes.byref(c)) != 0
 
 
 def test_harness_train_loop_checkpoint_golden(tmp_path):

@@ -159,3 +159,72 @@ struct WClass {
   }
 };
 
+
+// ---- the same accumulators with the M tiles dealt out to the four waves ---------------------------------------
+// Unit u = (tiles of the classes before CLS) + tile index belongs to wave u % 4.  A wave then keeps a quarter of the
+// accumulators (14 tiles x 2 x 4 = 112 VGPRs -> 32 for the 24-channel layers), sweeps ALL pixels of a tile instead
+// of a quarter of them, and its rows of the partial result are final: no cross-wave reduction at the end.
+template <int MODE> __host__ __device__ constexpr int wsplit_base(int cls, int cin) {
+  int b = 0;
+  for (int c = 0; c < cls; ++c) b += (n_taps<MODE>(c) * cin + 15) / 16;
+  return b;
+}
+template <int CIN, int COUT, int MODE, int CLS, int IC>
+struct WSplit {
+  static constexpr int KROWS = n_taps<MODE>(CLS) * CIN;
+  static constexpr int MTK = (KROWS + 15) / 16;
+  static constexpr int NT = (COUT + 15) / 16;
+  static constexpr int BASE = wsplit_base<MODE>(CLS, CIN);
+  static constexpr int MTL = (MTK + 3) / 4;          // most tiles any wave owns
+  int first;                                         // first owned tile; the wave owns first, first+4, ...
+  int offA[MTL];
+  f32x4 acc[MTL][NT];
+
+  __device__ __forceinline__ void init(int lane, int wave) {
+    const int m = lane & 15;
+    first = (wave - BASE % 4 + 4) & 3;
+#pragma unroll
+    for (int i = 0; i < MTL; ++i) {
+      const int mm = 16 * (first + 4 * i) + m;
+      int tapg, ci, dr, dc;
+      WClass<CIN, COUT, MODE, CLS, IC>::tap_of_row(mm < KROWS ? mm : 0, tapg, ci, dr, dc);
+      offA[i] = (dr * IC + dc) * CIN + ci;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __device__ __forceinline__ bool owns_any() const { return first < MTK; }
+
+  __device__ __forceinline__ void step(const float* __restrict__ xa, const float (&bf)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MTL; ++i)
+      if (first + 4 * i < MTK) {                      // wave-uniform
+        const float af = xa[offA[i]];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[nt], acc[i][nt], 0, 0, 0);
+      }
+  }
+
+  // this wave's rows of the partial result, gather layout, plain stores (rows are disjoint between waves)
+  __device__ __forceinline__ void flush(float* __restrict__ wacc, int lane) const {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MTL; ++i)
+      if (first + 4 * i < MTK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mm = 16 * (first + 4 * i) + 4 * kg + r;
+          if (mm < KROWS) {
+            int tapg, ci, dr, dc;
+            WClass<CIN, COUT, MODE, CLS, IC>::tap_of_row(mm, tapg, ci, dr, dc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int co = 16 * nt + n;
+              if (co < COUT) wacc[(tapg * CIN + ci) * COUT + co] = acc[i][nt][r];
+            }
+          }
+        }
+      }
+  }
+};

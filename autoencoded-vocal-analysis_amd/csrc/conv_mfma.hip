@@ -405,15 +405,148 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const WgradArgs
 }
 
 template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArgs a) {
+  using G = Geom<MODE, TW, TH>;
+  constexpr int IR = G::IR, IC = G::IC;
+  constexpr int NT = (COUT + 15) / 16;
+  constexpr int NCLS = n_classes<MODE>();
+  constexpr int NW = 9 * CIN * COUT;
+  extern __shared__ __align__(16) float smem[];
+  float* xt = smem;                               // [IR*IC*CIN]
+  float* dyt = xt + IR * IC * CIN;                // [TH*TW*COUT] (+16 pad: padded cout columns read past the end)
+  float* cx = dyt + TH * TW * COUT + 16;          // [3][32]
+  float* cd = cx + 96;                            // [3][32]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = lane & 15, kg = lane >> 4;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
+    cx[t] = (sx != nullptr && c < CIN) ? sx[c] : 0.f;
+    cd[t] = (sd != nullptr && c < COUT) ? sd[c] : 0.f;
+  }
+  if (t < 16) dyt[TH * TW * COUT + t] = 0.f;
+
+  WSplit<CIN, COUT, MODE, 0, IC> w0;
+  WSplit<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC> w1;
+  WSplit<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC> w2;
+  WSplit<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC> w3;
+  w0.init(lane, wave);
+  if (NCLS > 1) { w1.init(lane, wave); w2.init(lane, wave); w3.init(lane, wave); }
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
+    b = tl / (a.tiles_y * a.tiles_x);
+    const int rem = tl - b * (a.tiles_y * a.tiles_x);
+    oy0 = (rem / a.tiles_x) * TH;
+    ox0 = (rem % a.tiles_x) * TW;
+    if (MODE == MODE_S1) { gy0 = oy0 - 1; gx0 = ox0 - 1; }
+    else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
+    else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
+  };
+  TileStager<CIN, PRO_BN, IR, IC> sx;
+  TileStager<COUT, DYPRO, TH, TW> sd;
+  sx.init();
+  sd.init();
+  TileWalk walk(a.ntiles);
+  if (walk.valid()) {
+    int b, oy0, ox0, gy0, gx0;
+    origin(walk.cur, b, oy0, ox0, gy0, gx0);
+    sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy0, gx0);
+    sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, oy0, ox0);
+  }
+  for (; walk.valid(); walk.advance()) {
+    __syncthreads();
+    sx.store(xt, cx);
+    sd.store(dyt, cd);
+    __syncthreads();
+    if (walk.has_next()) {
+      int b, oy0, ox0, gy0, gx0;
+      origin(walk.next(), b, oy0, ox0, gy0, gx0);
+      sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy0, gx0);
+      sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, oy0, ox0);
+    }
+
+    if (MODE == MODE_UP) {
+      // every wave sweeps all TH/2 x-space rows; per class 16 columns c = 4*s + kg
+#pragma unroll 1
+      for (int r = 0; r < TH / 2; ++r) {
+        const bool mine = (r & 3) == wave;            // bias gradient: each dU pixel is counted by one wave
+#pragma unroll 1
+        for (int s = 0; s < TW / 8; ++s) {
+          const int c = 4 * s + kg;
+          const float* xa = xt + (r * IC + c) * CIN;
+#pragma unroll
+          for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            const float* bp = dyt + ((2 * r + py) * TW + 2 * c + px) * COUT + n;
+            float bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (mine && 16 * nt + n < COUT) ? bf[nt] : 0.f; }
+            if (cls == 0) w0.step(xa, bf);
+            else if (cls == 1) w1.step(xa, bf);
+            else if (cls == 2) w2.step(xa, bf);
+            else w3.step(xa, bf);
+          }
+        }
+      }
+    } else {
+      constexpr int S = MODE == MODE_S1 ? 1 : 2;
+#pragma unroll 1
+      for (int ty = 0; ty < TH; ++ty) {
+        const bool mine = (ty & 3) == wave;
+#pragma unroll 1
+        for (int s = 0; s < TW / 4; ++s) {
+          const int x = 4 * s + kg;
+          const float* bp = dyt + (ty * TW + x) * COUT + n;
+          float bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (mine && 16 * nt + n < COUT) ? bf[nt] : 0.f; }
+          w0.step(xt + ((S * ty) * IC + S * x) * CIN, bf);
+        }
+      }
+    }
+  }
+
+  // ---- every wave's rows are final: gather them in LDS, add the bias sums of the four waves, one partial row ----
+  __syncthreads();
+  float* wacc = smem;                             // [NW + 4*COUT], aliases the tiles (all reads are done)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] += __shfl_xor(bsum[nt], 16, 64);
+    bsum[nt] += __shfl_xor(bsum[nt], 32, 64);
+  }
+  w0.flush(wacc, lane);
+  if (NCLS > 1) { w1.flush(wacc, lane); w2.flush(wacc, lane); w3.flush(wacc, lane); }
+  if (kg == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = 16 * nt + n;
+      if (co < COUT) wacc[NW + wave * COUT + co] = bsum[nt];
+    }
+  }
+  __syncthreads();
+  float* prow = a.partials + (size_t)blockIdx.x * (NW + COUT);
+  for (int e = t; e < NW; e += 256) prow[e] = wacc[e];
+  if (t < COUT) prow[NW + t] = (wacc[NW + t] + wacc[NW + COUT + t]) + (wacc[NW + 2 * COUT + t] + wacc[NW + 3 * COUT + t]);
+}
+
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
 static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
+  // layers with many (tap, cin) rows deal the M tiles out to the waves (fewer registers, no cross-wave reduction)
+  constexpr bool SPLIT = CIN >= 24 && COUT > 16;   // measured: 24->24, 24->32, 32->24 gain 10-55 %, 16-channel sides lose
+  const auto kernel = SPLIT ? &conv3x3_wgrad_split_kernel<CIN, COUT, MODE, DYPRO, TW, TH>
+                            : &conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>;
   const size_t tiles_f = (size_t)G::IR * G::IC * CIN + TH * TW * COUT + 16 + 192;
-  const size_t red_f = (size_t)9 * CIN * COUT + COUT;
+  const size_t red_f = (size_t)9 * CIN * COUT + 4 * COUT;
   const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
   }
@@ -422,10 +555,11 @@ static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid > b.ntiles) return AVA_EINVAL;
-  static const int resident = ava_resident_grid(&conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>, lds);
+  static const int resident = ava_resident_grid(kernel, lds);
   if (grid > resident) grid = resident;          // one resident wave of workgroups = partial rows written
+  { const char* e = getenv("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (a.partials == nullptr) return grid;        // row-count query (ava_conv_wgrad_rows)
-  hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>), dim3(grid), dim3(256), lds, st, b);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -41,7 +41,7 @@ for name, cin, cout, mode, hi, tr in LAYERS:
     def fused(i):
         k = i % NBUF
         return lib.ava_conv3x3_bwd_fused(p(xs[k]), p(coef[0]), p(coef[1]), p(gs[k]), p(ys[k]), p(coef[0]), p(coef[1]), p(coef[2]),
-                                         p(G), p(dxs[k]), p(coef[1]), p(coef[2]), p(bnp), p(wparts), B, hi, hi, cin, cout, mode,
+                                         p(G), p(dxs[k]) if cin > 1 else None, p(coef[1]), p(coef[2]), p(bnp), p(wparts), B, hi, hi, cin, cout, mode,
                                          PRO_BWD, stream())
     def bwd(i):
         k = i % NBUF

@@ -419,12 +419,15 @@ static int conv_geometry(int B, int Ho, int Wo, int* tiles_y, int* tiles_x) {
   return B * (*tiles_y) * (*tiles_x);
 }
 
+// rows of the per-workgroup partial statistics buffer: one per 128 output pixels, at most 1024 (the matrix-core
+// kernels launch one resident wave of workgroups, which can be up to twice the number of 256-pixel tiles for the
+// 16 x 16 layers; rows of workgroups that are not launched are zero-filled)
 extern "C" int ava_conv_grid(int B, int Ho, int Wo, int mode) {
   (void)mode;
   int ty, tx;
   const int nt = conv_geometry(B, Ho, Wo, &ty, &tx);
   if (nt < 0) return AVA_EINVAL;
-  return nt < 1024 ? nt : 1024;
+  return 2 * nt < 1024 ? 2 * nt : 1024;
 }
 extern "C" int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode) {
   (void)mode;
@@ -492,7 +495,7 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
   if (a.ntiles <= 0 || in == nullptr || G == nullptr) return AVA_EINVAL;
   if (epi != EPI_BWD && bias == nullptr) return AVA_EINVAL;
   if (pro == PRO_BWD && in2 == nullptr) return AVA_EINVAL;
-  const int grid = a.ntiles < 1024 ? a.ntiles : 1024;
+  const int grid = 2 * a.ntiles < 1024 ? 2 * a.ntiles : 1024;     // == ava_conv_grid
   a.part_rows = grid;
   const int tw = tile_w(a.Wo);
   hipStream_t st = to_stream(s);

@@ -30,16 +30,18 @@ template <int MODE> __host__ __device__ constexpr int tap_kx(int cls, int t) {
 }
 
 // per-lane, per-class constants: LDS offsets of the chunk reads and the A (weight) fragments
-template <int CIN, int COUT, int MODE, int CLS, int IC>
+// MTO > 0: the fragment covers only MTO cout tiles starting at tile `mtb` (init argument) -- used when the cout tiles
+// of a layer are dealt out to different waves.
+template <int CIN, int COUT, int MODE, int CLS, int IC, int MTO = 0>
 struct ClassFrag {
   static constexpr int KTOT = n_taps<MODE>(CLS) * CIN;
   static constexpr int NCH = (KTOT + 15) / 16;
-  static constexpr int MT = (COUT + 15) / 16;
+  static constexpr int MT = MTO > 0 ? MTO : (COUT + 15) / 16;
   int off[NCH];
   float w[NCH][4][MT];
 
   // lane_base: LDS offset (floats) of this lane's pixel inside a 16-pixel group (n * CIN * stride)
-  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base) {
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base, int mtb = 0) {
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -60,7 +62,7 @@ struct ClassFrag {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const int co = 16 * mt + m;
+          const int co = 16 * (mtb + mt) + m;
           w[c][j][mt] = (valid && co < COUT) ? G[((ky * 3 + kx) * CIN + ci + j) * COUT + co] : 0.f;
         }
     }

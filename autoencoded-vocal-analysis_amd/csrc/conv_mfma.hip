@@ -15,32 +15,38 @@
 #include <stdlib.h>
 #include "conv_mfma.h"
 
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
+// MSPLIT (layers with two cout tiles): waves 0,2 compute cout tile 0 and waves 1,3 tile 1, each for half of the pixel
+// groups -- half the weight registers per wave (112 -> 56 for 24 -> 24 channels), so two workgroups fit on a CU.
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT>
+__global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(const ConvArgs a) {
   using G = Geom<MODE, TW, TH>;
   constexpr int IR = G::IR, IC = G::IC;
-  constexpr int MT = (COUT + 15) / 16;
+  constexpr int MTA = (COUT + 15) / 16;             // cout tiles of the layer
+  constexpr int MT = MSPLIT ? 1 : MTA;              // cout tiles of this wave
+  static_assert(!MSPLIT || MTA == 2, "MSPLIT deals exactly two cout tiles to the wave pairs");
   constexpr int NCLS = n_classes<MODE>();
   extern __shared__ __align__(16) float smem[];
   float* tile = smem;                       // [IR*IC*CIN]
   float* coef = smem + IR * IC * CIN;       // [3][32]
-  float* red = coef + 96;                   // [4][2*16*MT]
+  float* red = coef + 96;                   // [4][2*16*MTA]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = lane & 15, kg = lane >> 4;
+  const int mtb = MSPLIT ? (wave & 1) : 0;  // first cout tile of this wave
+  const int wp = wave >> 1;                 // MSPLIT: which half of the pixel groups
   if (t < 96) {
     const int which = t >> 5, c = t & 31;
     const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
     coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
   }
 
-  ClassFrag<CIN, COUT, MODE, 0, IC> f0;
-  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC> f1;
-  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC> f2;
-  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC> f3;
+  ClassFrag<CIN, COUT, MODE, 0, IC, MT> f0;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT> f1;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT> f2;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT> f3;
   constexpr int SP = MODE == MODE_DOWN ? 2 : 1;            // input pixels per output pixel along x
-  if (!(a.dbg & 8)) f0.init(a.G, lane, SP * n * CIN);
-  if (NCLS > 1) { f1.init(a.G, lane, n * CIN); f2.init(a.G, lane, n * CIN); f3.init(a.G, lane, n * CIN); }
+  if (!(a.dbg & 8)) f0.init(a.G, lane, SP * n * CIN, mtb);
+  if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
   // output offset (floats) of this lane inside a 16-pixel group: pixel n (every 2nd pixel for UP), channels 4kg..
   const int lane_out = (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
 
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = 16 * mt + 4 * kg + r;
+      const int co = 16 * (mtb + mt) + 4 * kg + r;
       bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
       emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
       einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
@@ -71,8 +77,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
   constexpr int GROUPS = (MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16);
-  constexpr int GPW = GROUPS / 4;           // groups per wave
-  static_assert(GROUPS % 4 == 0, "tile must give every wave the same number of pixel groups");
+  constexpr int GPW = MSPLIT ? GROUPS / 2 : GROUPS / 4;     // groups per wave
+  static_assert(GROUPS % 4 == 0 && (!MSPLIT || MODE != MODE_UP || GROUPS % 8 == 0),
+                "tile must give every wave the same number of pixel groups");
+  // gi-th group of this wave.  UP pattern: the parity class (g & 3) must stay a compile-time function of gi.
+  auto group_of = [&](int gi) -> int {
+    if (!MSPLIT) return wave * GPW + gi;
+    if (MODE == MODE_UP) return 8 * (gi >> 2) + 4 * wp + (gi & 3);
+    return wp + 2 * gi;
+  };
   // scalar offset (floats) of pixel group g's first pixel relative to the tile's first output pixel
   //   S1/DOWN: group g = (row g / GPR, 16 columns from 16*(g % GPR));  UP: g = (row pair g >> 2, parity class g & 3)
   auto group_out = [&](int g) -> int {
@@ -87,9 +100,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int cb = 16 * mt + 4 * kg;
+        const int cb = 16 * (mtb + mt) + 4 * kg;
         // lanes whose 4-channel slot lies beyond COUT (COUT = 8 or 24) re-read slot 0: stays in bounds
-        exn[gi * MT + mt] = ava_load_f4_async(xb + group_out(wave * GPW + gi) + (cb < COUT ? lane_out + 16 * mt : lane_out - 4 * kg));
+        exn[gi * MT + mt] = ava_load_f4_async(xb + group_out(group_of(gi)) + (cb < COUT ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
       }
   };
   TileStager<CIN, PRO, IR, IC> stg;
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {   // fully unrolled: hipcc drains vmcnt(0) in front of a loop that stores
-      const int g = wave * GPW + gi;
+      const int g = group_of(gi);
       f32x4 acc[2][MT];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (a.dbg & 1) {
       } else if (MODE == MODE_UP) {
-        const int cls = g & 3, r = g >> 2;
+        const int cls = gi & 3, r = g >> 2;       // == g & 3 (both group mappings keep the class in the low bits of gi)
         const float* px = tile + r * IC * CIN;
         if (cls == 0) f0.run(px, acc);
         else if (cls == 1) f1.run(px, acc);
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
       const int gout = group_out(g) + lane_out;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int cb = 16 * mt + 4 * kg;
+        const int cb = 16 * (mtb + mt) + 4 * kg;
         if (cb < COUT) {
           f32x4 v = acc[0][mt] + acc[1][mt];
           if (EPI == EPI_FWD) {
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
             }
           }
           if (obase != nullptr && !(a.dbg & 4))
-            *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -180,6 +193,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
   if (a.dbg & 16) return;
   // ---- per-workgroup partial statistics: reduce over the 16 pixel lanes, then over the 4 waves ----
   __syncthreads();
+  if (MSPLIT) {                              // a wave only fills its own cout tile: the other slots must read as 0
+    if (t < 4 * 32 * MTA / 2) { red[t] = 0.f; red[t + 4 * 32 * MTA / 2] = 0.f; }
+    __syncthreads();
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -188,17 +205,17 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
       if (n == 0) {
-        const int co = 16 * mt + 4 * kg + r;
-        red[wave * 32 * MT + co] = v1;
-        red[wave * 32 * MT + 16 * MT + co] = v2;
+        const int co = 16 * (mtb + mt) + 4 * kg + r;
+        red[wave * 32 * MTA + co] = v1;
+        red[wave * 32 * MTA + 16 * MTA + co] = v2;
       }
     }
   __syncthreads();
   if (t < 2 * COUT && a.partials != nullptr) {
     const int which = t / COUT, co = t - which * COUT;
-    const int idx = which * 16 * MT + co;
+    const int idx = which * 16 * MTA + co;
     bn_partial_store(a.bn, a.partials + (size_t)blockIdx.x * 2 * COUT + t,
-                     (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]));
+                     (red[idx] + red[32 * MTA + idx]) + (red[64 * MTA + idx] + red[96 * MTA + idx]));
     for (int r = gridDim.x + blockIdx.x; r < a.part_rows; r += gridDim.x)       // rows of workgroups not launched
       a.partials[(size_t)r * 2 * COUT + t] = 0.f;
   }
@@ -210,10 +227,11 @@ template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
 static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   constexpr int MT = (COUT + 15) / 16;
+  constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // the register-bound shapes
   const size_t lds = (size_t)(G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
@@ -222,13 +240,13 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   b.tiles_y = a.Ho / TH;
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
-  if (grid > b.ntiles) return AVA_EINVAL;
   // one resident wave of workgroups; the partial rows of the workgroups not launched are zero-filled by the kernel
-  static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>, lds);
+  static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>, lds);
   b.part_rows = grid;
+  if (grid > b.ntiles) grid = b.ntiles;
   if (grid > resident && a.bn.counter == nullptr) grid = resident;
   { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH>), dim3(grid), dim3(256), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
@@ -252,9 +270,9 @@ int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, i
   AVA_MFMA_CASE(8, 16, MODE_S1, 32, 8)
   AVA_MFMA_CASE(16, 16, MODE_DOWN, 32, 4)
   AVA_MFMA_CASE(16, 24, MODE_S1, 32, 8)
-  AVA_MFMA_CASE(24, 24, MODE_DOWN, 16, 8)
-  AVA_MFMA_CASE(24, 32, MODE_S1, 16, 16)
-  AVA_MFMA_CASE(32, 24, MODE_S1, 16, 16)
+  AVA_MFMA_CASE(24, 24, MODE_DOWN, 16, 4)
+  AVA_MFMA_CASE(24, 32, MODE_S1, 16, 8)
+  AVA_MFMA_CASE(32, 24, MODE_S1, 16, 8)
   AVA_MFMA_CASE(24, 24, MODE_UP, 32, 8)
   AVA_MFMA_CASE(24, 16, MODE_S1, 32, 8)
   AVA_MFMA_CASE(16, 16, MODE_UP, 32, 8)

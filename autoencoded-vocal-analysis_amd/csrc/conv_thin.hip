@@ -33,6 +33,13 @@ __device__ __forceinline__ void thin_block_reduce(const float (&v)[N], float* ld
     out[threadIdx.x] = (lds[threadIdx.x] + lds[N + threadIdx.x]) + (lds[2 * N + threadIdx.x] + lds[3 * N + threadIdx.x]);
 }
 
+// partial rows of workgroups that were not launched (grid < part_rows) are zero-filled, N floats per row
+template <int N>
+__device__ __forceinline__ void thin_zero_rows(float* __restrict__ partials, int part_rows) {
+  if (partials == nullptr || threadIdx.x >= N) return;
+  for (int r = gridDim.x + blockIdx.x; r < part_rows; r += gridDim.x) partials[(size_t)r * N + threadIdx.x] = 0.f;
+}
+
 // The 72 wave-uniform weights of a thin layer, fetched ONCE into scalar registers.  Left as G[...] reads inside
 // the tile loop they cannot be hoisted (hipcc must assume the output stores alias them) and turn into 18
 // vector loads per tile and thread plus 72 VGPRs.
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
 #pragma unroll
   for (int co = 0; co < 8; ++co) { sv[co] = s1[co]; sv[8 + co] = s2[co]; }
   thin_block_reduce<16>(sv, red, a.partials != nullptr ? a.partials + (size_t)blockIdx.x * 16 : nullptr);
+  thin_zero_rows<16>(a.partials, a.part_rows);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
   }
   const float sv[2] = {s1, s2};
   thin_block_reduce<2>(sv, red, a.partials != nullptr ? a.partials + (size_t)blockIdx.x * 2 : nullptr);
+  thin_zero_rows<2>(a.partials, a.part_rows);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -709,6 +718,9 @@ int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, 
   if (a0.bn.counter != nullptr) return AVA_EINVAL;       // fused BatchNorm finalisation lives in the generic kernels
   ConvArgs a = a0;
   a.ntiles = a.B * (a.Ho / THIN_TH);                     // workgroups beyond ntiles still write their (zero) partial row
+  a.part_rows = grid;                                    // rows the caller sized; one resident wave is launched
+  if (Cin == 8 && grid > 512) grid = 512;                // 8 -> 1: two workgroups per CU are resident (measured -3.5 us)
+  { const char* e = getenv("AVA_THIN_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (Cin == 1 && Cout == 8) {
     if (pro == PRO_BN && epi == EPI_FWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BN, EPI_FWD>), dim3(grid), dim3(256), 0, st, a);
     else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_BWD>), dim3(grid), dim3(256), 0, st, a);

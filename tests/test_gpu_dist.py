@@ -1,0 +1,79 @@
+"""The data-parallel path of VAE on the GPU with TWO processes: backward in parts, every gradient bucket all-reduced
+(SUM) asynchronously as its part completes, global loss, Adam on the reduced gradient.  The gpurun boxes have one
+GPU, so both ranks share cuda:0 and the collective runs over gloo (which stages device tensors through the host);
+RCCL itself is exercised by `bench.py --gpus N` on a multi-GPU node.  Pinned by the reference-generated two-shard
+golden (tests/golden/ddp2.npz): each shard run separately from identical weights, gradients summed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    from ava_amd import dist as adist, synthetic as syn, layout
+    from gpu_util import build_model
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, B = 32, 8
+        x = syn.spectrograms(B * world)
+        ew, ed = syn.noise(B * world, z)
+        sl = slice(B * rank, B * rank + B)
+        model = build_model(z)
+        adist.broadcast_parameters(model)
+        model.noise_source = lambda b, zz: (ew[sl], ed[sl])
+        model.optimizer.zero_grad()
+        loss = model.forward(torch.from_numpy(x[sl]).cuda())
+        loss.backward()                                   # VAE._backward_device: parts + asynchronous buckets
+        torch.cuda.synchronize()
+        offs, total = layout.arena_offsets(z)
+        g = model._grads.cpu().double()
+        norms = {s.name: float(g[offs[s.name]:offs[s.name] + s.numel].norm()) for s in layout.param_specs(z)}
+        gl = adist.global_loss(loss.detach().double(), z, 10.0, 1)
+        before = model.fc8.weight.detach().clone()
+        model.optimizer.step()
+        torch.cuda.synchronize()
+        moved = float((model.fc8.weight.detach() - before).abs().max())
+        q.put((rank, float(loss.item()), norms, gl, moved, float(model._params.double().sum().item())))
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_step_on_gpu():
+    G = load_golden("ddp2.npz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort()
+    from ava_amd import dist as adist
+    c = adist.per_call_constants(32, 10.0)
+    for rank, loss, norms, gl, moved, psum in res:
+        assert abs(loss - float(G["shard%d.loss" % rank])) / abs(loss) < 1e-5
+        want = float(G["shard0.loss"]) + float(G["shard1.loss"]) - c
+        assert abs(gl - want) / abs(want) < 1e-5
+        for name, v in norms.items():
+            sens = name.split(".")[0] in ("conv1", "bn1")
+            ref = float(G["gradnorm." + name])
+            scale = max(ref, float(G["gradnorm.conv1.bias"]) if sens else 0.0)
+            assert abs(v - ref) < (2e-2 if sens else 1e-3) * scale, name
+        assert 0.0 < moved < 2e-3                          # Adam's first step moves every weight by ~lr
+    assert res[0][2] == res[1][2] and res[0][5] == res[1][5]   # identical reduced gradients and updated parameters

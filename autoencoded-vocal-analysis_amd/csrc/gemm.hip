@@ -303,6 +303,82 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small products (the fc2 .. fc7 chain and its dX chain: <= 0.13 GFLOP each, launch- and latency-bound).  One
+// workgroup per 16x16 output tile, no LDS staging and no split-K slabs: the four waves take every fourth 16-wide
+// K chunk, read their operand fragments straight from global memory (the matrices are L2 resident; lane (i, kg)
+// loads the 4 consecutive k of chunk position 4 kg, one value per MFMA -- the same K permutation on both operands),
+// and are summed through LDS in wave order (deterministic).  A is k-major; B is k-major ([N,K], forward) or
+// n-major ([K,N], dX = dY W).  v_mfma_f32_16x16x4_f32, exact fp32.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
+template <bool B_KMAJ>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g) {
+  __shared__ float red[3][64][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int am = min(m0 + i, g.M - 1);            // clamped row of A / column of B owned by this lane
+  const int bn = min(n0 + i, g.N - 1);
+  const float* __restrict__ arow = g.A + (size_t)am * g.lda;
+  const float* __restrict__ bcol = B_KMAJ ? g.B + (size_t)bn * g.ldb : g.B + bn;
+  const int nchunks = (g.K + 15) >> 4;
+  f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;                            // chunks in flight per wave
+  for (int c0 = wave; c0 < nchunks; c0 += 4 * U) {
+    f32x4g a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = 16 * (c0 + 4 * u) + 4 * kg;   // K % 4 == 0: a quad is inside or outside as a whole
+      const bool ok = k < g.K;
+      const int kc = ok ? k : 0;
+      a[u] = *reinterpret_cast<const f32x4g*>(arow + kc);
+      if (B_KMAJ) {
+        b[u] = *reinterpret_cast<const f32x4g*>(bcol + kc);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[u][j] = bcol[(size_t)(kc + j) * g.ldb];
+      }
+      if (!ok) { a[u] = (f32x4g){0.f, 0.f, 0.f, 0.f}; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][j], acc, 0, 0, 0);
+  }
+  // D[row = 4 kg + r][col = i] ; waves 1..3 hand their tile to wave 0, summed in wave order
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const int gn = n0 + i;
+  if (gn >= g.N) return;
+  const float bv = g.bias != nullptr ? g.bias[gn] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gm = m0 + 4 * kg + r;
+    if (gm < g.M) {
+      float v = ((acc[r] + red[0][lane][r]) + red[1][lane][r]) + red[2][lane][r];
+      v = apply_act(v + bv, g.act);
+      if (g.mask != nullptr && !(g.mask[(size_t)gm * g.ldc + gn] > 0.f)) v = 0.f;
+      g.C[(size_t)gm * g.ldc + gn] = v;
+    }
+  }
+}
+
+// products the skinny kernel takes: small output, A k-major, 16-byte alignable operands, no bias-gradient column sums
+static bool skinny_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
+  static const bool on = [] { const char* e = getenv("AVA_GEMM_SKINNY"); return e == nullptr || atoi(e) != 0; }();
+  if (!on || !a_kmajor || g.colsum != nullptr) return false;
+  if ((size_t)g.M * g.N > 262144 || g.K > 2048 || g.K % 4 != 0 || g.lda % 4 != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(g.A) & 15) != 0) return false;
+  if (b_kmajor && (g.ldb % 4 != 0 || (reinterpret_cast<uintptr_t>(g.B) & 15) != 0)) return false;
+  return true;
+}
+
 static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
   *bm = (M >= 128 && N >= 128) ? 128 : 64;
   // small outputs with a short K (fc2, fc3x, fc6, fc7 and their dX): 64x64 tiles give 4x the workgroups per split,
@@ -359,6 +435,14 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   g.vec_b = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (b_kmajor ? K % 4 == 0 && K >= 4 : N % 4 == 0 && N >= 4);
   const bool vec = g.vec_a && g.vec_b;
   hipStream_t st = to_stream(s);
+  if (skinny_ok(g, a_kmajor, b_kmajor)) {
+    g.C = C;
+    const dim3 sgrid(ceil_div(N, 16), ceil_div(M, 16));
+    if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true>), sgrid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<false>), sgrid, dim3(256), 0, st, g);
+    AVA_CHECK_LAUNCH();
+    return AVA_OK;
+  }
   dim3 grid(ceil_div(N, bm), ceil_div(M, bm), splits);
   static int bk32 = -1;
   if (bk32 < 0) { const char* e = getenv("AVA_GEMM_BK"); bk32 = (e && atoi(e) == 16) ? 0 : 1; }

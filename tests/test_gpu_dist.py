@@ -74,6 +74,6 @@ def test_two_rank_step_on_gpu():
             sens = name.split(".")[0] in ("conv1", "bn1")
             ref = float(G["gradnorm." + name])
             scale = max(ref, float(G["gradnorm.conv1.bias"]) if sens else 0.0)
-            assert abs(v - ref) < (2e-2 if sens else 1e-3) * scale, name
+            assert abs(v - ref) < (2e-2 if sens else 2e-3) * scale, name     # ReLU-flip noise floor: test_gpu_step.GTOL
         assert 0.0 < moved < 2e-3                          # Adam's first step moves every weight by ~lr
     assert res[0][2] == res[1][2] and res[0][5] == res[1][5]   # identical reduced gradients and updated parameters

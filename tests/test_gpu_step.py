@@ -115,6 +115,31 @@ def test_three_steps_then_eval_matches_golden():
         assert rel(float(fresh.forward(x).item()), G["eval_fresh.loss"]) < 1e-5
 
 
+def test_six_step_trajectory_matches_oracle():
+    """Training dynamics: 6 Adam steps on three alternating batches (B = 16, z = 32), the loss of every step against
+    the CPU oracle run on the same inputs and noise.  Adam's first steps are sign-like (g / sqrt(g^2)), so rounding
+    noise in near-zero gradient entries becomes O(lr) parameter differences and the two fp32 trajectories separate
+    exponentially (measured: 1e-7, 2e-7, 2e-5, 5e-5, 2e-4, 6e-5 ... 1.5e-3 at step 12, tools/traj.py): steps 1-2 are
+    held to 1e-5, the rest to 1e-3."""
+    B, z, steps = 16, 32, 6
+    xs = [torch.from_numpy(syn.spectrograms(B, salt=77 + i)) for i in range(3)]
+    model = build_model(z)
+    ew, ed = fixed_noise(model, B, z)
+    P = O.to_params(syn.fixture_parameters(z), requires_grad=True)
+    running = O.fresh_running_stats()
+    opt = {"step": 0, "m": {}, "v": {}}
+    for step in range(steps):
+        x = xs[step % 3]
+        model.optimizer.zero_grad()
+        loss = model.forward(x)
+        loss.backward()
+        model.optimizer.step()
+        want, _, _ = O.train_step(P, x, torch.from_numpy(ew), torch.from_numpy(ed), running, opt)
+        assert rel(float(loss.item()), want) < (1e-5 if step < 2 else 1e-3), step
+    for i in range(1, 15):
+        assert rel(getattr(model, "bn%d" % i).running_mean.cpu(), running["bn%d.running_mean" % i]) < 1e-3
+
+
 @pytest.mark.parametrize("B", [1, 5, 37])
 def test_forward_backward_matches_oracle_odd_batches(B):
     """Ragged batch sizes (visualize uses 5, shotgun_movie batch 1: vae.py:503-510, shotgun_movie.py:116-120)."""

@@ -142,8 +142,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   constexpr int LDB_S = BN + (B_KMAJ ? 2 : 4);
   constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;      // 32x32 MFMA tiles per wave
-  __shared__ __align__(16) float As2[2][BK * LDA_S];
-  __shared__ __align__(16) float Bs2[2][BK * LDB_S];
+  // one LDS block: the two double-buffered operand tiles during the K loop, the C tile [BM][BN + 4] in the epilogue
+  constexpr int LDC_S = BN + 4;
+  constexpr int OPER_F = 2 * BK * LDA_S + 2 * BK * LDB_S, CT_F = BM * LDC_S;
+  __shared__ __align__(16) float smem_all[OPER_F > CT_F ? OPER_F : CT_F];
+  float (*As2)[BK * LDA_S] = reinterpret_cast<float (*)[BK * LDA_S]>(smem_all);
+  float (*Bs2)[BK * LDB_S] = reinterpret_cast<float (*)[BK * LDB_S]>(smem_all + 2 * BK * LDA_S);
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -219,32 +223,53 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     cur ^= 1;
   }
 
-  // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
-  float* Cout = g.C + (size_t)split * g.M * g.N;   // partial slab (splits > 1 only)
-  const bool fin = g.splits == 1;
+  // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators go through LDS
+  // so that the tile leaves as full rows of 16-byte stores (BN*4 contiguous bytes per 32 lanes) instead of 64 scalar
+  // stores per thread; the last K step's barrier has already retired every read of the operand buffers. ----
+  float* Ct = smem_all;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int gn = n0 + wn * WN + j * 32 + (lane & 31);
-      if (gn < g.N) {
-        const float bv = (fin && g.bias != nullptr) ? g.bias[gn] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (gm < g.M) {
-            float v = acc[i][j][r];
-            if (fin) {
-              v = apply_act(v + bv, g.act);
-              if (g.mask != nullptr && !(g.mask[(size_t)gm * g.ldc + gn] > 0.f)) v = 0.f;
-              g.C[(size_t)gm * g.ldc + gn] = v;
-            } else {
-              Cout[(size_t)gm * g.N + gn] = v;
-            }
-          }
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Ct[row * LDC_S + wn * WN + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  __syncthreads();
+  float* Cout = g.C + (size_t)split * g.M * g.N;   // partial slab (splits > 1 only)
+  const bool fin = g.splits == 1;
+  const int ldo = fin ? g.ldc : g.N;
+  float* __restrict__ obase = fin ? g.C : Cout;
+  constexpr int QPR = BN / 4;                       // float4 per tile row
+  const bool vec_out = (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(obase) & 15) == 0) && (n0 + BN <= g.N) &&
+                       (!fin || g.mask == nullptr || ((reinterpret_cast<uintptr_t>(g.mask) & 15) == 0));
+  for (int v = t; v < BM * QPR; v += 256) {
+    const int row = v / QPR, q = v - row * QPR;
+    const int gm = m0 + row, gn = n0 + 4 * q;
+    if (gm >= g.M) continue;
+    const float4 c4 = *reinterpret_cast<const float4*>(&Ct[row * LDC_S + 4 * q]);
+    float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+    if (fin) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (gn + e < g.N) {
+          float x = cv[e] + (g.bias != nullptr ? g.bias[gn + e] : 0.f);
+          x = apply_act(x, g.act);
+          if (g.mask != nullptr && !(g.mask[(size_t)gm * g.ldc + gn + e] > 0.f)) x = 0.f;
+          cv[e] = x;
         }
       }
     }
+    float* dst = obase + (size_t)gm * ldo + gn;
+    if (vec_out) {
+      *reinterpret_cast<float4*>(dst) = make_float4(cv[0], cv[1], cv[2], cv[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gn + e < g.N) dst[e] = cv[e];
+    }
+  }
   if (do_colsum && t < BM && m0 + t < g.M) {
     if (fin) g.colsum[m0 + t] = csum;
     else g.C[(size_t)g.splits * g.M * g.N + (size_t)split * g.M + m0 + t] = csum;   // partial, behind the slabs

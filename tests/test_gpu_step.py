@@ -137,7 +137,7 @@ def test_six_step_trajectory_matches_oracle():
         want, _, _ = O.train_step(P, x, torch.from_numpy(ew), torch.from_numpy(ed), running, opt)
         assert rel(float(loss.item()), want) < (1e-5 if step < 2 else 1e-3), step
     for i in range(1, 15):
-        assert rel(getattr(model, "bn%d" % i).running_mean.cpu(), running["bn%d.running_mean" % i]) < 1e-3
+        assert rel(getattr(model, "bn%d" % i).running_mean.cpu(), running["bn%d.running_mean" % i]) < 5e-3
 
 
 @pytest.mark.parametrize("B", [1, 5, 37])

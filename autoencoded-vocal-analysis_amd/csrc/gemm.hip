@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g) {
 static bool skinny_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
   static const bool on = [] { const char* e = getenv("AVA_GEMM_SKINNY"); return e == nullptr || atoi(e) != 0; }();
   if (!on || !a_kmajor || g.colsum != nullptr) return false;
-  if ((size_t)g.M * g.N > 262144 || g.K > 2048 || g.K % 4 != 0 || g.lda % 4 != 0) return false;
+  static const int kmax = [] { const char* e = getenv("AVA_GEMM_SKINNY_KMAX"); return e ? atoi(e) : 2048; }();
+  if ((size_t)g.M * g.N > 262144 || g.K > kmax || g.K % 4 != 0 || g.lda % 4 != 0) return false;
   if ((reinterpret_cast<uintptr_t>(g.A) & 15) != 0) return false;
   if (b_kmajor && (g.ldb % 4 != 0 || (reinterpret_cast<uintptr_t>(g.B) & 15) != 0)) return false;
   return true;

@@ -140,10 +140,12 @@ def test_six_step_trajectory_matches_oracle():
         assert rel(getattr(model, "bn%d" % i).running_mean.cpu(), running["bn%d.running_mean" % i]) < 5e-3
 
 
-@pytest.mark.parametrize("B", [1, 5, 37])
-def test_forward_backward_matches_oracle_odd_batches(B):
-    """Ragged batch sizes (visualize uses 5, shotgun_movie batch 1: vae.py:503-510, shotgun_movie.py:116-120)."""
-    z = 32
+@pytest.mark.parametrize("B,z", [(1, 32), (5, 32), (37, 32), (5, 8), (3, 30), (6, 100), (2, 128)],
+                         ids=["B1", "B5", "B37", "z8", "z30", "z100", "z128"])
+def test_forward_backward_matches_oracle_odd_batches(B, z):
+    """Ragged batch sizes (visualize uses 5, shotgun_movie batch 1: vae.py:503-510, shotgun_movie.py:116-120) and
+    latent sizes other than 32 / 64 (z_dim is a constructor argument, vae.py:80; 30 is not a multiple of 4, so the
+    fully connected products around the latent take the scalar-load GEMM path)."""
     model = build_model(z)
     ew, ed = fixed_noise(model, B, z, 11, 12)
     x = torch.from_numpy(syn.spectrograms(B, salt=77))

@@ -17,9 +17,8 @@
 // ---- statistics of a raw tensor x[n][C] (used for bn1, whose input has no producer kernel) --------
 template <int C>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t n,
-                                                       float* __restrict__ partials, const BnFuse fuse) {
+                                                       float* __restrict__ partials) {
   __shared__ float red[4][2 * C];
-  __shared__ double fuse_scratch[260];
   float s1[C], s2[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) s1[c] = s2[c] = 0.f;
@@ -52,9 +51,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
   __syncthreads();
   if (threadIdx.x < 2 * C)
-    bn_partial_store(fuse, partials + (size_t)blockIdx.x * 2 * C + threadIdx.x,
-                     (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
-  bn_fused_finalize(fuse, partials, gridDim.x, fuse_scratch);
+    partials[(size_t)blockIdx.x * 2 * C + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // column sums of partials[nparts][ncols] in fp64; result in sums[ncols] (shared memory, double).
@@ -166,11 +164,9 @@ __device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const
 
 // f8 [B][32*256] (c*256+p) -> out [B][256][32], plus per-channel {sum, sum^2} partials for bn8
 __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                 float* __restrict__ partials, int B,
-                                                                 const BnFuse fuse) {
+                                                                 float* __restrict__ partials, int B) {
   __shared__ float tile[32][QPIX + 1];
   __shared__ float red[8][64];
-  __shared__ double fuse_scratch[260];
   const int t = threadIdx.x;
   float s1 = 0.f, s2 = 0.f;                 // thread -> channel t&31, 8 threads per channel
   for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
@@ -193,9 +189,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k][t];
-    bn_partial_store(fuse, partials + (size_t)blockIdx.x * 64 + t, s);
+    partials[(size_t)blockIdx.x * 64 + t] = s;
   }
-  bn_fused_finalize(fuse, partials, gridDim.x, fuse_scratch);
 }
 
 // y7 [B][256][32] -> out [B][32*256]
@@ -274,25 +269,19 @@ int ava_bn_eval_all(const float* const* gamma, const float* const* beta, const i
   return AVA_OK;
 }
 
-int ava_bn_stats_ex(const float* x, int64_t n, int C, float* partials, int* nparts, const BnFuse* bn, ava_stream_t s);
 extern "C" int ava_bn_stats(const float* x, int64_t n, int C, float* partials, int* nparts, ava_stream_t s) {
-  return ava_bn_stats_ex(x, n, C, partials, nparts, nullptr, s);
-}
-int ava_bn_stats_ex(const float* x, int64_t n, int C, float* partials, int* nparts, const BnFuse* bn, ava_stream_t s) {
   if (x == nullptr || partials == nullptr || n <= 0) return AVA_EINVAL;
-  BnFuse fuse;
-  if (bn != nullptr) fuse = *bn; else memset(&fuse, 0, sizeof(fuse));
   int64_t work = C == 1 ? n / 4 : n;
   int grid = (int)((work + 256 * 8 - 1) / (256 * 8));
   if (grid < 1) grid = 1;
   if (grid > 1024) grid = 1024;
   hipStream_t st = to_stream(s);
   switch (C) {
-    case 1: hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
-    case 8: hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
-    case 16: hipLaunchKernelGGL(bn_stats_kernel<16>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
-    case 24: hipLaunchKernelGGL(bn_stats_kernel<24>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
-    case 32: hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid), dim3(256), 0, st, x, n, partials, fuse); break;
+    case 1: hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 8: hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 16: hipLaunchKernelGGL(bn_stats_kernel<16>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 24: hipLaunchKernelGGL(bn_stats_kernel<24>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
+    case 32: hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid), dim3(256), 0, st, x, n, partials); break;
     default: return AVA_EINVAL;
   }
   AVA_CHECK_LAUNCH();
@@ -323,12 +312,9 @@ extern "C" int ava_bn_finalize_bwd(const float* partials, int nparts, int64_t n,
 }
 
 // internal (model.hip)
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, const BnFuse* bn,
-                           hipStream_t st) {
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, hipStream_t st) {
   const int grid = 4 * B < 1024 ? 4 * B : 1024;
-  BnFuse fuse;
-  if (bn != nullptr) fuse = *bn; else memset(&fuse, 0, sizeof(fuse));
-  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B, fuse);
+  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B);
   AVA_CHECK_LAUNCH();
   *nparts = grid;
   return AVA_OK;

@@ -169,9 +169,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
   }
   __syncthreads();
   if (t < 2 * COUT && a.partials != nullptr)
-    bn_partial_store(a.bn, a.partials + (size_t)blockIdx.x * 2 * COUT + t,
-                     (red[t] + red[2 * COUT + t]) + (red[4 * COUT + t] + red[6 * COUT + t]));
-  if (EPI != EPI_SSE) bn_fused_finalize(a.bn, a.partials, gridDim.x, reinterpret_cast<double*>(smem));
+    a.partials[(size_t)blockIdx.x * 2 * COUT + t] =
+        (red[t] + red[2 * COUT + t]) + (red[4 * COUT + t] + red[6 * COUT + t]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,23 +467,22 @@ static int launch_conv_pe(const ConvArgs& a, int grid, int pro, int epi, hipStre
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, const BnFuse* bn, ava_stream_t s);
+                   int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s);
 
 extern "C" int ava_conv3x3(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                            const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                            const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi,
                            int Cin, int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s) {
   return ava_conv3x3_ex(in, in2, pa, pb, pc, G, bias, out, out2, epi_x, epi_mean, epi_invstd, partials, B, Hi, Wi, Cin,
-                        Cout, mode, pro, epi, relu, prec, nullptr, s);
+                        Cout, mode, pro, epi, relu, prec, s);
 }
 
-// same, with an optional fused BatchNorm finalisation (model.hip)
+// the same entry for the model driver (model.hip)
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, const BnFuse* bn, ava_stream_t s) {
+                   int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s) {
   ConvArgs a;
-  if (bn != nullptr) a.bn = *bn; else memset(&a.bn, 0, sizeof(a.bn));
   a.in = in; a.in2 = in2; a.pa = pa; a.pb = pb; a.pc = pc; a.G = G; a.bias = bias; a.out = out; a.out2 = out2;
   a.epi_x = epi_x; a.epi_mean = epi_mean; a.epi_invstd = epi_invstd; a.partials = partials;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.prec = prec;

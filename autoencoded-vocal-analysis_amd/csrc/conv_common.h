@@ -25,7 +25,6 @@ struct ConvArgs {
   int relu;
   float prec;
   int tiles_y, tiles_x, ntiles;
-  BnFuse bn; // optional fused BatchNorm finalisation by the last workgroup (bn.counter == nullptr: off)
   int part_rows; // rows of `partials` the caller sized ([ava_conv_grid]); rows beyond the launched grid are zero-filled
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };

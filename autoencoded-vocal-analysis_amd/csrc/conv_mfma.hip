@@ -214,12 +214,11 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   if (t < 2 * COUT && a.partials != nullptr) {
     const int which = t / COUT, co = t - which * COUT;
     const int idx = which * 16 * MTA + co;
-    bn_partial_store(a.bn, a.partials + (size_t)blockIdx.x * 2 * COUT + t,
-                     (red[idx] + red[32 * MTA + idx]) + (red[64 * MTA + idx] + red[96 * MTA + idx]));
+    a.partials[(size_t)blockIdx.x * 2 * COUT + t] =
+        (red[idx] + red[32 * MTA + idx]) + (red[64 * MTA + idx] + red[96 * MTA + idx]);
     for (int r = gridDim.x + blockIdx.x; r < a.part_rows; r += gridDim.x)       // rows of workgroups not launched
       a.partials[(size_t)r * 2 * COUT + t] = 0.f;
   }
-  bn_fused_finalize(a.bn, a.partials, gridDim.x, reinterpret_cast<double*>(smem));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,7 +243,7 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>, lds);
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
-  if (grid > resident && a.bn.counter == nullptr) grid = resident;
+  if (grid > resident) grid = resident;
   { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
   hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();

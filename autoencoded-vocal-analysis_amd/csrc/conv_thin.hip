@@ -715,7 +715,6 @@ static int thin_set_lds(K kernel) {
 
 int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
   if (mode != MODE_S1 || a0.Wo != THIN_W || a0.Ho % THIN_TH != 0) return AVA_EINVAL;
-  if (a0.bn.counter != nullptr) return AVA_EINVAL;       // fused BatchNorm finalisation lives in the generic kernels
   ConvArgs a = a0;
   a.ntiles = a.B * (a.Ho / THIN_TH);                     // workgroups beyond ntiles still write their (zero) partial row
   a.part_rows = grid;                                    // rows the caller sized; one resident wave is launched

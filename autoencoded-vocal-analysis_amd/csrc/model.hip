@@ -9,15 +9,14 @@
 #include "conv_fused.h"
 
 // internal entry points of the other translation units
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, const BnFuse* bn,
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts,
                            hipStream_t st);
-int ava_bn_stats_ex(const float* x, int64_t n, int C, float* partials, int* nparts, const BnFuse* bn, ava_stream_t s);
 int ava_bn_eval_all(const float* const* gamma, const float* const* beta, const int* C, const float* running, float* save,
                     hipStream_t st);
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, const BnFuse* bn, ava_stream_t s);
+                   int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s);
 int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st);
 int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
@@ -123,7 +122,6 @@ struct ava_model {
   size_t gemm_ws_bytes;
   float* loss_dev;          // 4 floats scratch when the caller passes none
   int* status_dev;
-  int* bn_counters;         // [32] tickets of the fused BatchNorm finalisations (zero between launches)
   const float* eps_w_last;
   const float* eps_d_last;  // noise of the last forward (caller-owned; needed again by backward)
   int sse_parts;
@@ -209,7 +207,6 @@ static void carve(ava_model* m, void* ws, size_t* total) {
   m->gemm_ws = c.take(m->gemm_ws_bytes / sizeof(float) + 64);
   m->loss_dev = c.take(64);
   m->status_dev = reinterpret_cast<int*>(c.take(64));
-  m->bn_counters = reinterpret_cast<int*>(c.take(64));
   *total = c.off;
 }
 
@@ -254,7 +251,6 @@ extern "C" int ava_model_create(ava_model** out, int z_dim, int max_batch, float
   m->lastB = 0;
   m->sse_parts = 0;
   // the only device write outside a stream: the ticket counters start at zero (every launch leaves them at zero)
-  if (hipMemset(m->bn_counters, 0, 64 * sizeof(int)) != hipSuccess) { delete m; return AVA_ELAUNCH; }
   const size_t B = max_batch;
   for (int l = 1; l < NCONV; ++l) {
     char nm[16];
@@ -362,40 +358,6 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st) {
   return AVA_OK;
 }
 
-// fused finalisation descriptors: forward statistics of BatchNorm l (n elements per channel) / its backward sums
-static BnFuse fuse_fwd(ava_model* m, int l, int64_t n) {
-  const ConvLayer& L = kLayers[l];
-  BnFuse f;
-  memset(&f, 0, sizeof(f));
-  f.counter = m->bn_counters + l;
-  f.mode = 1; f.C = L.cin; f.n = (double)n;
-  f.gamma = PP(m, L.pg); f.beta = PP(m, L.pbeta);
-  f.running_mean = m->bn_running + l * 32; f.running_var = m->bn_running + (NCONV + l) * 32;
-  f.num_batches = m->bn_batches + l;
-  f.mean = bn_mean(m, l); f.invstd = bn_invstd(m, l); f.scale = bn_scale(m, l); f.shift = bn_shift(m, l);
-  return f;
-}
-static BnFuse fuse_bwd(ava_model* m, int l, int64_t n) {
-  const ConvLayer& L = kLayers[l];
-  BnFuse f;
-  memset(&f, 0, sizeof(f));
-  f.counter = m->bn_counters + 16 + l;
-  f.mode = 2; f.C = L.cin; f.n = (double)n;
-  f.gamma = PP(m, L.pg);
-  f.mean = bn_mean(m, l); f.invstd = bn_invstd(m, l);
-  f.dgamma = GG(m, L.pg); f.dbeta = GG(m, L.pbeta);
-  f.A = bn_A(m, l); f.Bc = bn_B(m, l); f.Cc = bn_C(m, l);
-  return f;
-}
-// The fused (last-workgroup) finalisation is correct but SLOWER on this part: its agent-scope release fence
-// writes back the whole XCD L2, which is full of the kernel's own freshly written activations, once per
-// workgroup (+0.6 ms/step measured, profiles/r01).  Kept behind AVA_BN_FUSE=1; the default is one tiny
-// finalise launch after each producer.
-static bool bn_fuse_enabled() {
-  static int cached = -1;
-  if (cached < 0) { const char* e = getenv("AVA_BN_FUSE"); cached = (e != nullptr && atoi(e) != 0) ? 1 : 0; }
-  return cached == 1;
-}
 static int finalize_fwd(ava_model* m, int l, int nparts, int64_t n, hipStream_t st) {
   const ConvLayer& L = kLayers[l];
   const int rc = ava_bn_finalize(m->bn_part, nparts, n, L.cin, PP(m, L.pg), PP(m, L.pbeta), m->bn_running + l * 32,
@@ -445,11 +407,9 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
   const int z = m->z;
   int nparts = 0;
   if (train) {
-    const bool fuse = bn_fuse_enabled();
-    const BnFuse f0 = fuse_fwd(m, 0, (int64_t)B * 16384);
-    TRY(ava_bn_stats_ex(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, fuse ? &f0 : nullptr, st));
+    TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_BN, st);
-    if (!fuse) TRY(finalize_fwd(m, 0, nparts, (int64_t)B * 16384, st));
+    TRY(finalize_fwd(m, 0, nparts, (int64_t)B * 16384, st));
   } else {
     TRY(bn_eval_all(m, st));       // all 14 layers from the running statistics (also serves the decoder)
   }
@@ -457,13 +417,11 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
     const ConvLayer& L = kLayers[l];
     const float* in = l == 0 ? x : m->X[l];
     float* out = l == 6 ? m->y7 : m->X[l + 1];
-    const bool stats = train && l < 6, fuse = stats && bn_fuse_enabled();
-    const BnFuse fn = stats ? fuse_fwd(m, l + 1, (int64_t)B * L.ho * L.ho) : BnFuse{};
     TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nullptr,
                        nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
-                       0.f, fuse ? &fn : nullptr, st));
+                       0.f, reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_CONV_FWD, st);
-    if (stats && !fuse)
+    if (train && l < 6)
       TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, L.ho, L.ho, L.mode), (int64_t)B * L.ho * L.ho, st));
   }
   TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, st));
@@ -489,21 +447,19 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
   TRY(gemm(m, m->h6, 0, PP(m, FC7), 0, PP(m, FC7 + 1), m->h7, 0, nullptr, nullptr, B, 1024, 256, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, 8192, 1024, 1, 1, ACT_RELU, st));
   int nparts = 0;
-  const BnFuse f7 = train ? fuse_fwd(m, 7, (int64_t)B * 256) : BnFuse{};
-  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, &nparts, (train && bn_fuse_enabled()) ? &f7 : nullptr, st));
+  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, &nparts, st));
   mark(m, CAT_LAYOUT, st);
-  if (train && !bn_fuse_enabled()) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * 256, st));
+  if (train) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * 256, st));
   for (int l = 7; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
     const bool last = l == NCONV - 1;
     float* out = last ? xrec : m->X[l + 1];
-    const bool stats = train && !last, fuse = stats && bn_fuse_enabled();
-    const BnFuse fn = stats ? fuse_fwd(m, l + 1, (int64_t)B * L.ho * L.ho) : BnFuse{};
     TRY(ava_conv3x3_ex(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
                        last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi,
-                       L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, fuse ? &fn : nullptr, st));
+                       L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec,
+                       reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_CONV_FWD, st);
-    if (stats && !fuse)
+    if (train && !last)
       TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, L.ho, L.ho, L.mode), (int64_t)B * L.ho * L.ho, st));
     if (last) m->sse_parts = ava_conv_grid(B, L.ho, L.ho, L.mode);
   }
@@ -551,7 +507,7 @@ extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, flo
 // workgroups (= partial rows) of layer l's fused backward kernel; 0: the layer runs the separate kernels
 static int fused_grid(int l, int B) {
   static const bool on = [] { const char* e = getenv("AVA_CONV_FUSED"); return e == nullptr || atoi(e) != 0; }();
-  if (!on || bn_fuse_enabled()) return 0;
+  if (!on) return 0;
   const ConvLayer& L = kLayers[l];
   return ava_conv_fused_grid_for(B, L.hi, L.hi, L.cin, L.cout, L.mode);
 }
@@ -581,12 +537,11 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   mark(m, CAT_CONV_WGRAD, st);
   // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
   const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
-  const BnFuse fb = fuse_bwd(m, l, (int64_t)B * L.hi * L.hi);
   TRY(ava_conv3x3_ex(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
                      m->bn_part, B, L.ho, L.ho, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f,
-                     bn_fuse_enabled() ? &fb : nullptr, st));
+                     reinterpret_cast<ava_stream_t>(st)));
   mark(m, CAT_CONV_BWD_DATA, st);
-  if (!bn_fuse_enabled()) TRY(finalize_bwd(m, l, ava_conv_grid(B, L.hi, L.hi, bmode), (int64_t)B * L.hi * L.hi, st));
+  TRY(finalize_bwd(m, l, ava_conv_grid(B, L.hi, L.hi, bmode), (int64_t)B * L.hi * L.hi, st));
   return AVA_OK;
 }
 

@@ -45,26 +45,8 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT> f2;
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT> f3;
   constexpr int SP = MODE == MODE_DOWN ? 2 : 1;            // input pixels per output pixel along x
-  if (!(a.dbg & 8)) f0.init(a.G, lane, SP * n * CIN, mtb);
-  if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
   // output offset (floats) of this lane inside a 16-pixel group: pixel n (every 2nd pixel for UP), channels 4kg..
   const int lane_out = (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
-
-  // epilogue constants for this lane's 4 output channels per cout tile
-  float bias[MT][4], emean[MT][4], einv[MT][4];
-  float s1[MT][4], s2[MT][4];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = 16 * (mtb + mt) + 4 * kg + r;
-      bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
-      emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
-      einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
-      s1[mt][r] = s2[mt][r] = 0.f;
-      // retire these loop-invariant loads before the tile loop (see ClassFrag::init)
-      asm volatile("" ::"v"(bias[mt][r]), "v"(emean[mt][r]), "v"(einv[mt][r]));
-    }
 
   // tile origin (image, output row/col, input row/col) of tile `tl`
   auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
@@ -114,6 +96,26 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
     stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
     if (EPI == EPI_BWD) load_ex(b, oy0, ox0);
   }
+  // Weights and epilogue constants are fetched AFTER the first tile's loads were issued: both round trips to
+  // memory overlap instead of following each other at the start of every workgroup.
+  if (!(a.dbg & 8)) f0.init(a.G, lane, SP * n * CIN, mtb);
+  if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
+  // epilogue constants for this lane's 4 output channels per cout tile
+  float bias[MT][4], emean[MT][4], einv[MT][4];
+  float s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * (mtb + mt) + 4 * kg + r;
+      bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
+      emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
+      einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
+      s1[mt][r] = s2[mt][r] = 0.f;
+      // retire these loop-invariant loads before the tile loop (see ClassFrag::init)
+      asm volatile("" ::"v"(bias[mt][r]), "v"(emean[mt][r]), "v"(einv[mt][r]));
+    }
+
   for (; walk.valid(); walk.advance()) {
     int b, oy0, ox0, gy0, gx0;
     origin(walk.cur, b, oy0, ox0, gy0, gx0);

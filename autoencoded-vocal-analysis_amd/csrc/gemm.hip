@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #define AVA_GEMM_GROUP_MAX 8
 struct GemmGroup {
   GemmArgs g[AVA_GEMM_GROUP_MAX];
+  int tile0[AVA_GEMM_GROUP_MAX + 1];     // skinny grouped launch: first 16x16 tile of each problem in a flat grid
+  int n;
 };
 template <int BM, bool A_KMAJ, bool B_KMAJ, bool VEC>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(const GemmGroup grp) {
@@ -338,47 +340,66 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 
-template <bool B_KMAJ>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g) {
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx, const int by) {
   __shared__ float red[3][64][4];
+  __shared__ float cred[4][16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = lane & 15, kg = lane >> 4;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int m0 = by * 16, n0 = bx * 16;
   const int am = min(m0 + i, g.M - 1);            // clamped row of A / column of B owned by this lane
   const int bn = min(n0 + i, g.N - 1);
-  const float* __restrict__ arow = g.A + (size_t)am * g.lda;
+  const float* __restrict__ arow = A_KMAJ ? g.A + (size_t)am * g.lda : g.A + am;
   const float* __restrict__ bcol = B_KMAJ ? g.B + (size_t)bn * g.ldb : g.B + bn;
   const int nchunks = (g.K + 15) >> 4;
+  const bool do_colsum = g.colsum != nullptr && bx == 0;     // bias gradient: column sums of A (m-major A only)
   f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
   constexpr int U = 4;                            // chunks in flight per wave
   for (int c0 = wave; c0 < nchunks; c0 += 4 * U) {
     f32x4g a[U], b[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = 16 * (c0 + 4 * u) + 4 * kg;   // K % 4 == 0: a quad is inside or outside as a whole
-      const bool ok = k < g.K;
-      const int kc = ok ? k : 0;
-      a[u] = *reinterpret_cast<const f32x4g*>(arow + kc);
-      if (B_KMAJ) {
-        b[u] = *reinterpret_cast<const f32x4g*>(bcol + kc);
+      const int k = 16 * (c0 + 4 * u) + 4 * kg;
+      if (A_KMAJ) {                               // K % 4 == 0: a quad is inside or outside as a whole
+        const bool ok = k < g.K;
+        a[u] = *reinterpret_cast<const f32x4g*>(arow + (ok ? k : 0));
+        if (!ok) a[u] = (f32x4g){0.f, 0.f, 0.f, 0.f};
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[u][j] = bcol[(size_t)(kc + j) * g.ldb];
+        for (int j = 0; j < 4; ++j) {
+          const float v = arow[(size_t)min(k + j, g.K - 1) * g.lda];
+          a[u][j] = k + j < g.K ? v : 0.f;
+        }
       }
-      if (!ok) { a[u] = (f32x4g){0.f, 0.f, 0.f, 0.f}; }
+      if (B_KMAJ) {
+        b[u] = *reinterpret_cast<const f32x4g*>(bcol + (k < g.K ? k : 0));      // multiplied by a zero A quad when outside
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[u][j] = bcol[(size_t)min(k + j, g.K - 1) * g.ldb];
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][j], acc, 0, 0, 0);
+        csum += a[u][j];
+      }
   }
   // D[row = 4 kg + r][col = i] ; waves 1..3 hand their tile to wave 0, summed in wave order
   if (wave > 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
   }
+  if (do_colsum) {
+    csum += __shfl_xor(csum, 16, 64);
+    csum += __shfl_xor(csum, 32, 64);
+    if (kg == 0) cred[wave][i] = csum;
+  }
   __syncthreads();
   if (wave != 0) return;
+  if (do_colsum && kg == 0 && m0 + i < g.M) g.colsum[m0 + i] = (cred[0][i] + cred[1][i]) + (cred[2][i] + cred[3][i]);
   const int gn = n0 + i;
   if (gn >= g.N) return;
   const float bv = g.bias != nullptr ? g.bias[gn] : 0.f;
@@ -394,15 +415,30 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g) {
   }
 }
 
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g) {
+  gemm_skinny_body<A_KMAJ, B_KMAJ>(g, blockIdx.x, blockIdx.y);
+}
+
 // products the skinny kernel takes: small output, A k-major, 16-byte alignable operands, no bias-gradient column sums
 static bool skinny_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
   static const bool on = [] { const char* e = getenv("AVA_GEMM_SKINNY"); return e == nullptr || atoi(e) != 0; }();
-  if (!on || !a_kmajor || g.colsum != nullptr) return false;
   static const int kmax = [] { const char* e = getenv("AVA_GEMM_SKINNY_KMAX"); return e ? atoi(e) : 2048; }();
-  if ((size_t)g.M * g.N > 262144 || g.K > kmax || g.K % 4 != 0 || g.lda % 4 != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(g.A) & 15) != 0) return false;
-  if (b_kmajor && (g.ldb % 4 != 0 || (reinterpret_cast<uintptr_t>(g.B) & 15) != 0)) return false;
+  if (!on) return false;
+  if (g.colsum != nullptr && a_kmajor) return false;         // column sums are taken from an m-major A
+  if ((size_t)g.M * g.N > 262144 || g.K > kmax) return false;
+  if (a_kmajor && (g.K % 4 != 0 || g.lda % 4 != 0 || (reinterpret_cast<uintptr_t>(g.A) & 15) != 0)) return false;
+  if (b_kmajor && (g.K % 4 != 0 || g.ldb % 4 != 0 || (reinterpret_cast<uintptr_t>(g.B) & 15) != 0)) return false;
   return true;
+}
+
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(256) void gemm_skinny_grouped_kernel(const GemmGroup grp) {
+  int p = 0;
+  while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile0[p + 1]) ++p;        // flat tile index -> (problem, tile)
+  const GemmArgs& g = grp.g[p];
+  const int tile = blockIdx.x - grp.tile0[p], tx = (g.N + 15) >> 4;
+  gemm_skinny_body<A_KMAJ, B_KMAJ>(g, tile % tx, tile / tx);
 }
 
 static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
@@ -464,8 +500,10 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   if (skinny_ok(g, a_kmajor, b_kmajor)) {
     g.C = C;
     const dim3 sgrid(ceil_div(N, 16), ceil_div(M, 16));
-    if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true>), sgrid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<false>), sgrid, dim3(256), 0, st, g);
+    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), sgrid, dim3(256), 0, st, g);
+    else if (a_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), sgrid, dim3(256), 0, st, g);
+    else if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), sgrid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), sgrid, dim3(256), 0, st, g);
     AVA_CHECK_LAUNCH();
     return AVA_OK;
   }
@@ -520,6 +558,24 @@ int ava_gemm_grouped(const AvaGemmProblem* p, int n, int a_kmajor, int b_kmajor,
     vec = vec && g.vec_a && g.vec_b;
     tx = tx > ceil_div(g.N, 64) ? tx : ceil_div(g.N, 64);
     ty = ty > ceil_div(g.M, 64) ? ty : ceil_div(g.M, 64);
+  }
+  bool skinny = true;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    skinny = skinny && skinny_ok(grp.g[i], a_kmajor, b_kmajor);
+    grp.tile0[i] = tiles;
+    tiles += ceil_div(grp.g[i].N, 16) * ceil_div(grp.g[i].M, 16);
+  }
+  grp.tile0[n] = tiles;
+  grp.n = n;
+  if (skinny) {
+    const dim3 sgrid(tiles);
+    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_skinny_grouped_kernel<true, true>), sgrid, dim3(256), 0, st, grp);
+    else if (a_kmajor) hipLaunchKernelGGL((gemm_skinny_grouped_kernel<true, false>), sgrid, dim3(256), 0, st, grp);
+    else if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_grouped_kernel<false, true>), sgrid, dim3(256), 0, st, grp);
+    else hipLaunchKernelGGL((gemm_skinny_grouped_kernel<false, false>), sgrid, dim3(256), 0, st, grp);
+    AVA_CHECK_LAUNCH();
+    return AVA_OK;
   }
   const dim3 grid(tx, ty, n);
 #define AVA_GG(AK, BK_)                                                                                          \

@@ -355,7 +355,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
   const bool do_colsum = g.colsum != nullptr && bx == 0;     // bias gradient: column sums of A (m-major A only)
   f32x4g acc = {0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
-  constexpr int U = 4;                            // chunks in flight per wave
+  constexpr int U = 4;                            // chunks in flight per wave (8 measured slower)
   for (int c0 = wave; c0 < nchunks; c0 += 4 * U) {
     f32x4g a[U], b[U];
 #pragma unroll

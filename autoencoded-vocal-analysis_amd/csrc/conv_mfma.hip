@@ -187,6 +187,15 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
           }
           if (obase != nullptr && !(a.dbg & 4))
             *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+          if (EPI == EPI_FWD && MODE == MODE_S1 && a.out2 != nullptr) {
+            // second copy in NCHW order (the flatten order of the fully connected layer that follows, vae.py:224):
+            // 16 lanes = 16 consecutive pixels of a row -> 64 contiguous bytes per channel
+            constexpr int GPR = TW / 16;
+            const int oy = oy0 + g / GPR, ox = ox0 + 16 * (g % GPR) + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              a.out2[(((size_t)b * COUT + cb + r) * a.Ho + oy) * a.Wo + ox] = v[r];
+          }
         }
       }
     }

@@ -402,6 +402,12 @@ static int gemm_group(ava_model* m, const AvaGemmProblem* p, int n, int ak, int 
 enum { FC1 = 28, FC2 = 30, FC31 = 32, FC32 = 34, FC33 = 36, FC41 = 38, FC42 = 40, FC43 = 42, FC5 = 44, FC6 = 46,
        FC7 = 48, FC8 = 50 };
 
+// the version-0 (VALU) conv kernels have no NCHW second output: keep the transpose launch for them
+static bool conv7_writes_nchw() {
+  static const bool on = [] { const char* e = getenv("AVA_CONV_IMPL"); return !(e != nullptr && strcmp(e, "valu") == 0); }();
+  return on;
+}
+
 static int encoder_forward(ava_model* m, const float* x, int B, int train, float* mu, float* u, float* logd_or_d,
                            int last_act, hipStream_t st) {
   const int z = m->z;
@@ -417,14 +423,16 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
     const ConvLayer& L = kLayers[l];
     const float* in = l == 0 ? x : m->X[l];
     float* out = l == 6 ? m->y7 : m->X[l + 1];
-    TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nullptr,
+    // conv7's matrix-core kernel also writes the NCHW-flatten copy fc1 reads (saves the transpose launch)
+    float* nchw = (l == 6 && conv7_writes_nchw()) ? m->y7t : nullptr;
+    TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nchw,
                        nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
                        0.f, reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_CONV_FWD, st);
     if (train && l < 6)
       TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, L.ho, L.ho, L.mode), (int64_t)B * L.ho * L.ho, st));
   }
-  TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, st));
+  if (!conv7_writes_nchw()) TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, st));
   mark(m, CAT_LAYOUT, st);
   TRY(gemm(m, m->y7t, 0, PP(m, FC1), 0, PP(m, FC1 + 1), m->h1, 0, nullptr, nullptr, B, 1024, 8192, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h1, 0, PP(m, FC2), 0, PP(m, FC2 + 1), m->h2, 0, nullptr, nullptr, B, 256, 1024, 1, 1, ACT_RELU, st));
@@ -583,26 +591,28 @@ extern "C" int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_
   return AVA_OK;
 }
 
-static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st);
+// `whole`: called from ava_backward (no bucket has to be complete before the end): the decoder's weight-gradient
+// reduction is deferred and runs together with the encoder's in ONE launch at the end of part 2
+static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, bool whole);
 static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st);
-static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st);
+static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, bool whole);
 
 extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s) {
   if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr) return AVA_EINVAL;
-  TRY(backward_part0(m, x, B, to_stream(s)));
+  TRY(backward_part0(m, x, B, to_stream(s), true));
   TRY(backward_part1(m, x, B, to_stream(s)));
-  return backward_part2(m, x, B, to_stream(s));
+  return backward_part2(m, x, B, to_stream(s), true);
 }
 // part 0: decoder convolutions, bn8, fc8's weight gradient;  part 1: the fully connected layers and the latent
 // block;  part 2: the encoder convolutions.  Each completes the gradient bucket of the same number.
 extern "C" int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s) {
   if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr || part < 0 || part >= AVA_BACKWARD_PARTS)
     return AVA_EINVAL;
-  if (part == 0) return backward_part0(m, x, B, to_stream(s));
-  return part == 1 ? backward_part1(m, x, B, to_stream(s)) : backward_part2(m, x, B, to_stream(s));
+  if (part == 0) return backward_part0(m, x, B, to_stream(s), false);
+  return part == 1 ? backward_part1(m, x, B, to_stream(s)) : backward_part2(m, x, B, to_stream(s), false);
 }
 
-static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st) {
+static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, bool whole) {
   // ---- decoder convolutions, last to first ----
   float* gcur = m->gA;
   float* gnext = m->gB;
@@ -617,7 +627,7 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st) {
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
   TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, st));
   mark(m, CAT_LAYOUT, st);
-  TRY(reduce_wgrads(m, 7, NCONV, B, st));
+  if (!whole) TRY(reduce_wgrads(m, 7, NCONV, B, st));
   TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), 8192, 1024, B, 0, 0, ACT_NONE, st));
   return AVA_OK;
 }
@@ -658,7 +668,7 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   return gemm_group(m, dws, 8, 0, 0, st);
 }
 
-static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st) {
+static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, bool whole) {
   // ---- encoder convolutions ----
   float* gcur = m->gA;
   float* gnext = m->gB;
@@ -672,7 +682,7 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st) {
                             l == 0 ? nullptr : gnext, B, st));
     float* t = gcur; gcur = gnext; gnext = t;
   }
-  return reduce_wgrads(m, 0, 7, B, st);      // encoder weight/bias gradients
+  return reduce_wgrads(m, whole ? 0 : 0, whole ? NCONV : 7, B, st);      // encoder (whole: all 14) weight/bias gradients
 }
 
 extern "C" int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step,

@@ -113,7 +113,9 @@ int ava_pack_conv_weight(const float* w, float* g, int c_first, int c_second, in
  *   pro 1: (in2 > 0) ? pa[c]*v + pb[c]*in2 + pc[c] : 0   (ReLU mask + BatchNorm backward, in2 = saved activation)
  *   pro 2: v
  * Epilogue:
- *   epi 0: + bias, optional ReLU, store, per-channel {sum, sum^2} partials (next BatchNorm's statistics)
+ *   epi 0: + bias, optional ReLU, store, per-channel {sum, sum^2} partials (next BatchNorm's statistics);
+ *          out2 (optional, stride-1 layers with >= 8 channels on both sides): a second copy in NCHW order
+ *          [B][Cout][Ho][Wo], the flatten order nn.Linear reads after conv7 (vae.py:224)
  *   epi 1: store, per-channel {sum g, sum g*xhat} partials with xhat = (epi_x - mean)*invstd (BatchNorm backward sums)
  *   epi 2: + bias, store x_rec, r = x_rec - epi_x, store prec*r to out2, partial {sum r^2}  (vae.py:319-320)
  * partials: [ava_conv_grid(...)][2*Cout] floats. */

@@ -118,6 +118,24 @@ def test_conv_backward_data_and_wgrad(layer):
         assert rel(fdw.cpu(), wr.grad.reshape(-1)) < TOL and rel(fdb.cpu(), br.grad) < TOL
 
 
+def test_conv7_writes_nchw_copy():
+    """conv7's forward also leaves its output in NCHW-flatten order for fc1 (vae.py:224)."""
+    name, cin, cout, mode, hi, tr = [l for l in LAYERS if l[0] == "conv7"][0]
+    B = 3
+    x, w, b, scale, shift = layer_tensors(name, cin, cout, hi, tr, B, 21)
+    lib = _lib.load()
+    G = pack(dev(w), 0)
+    out = torch.empty(B, hi, hi, cout, device="cuda")
+    out2 = torch.zeros(B, cout, hi, hi, device="cuda")
+    parts = torch.zeros(lib.ava_conv_grid(B, hi, hi, mode), 2 * cout, device="cuda")
+    xs, sc, sh, bb = dev(nhwc(x)), dev(scale), dev(shift), dev(b)
+    rc = lib.ava_conv3x3(p(xs), None, p(sc), p(sh), None, p(G), p(bb), p(out), p(out2), None, None, None, p(parts), B, hi, hi,
+                         cin, cout, mode, PRO_BN, EPI_FWD, 1, 0.0, stream())
+    _lib.check(rc, "ava_conv3x3")
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out.permute(0, 3, 1, 2).contiguous())
+
+
 def test_convt7_sse_epilogue():
     """x_rec, the SSE partial sums and the seed gradient prec*(x_rec - x) (vae.py:319-320)."""
     name, cin, cout, mode, hi, tr = LAYERS[13]

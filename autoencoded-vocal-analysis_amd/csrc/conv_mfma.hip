@@ -279,12 +279,12 @@ int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, i
   AVA_MFMA_CASE(8, 8, MODE_DOWN, 32, 4)
   AVA_MFMA_CASE(8, 16, MODE_S1, 32, 8)
   AVA_MFMA_CASE(16, 16, MODE_DOWN, 32, 4)
-  AVA_MFMA_CASE(16, 24, MODE_S1, 32, 8)
+  AVA_MFMA_CASE(16, 24, MODE_S1, 32, 4)
   AVA_MFMA_CASE(24, 24, MODE_DOWN, 16, 4)
   AVA_MFMA_CASE(24, 32, MODE_S1, 16, 8)
   AVA_MFMA_CASE(32, 24, MODE_S1, 16, 8)
   AVA_MFMA_CASE(24, 24, MODE_UP, 32, 8)
-  AVA_MFMA_CASE(24, 16, MODE_S1, 32, 8)
+  AVA_MFMA_CASE(24, 16, MODE_S1, 32, 4)
   AVA_MFMA_CASE(16, 16, MODE_UP, 32, 8)
   AVA_MFMA_CASE(16, 8, MODE_S1, 32, 8)
   AVA_MFMA_CASE(8, 8, MODE_UP, 32, 8)
@@ -603,12 +603,12 @@ int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int 
   AVA_WGM_CASE(8, 8, MODE_DOWN, 32, 4)
   AVA_WGM_CASE(8, 16, MODE_S1, 32, 8)
   AVA_WGM_CASE(16, 16, MODE_DOWN, 32, 4)
-  AVA_WGM_CASE(16, 24, MODE_S1, 32, 8)
+  AVA_WGM_CASE(16, 24, MODE_S1, 32, 4)
   AVA_WGM_CASE(24, 24, MODE_DOWN, 16, 8)
   AVA_WGM_CASE(24, 32, MODE_S1, 16, 16)
   AVA_WGM_CASE(32, 24, MODE_S1, 16, 16)
   AVA_WGM_CASE(24, 24, MODE_UP, 32, 8)
-  AVA_WGM_CASE(24, 16, MODE_S1, 32, 8)
+  AVA_WGM_CASE(24, 16, MODE_S1, 32, 4)
   AVA_WGM_CASE(16, 16, MODE_UP, 32, 8)
   AVA_WGM_CASE(16, 8, MODE_S1, 32, 8)
   AVA_WGM_CASE(8, 8, MODE_UP, 32, 8)

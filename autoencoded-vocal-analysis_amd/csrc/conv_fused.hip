@@ -12,6 +12,7 @@
 // ava/models/vae.py:347-353 loss.backward()).  Tiles are indexed in the LOW-resolution space of the layer
 // (S1: both tensors; stride-2 conv: the dU side; stride-2 convT: the x side).
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_mfma.h"
 #include "conv_fused.h"
 
@@ -36,6 +37,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
   constexpr int NT = (CO + 15) / 16;        // dG column tiles
   constexpr int NW = 9 * CI * CO;
   constexpr int BCLS = n_classes<BMODE>(), WCLS = n_classes<LMODE>();
+  // stride-1 layers with 8 input channels: the data gradient has 8 output channels -> two dx rows per MFMA tile
+  constexpr bool PAIR = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
   extern __shared__ __align__(16) float smem[];
   float* xt = smem;                          // [XR*XC*CI]   BatchNorm(x), zero padded
   float* dut = xt + XR * XC * CI;            // [DR*DC*CO]   dU, zero outside the image (+16 floats of zero pad)
@@ -56,19 +59,20 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
 
   // ---- backward-data fragments: the flipped/packed weights stay in registers for the whole kernel ----
   constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
-  ClassFrag<CO, CI, BMODE, 0, DC> f0;
+  typename std::conditional<PAIR, PairFrag<CO, DC>, ClassFrag<CO, CI, BMODE, 0, DC>>::type f0;
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC> f1;
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 2 : 0), DC> f2;
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 3 : 0), DC> f3;
   f0.init(a.Gb, lane, SPB * n * CO);
   if (BCLS > 1) { f1.init(a.Gb, lane, n * CO); f2.init(a.Gb, lane, n * CO); f3.init(a.Gb, lane, n * CO); }
-  const int lane_out = (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
+  const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
+  const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
   float emean[MT][4], einv[MT][4], s1[MT][4], s2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ci = 16 * mt + 4 * kg + r;
+      const int ci = 16 * mt + cq + r;
       emean[mt][r] = ci < CI ? a.mean[ci] : 0.f;
       einv[mt][r] = ci < CI ? a.invstd[ci] : 0.f;
       s1[mt][r] = s2[mt][r] = 0.f;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
 
   // pixel groups of the dx region: 16 consecutive pixels of a row (UP pattern: of one parity class)
   constexpr int CB = FG::OW / (BMODE == MODE_UP ? 32 : 16);          // column blocks
-  constexpr int GROUPS = BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB;
+  constexpr int GROUPS = PAIR ? (FG::OH / 2) * CB : (BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB);
   constexpr int GPW = GROUPS / 4;
   static_assert(GROUPS % 4 == 0 && (BMODE != MODE_UP || GPW % 4 == 0), "tile must split evenly over the 4 waves");
   // offset (floats, relative to the dx region's first pixel) and LDS pixel base of group g
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
       const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
       return ((2 * r + (cls >> 1)) * a.Wi + 32 * cb + (cls & 1)) * CI;
     }
-    return ((g / CB) * a.Wi + 16 * (g % CB)) * CI;
+    return (((PAIR ? 2 : 1) * (g / CB)) * a.Wi + 16 * (g % CB)) * CI;
   };
 
   // raw x at this lane's dx pixels (BatchNorm-backward sums).  Loaded one tile ahead, AFTER the tile's data-gradient
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int cb4 = 16 * mt + 4 * kg;
+        const int cb4 = 16 * mt + cq;
         // lanes whose 4-channel slot lies beyond CI re-read slot 0: stays in bounds
         ex[gi * MT + mt] = *reinterpret_cast<const avaf4*>(
             xb + group_out(wave * GPW + gi) + (cb4 < CI ? lane_out + 16 * mt : lane_out - 4 * kg));
@@ -181,13 +185,14 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
         else if (cls == 2) f2.run(px, acc);
         else f3.run(px, acc);
       } else {
-        constexpr int S = BMODE == MODE_S1 ? 1 : 2;
-        f0.run(dut + (S * (g / CB) * DC + S * 16 * (g % CB)) * CO, acc);
+        constexpr int S = (BMODE == MODE_S1 && !PAIR) ? 1 : 2;        // PAIR: a group is a pair of dx rows
+        constexpr int SX = BMODE == MODE_DOWN ? 2 : 1;
+        f0.run(dut + (S * (g / CB) * DC + SX * 16 * (g % CB)) * CO, acc);
       }
       const int gout = group_out(g) + lane_out;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int cb4 = 16 * mt + 4 * kg;
+        const int cb4 = 16 * mt + cq;
         if (cb4 < CI) {
           const f32x4 v = acc[0][mt] + acc[1][mt];
           const avaf4 xr = ex[gi * MT + mt];
@@ -256,8 +261,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
       float v1 = s1[mt][r], v2 = s2[mt][r];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
-      if (n == 0) {
-        const int ci = 16 * mt + 4 * kg + r;
+      if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair
+      if (n == 0 && (!PAIR || kg < 2)) {
+        const int ci = 16 * mt + cq + r;
         red[wave * 32 * MT + ci] = v1;
         red[wave * 32 * MT + 16 * MT + ci] = v2;
       }

@@ -230,3 +230,49 @@ struct WSplit {
       }
   }
 };
+
+// ---- two output rows in one 16-row MFMA tile (stride-1 layers with 8 output channels) ----------------------------
+// With Cout = 8 half of the 16 M rows of v_mfma_f32_16x16x4 are padding.  PairFrag puts output row y in M rows 0..7
+// and output row y+1 in rows 8..15: both read the same input pixels (B operand), so K walks the FOUR input rows
+// y-1 .. y+2 (x 3 taps x Cin) and the A operand holds W[ky = dr - half] where that tap exists, zero otherwise:
+// 12 Cin/4 MFMAs for two rows of 16 pixels instead of 2 x 9 Cin/4 -- a third fewer, and no idle lanes in the epilogue.
+template <int CIN, int IC>
+struct PairFrag {
+  static constexpr int KTOT = 12 * CIN;
+  static constexpr int NCH = (KTOT + 15) / 16;
+  static constexpr int MT = 1;
+  int off[NCH];
+  float w[NCH][4][1];
+
+  // G: gather weights [9][CIN][8]; lane_base: LDS offset of this lane's pixel inside the 16-pixel group
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base, int /*mtb*/ = 0) {
+    const int m = lane & 15, kg = lane >> 4;
+    const int half = m >> 3, co = m & 7;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = 16 * c + 4 * kg;
+      const bool valid = k < KTOT;
+      const int kk = valid ? k : 0;
+      const int dr = kk / (3 * CIN), rem = kk - dr * 3 * CIN;
+      const int kx = rem / CIN, ci = rem - kx * CIN;
+      const int ky = dr - half;
+      off[c] = lane_base + (dr * IC + kx) * CIN + ci;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[c][j][0] = (valid && ky >= 0 && ky <= 2) ? G[((ky * 3 + kx) * CIN + ci + j) * 8 + co] : 0.f;
+        asm volatile("" ::"v"(w[c][j][0]));          // retire before the tile loop (see ClassFrag::init)
+      }
+    }
+  }
+
+  __device__ __forceinline__ void run(const float* __restrict__ px, f32x4 (&acc)[2][1]) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 b = *reinterpret_cast<const float4*>(px + off[c]);
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j & 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][j][0], bv[j], acc[j & 1][0], 0, 0, 0);
+    }
+  }
+};

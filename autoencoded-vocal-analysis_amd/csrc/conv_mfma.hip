@@ -13,12 +13,15 @@
 // A workgroup (4 waves) walks a list of output tiles; each wave owns groups of 16 consecutive output
 // pixels of a row (for the x2-upsampling pattern: of one output-parity class, so the tap set is uniform).
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_mfma.h"
 
 // MSPLIT (layers with two cout tiles): waves 0,2 compute cout tile 0 and waves 1,3 tile 1, each for half of the pixel
 // groups -- half the weight registers per wave (112 -> 56 for 24 -> 24 channels), so two workgroups fit on a CU.
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT>
+// PAIR (stride 1, 8 output channels): two output rows share one MFMA tile (PairFrag) -- a third fewer MFMAs.
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR>
 __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(const ConvArgs a) {
+  static_assert(!PAIR || (MODE == MODE_S1 && COUT == 8 && !MSPLIT && TH % 2 == 0), "PAIR: stride 1, 8 output channels");
   using G = Geom<MODE, TW, TH>;
   constexpr int IR = G::IR, IC = G::IC;
   constexpr int MTA = (COUT + 15) / 16;             // cout tiles of the layer
@@ -40,13 +43,15 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
     coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
   }
 
-  ClassFrag<CIN, COUT, MODE, 0, IC, MT> f0;
+  typename std::conditional<PAIR, PairFrag<CIN, IC>, ClassFrag<CIN, COUT, MODE, 0, IC, MT>>::type f0;
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT> f1;
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT> f2;
   ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT> f3;
   constexpr int SP = MODE == MODE_DOWN ? 2 : 1;            // input pixels per output pixel along x
   // output offset (floats) of this lane inside a 16-pixel group: pixel n (every 2nd pixel for UP), channels 4kg..
-  const int lane_out = (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
+  // (PAIR: rows 4kg.. of the tile are output row kg >> 1, channels 4 (kg & 1)..)
+  const int lane_out = PAIR ? ((kg >> 1) * a.Wo + n) * COUT + 4 * (kg & 1) : (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
+  const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first output channel of this lane inside its cout tile
 
   // tile origin (image, output row/col, input row/col) of tile `tl`
   auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
     else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
-  constexpr int GROUPS = (MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16);
+  constexpr int GROUPS = PAIR ? (TH / 2) * (TW / 16) : ((MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16));
   constexpr int GPW = MSPLIT ? GROUPS / 2 : GROUPS / 4;     // groups per wave
   static_assert(GROUPS % 4 == 0 && (!MSPLIT || MODE != MODE_UP || GROUPS % 8 == 0),
                 "tile must give every wave the same number of pixel groups");
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   auto group_out = [&](int g) -> int {
     if (MODE == MODE_UP) return (((2 * (g >> 2)) + ((g & 3) >> 1)) * a.Wo + (g & 1)) * COUT;
     constexpr int GPR = TW / 16;
-    return ((g / GPR) * a.Wo + 16 * (g % GPR)) * COUT;
+    return (((PAIR ? 2 : 1) * (g / GPR)) * a.Wo + 16 * (g % GPR)) * COUT;
   };
   avaf4 exn[EPI == EPI_BWD ? GPW * MT : 1];
   auto load_ex = [&](int b, int oy0, int ox0) {
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int cb = 16 * (mtb + mt) + 4 * kg;
+        const int cb = 16 * (mtb + mt) + cq;
         // lanes whose 4-channel slot lies beyond COUT (COUT = 8 or 24) re-read slot 0: stays in bounds
         exn[gi * MT + mt] = ava_load_f4_async(xb + group_out(group_of(gi)) + (cb < COUT ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
       }
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = 16 * (mtb + mt) + 4 * kg + r;
+      const int co = 16 * (mtb + mt) + cq + r;
       bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
       emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
       einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
@@ -158,13 +163,14 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
         else f3.run(px, acc);
       } else {
         constexpr int GPR = TW / 16;
-        constexpr int S = MODE == MODE_S1 ? 1 : 2;
-        f0.run(tile + (S * (g / GPR) * IC + S * 16 * (g % GPR)) * CIN, acc);
+        constexpr int S = (MODE == MODE_S1 && !PAIR) ? 1 : 2;        // PAIR: a group is a pair of rows
+        constexpr int SX = MODE == MODE_DOWN ? 2 : 1;
+        f0.run(tile + (S * (g / GPR) * IC + SX * 16 * (g % GPR)) * CIN, acc);
       }
       const int gout = group_out(g) + lane_out;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int cb = 16 * (mtb + mt) + 4 * kg;
+        const int cb = 16 * (mtb + mt) + cq;
         if (cb < COUT) {
           f32x4 v = acc[0][mt] + acc[1][mt];
           if (EPI == EPI_FWD) {
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
           }
           if (obase != nullptr && !(a.dbg & 4))
             *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
-          if (EPI == EPI_FWD && MODE == MODE_S1 && a.out2 != nullptr) {
+          if (EPI == EPI_FWD && MODE == MODE_S1 && !PAIR && a.out2 != nullptr) {
             // second copy in NCHW order (the flatten order of the fully connected layer that follows, vae.py:224):
             // 16 lanes = 16 consecutive pixels of a row -> 64 contiguous bytes per channel
             constexpr int GPR = TW / 16;
@@ -215,8 +221,9 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
       float v1 = s1[mt][r], v2 = s2[mt][r];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
-      if (n == 0) {
-        const int co = 16 * (mtb + mt) + 4 * kg + r;
+      if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair
+      if (n == 0 && (!PAIR || kg < 2)) {
+        const int co = 16 * (mtb + mt) + cq + r;
         red[wave * 32 * MTA + co] = v1;
         red[wave * 32 * MTA + 16 * MTA + co] = v2;
       }
@@ -238,10 +245,11 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   constexpr int MT = (COUT + 15) / 16;
   constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // the register-bound shapes
+  constexpr bool PAIR = MODE == MODE_S1 && COUT == 8;
   const size_t lds = (size_t)(G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
@@ -251,12 +259,12 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   // one resident wave of workgroups; the partial rows of the workgroups not launched are zero-filled by the kernel
-  static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>, lds);
+  static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>, lds);
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
   if (grid > resident) grid = resident;
   { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT>), dim3(grid), dim3(256), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

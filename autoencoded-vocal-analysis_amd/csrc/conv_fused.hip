@@ -374,7 +374,8 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
   const int hl = mode == MODE_DOWN ? Hi / 2 : Hi, wl = mode == MODE_DOWN ? Wi / 2 : Wi;
   if (hl % th != 0 || wl % tw != 0) return 0;
   const int nt = B * (hl / th) * (wl / tw);
-  return nt < 512 ? nt : 512;
+  static const int cap = [] { const char* e = getenv("AVA_FUSED_GRID"); return (e && atoi(e) >= 8) ? atoi(e) : 512; }();
+  return nt < cap ? nt : cap;                 // 512 = two resident workgroups per CU (sweep: 384 / 768 / 1024 are slower)
 }
 
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {

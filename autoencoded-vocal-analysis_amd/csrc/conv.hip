@@ -428,12 +428,13 @@ extern "C" int ava_conv_grid(int B, int Ho, int Wo, int mode) {
   if (nt < 0) return AVA_EINVAL;
   return 2 * nt < 1024 ? 2 * nt : 1024;
 }
+// rows of the weight-gradient partial buffer: one per 128 output pixels, at most 512 (see ava_conv_grid)
 extern "C" int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode) {
   (void)mode;
   int ty, tx;
   const int nt = conv_geometry(B, Ho, Wo, &ty, &tx);
   if (nt < 0) return AVA_EINVAL;
-  return nt < 512 ? nt : 512;
+  return 2 * nt < 512 ? 2 * nt : 512;
 }
 
 template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW>
@@ -559,7 +560,7 @@ extern "C" int ava_conv3x3_wgrad(const float* x, const float* xa, const float* x
   a.ntiles = conv_geometry(B, a.Ho, a.Wo, &a.tiles_y, &a.tiles_x);
   if (a.ntiles <= 0 || x == nullptr || dy == nullptr || partials == nullptr) return AVA_EINVAL;
   if (dy_pro == PRO_BWD && dy2 == nullptr) return AVA_EINVAL;
-  const int grid = a.ntiles < 512 ? a.ntiles : 512;   // the matrix-core kernels may launch (= write rows for) fewer
+  const int grid = 2 * a.ntiles < 512 ? 2 * a.ntiles : 512;   // == ava_conv_wgrad_grid; the matrix-core kernels may launch fewer
   const int tw = tile_w(a.Wo);
   hipStream_t st = to_stream(s);
   if (use_mfma()) {
@@ -601,7 +602,7 @@ extern "C" int ava_conv_wgrad_rows(int B, int Hi, int Wi, int Cin, int Cout, int
   a.Wo = mode == MODE_S1 ? Wi : (mode == MODE_DOWN ? Wi / 2 : Wi * 2);
   a.ntiles = conv_geometry(B, a.Ho, a.Wo, &a.tiles_y, &a.tiles_x);
   if (a.ntiles <= 0) return AVA_EINVAL;
-  const int grid = a.ntiles < 512 ? a.ntiles : 512;
+  const int grid = 2 * a.ntiles < 512 ? 2 * a.ntiles : 512;
   if (use_mfma()) {
     const int rows = ava_conv3x3_wgrad_mfma(a, grid, Cin, Cout, mode, dy_pro, nullptr);   // partials == NULL: query
     if (rows > 0) return rows;

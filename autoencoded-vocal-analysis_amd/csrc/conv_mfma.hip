@@ -590,7 +590,7 @@ static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
   b.tiles_y = a.Ho / TH;
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
-  if (grid > b.ntiles) return AVA_EINVAL;
+  if (grid > b.ntiles) grid = b.ntiles;
   static const int resident = ava_resident_grid(kernel, lds);
   if (grid > resident) grid = resident;          // one resident wave of workgroups = partial rows written
   { const char* e = getenv("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
@@ -612,9 +612,9 @@ int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int 
   AVA_WGM_CASE(8, 16, MODE_S1, 32, 8)
   AVA_WGM_CASE(16, 16, MODE_DOWN, 32, 4)
   AVA_WGM_CASE(16, 24, MODE_S1, 32, 4)
-  AVA_WGM_CASE(24, 24, MODE_DOWN, 16, 8)
-  AVA_WGM_CASE(24, 32, MODE_S1, 16, 16)
-  AVA_WGM_CASE(32, 24, MODE_S1, 16, 16)
+  AVA_WGM_CASE(24, 24, MODE_DOWN, 16, 4)
+  AVA_WGM_CASE(24, 32, MODE_S1, 16, 8)
+  AVA_WGM_CASE(32, 24, MODE_S1, 16, 8)
   AVA_WGM_CASE(24, 24, MODE_UP, 32, 8)
   AVA_WGM_CASE(24, 16, MODE_S1, 32, 4)
   AVA_WGM_CASE(16, 16, MODE_UP, 32, 8)

@@ -342,8 +342,9 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 
 template <bool A_KMAJ, bool B_KMAJ>
 __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx, const int by) {
-  __shared__ float red[3][64][4];
-  __shared__ float cred[4][16];
+  __shared__ float red[7][64][4];             // up to 8 waves (long K): waves 1.. hand their tile to wave 0
+  __shared__ float cred[8][16];
+  const int nw = blockDim.x >> 6;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = lane & 15, kg = lane >> 4;
   const int m0 = by * 16, n0 = bx * 16;
@@ -356,11 +357,11 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
   f32x4g acc = {0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
   constexpr int U = 4;                            // chunks in flight per wave (8 measured slower)
-  for (int c0 = wave; c0 < nchunks; c0 += 4 * U) {
+  for (int c0 = wave; c0 < nchunks; c0 += nw * U) {
     f32x4g a[U], b[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = 16 * (c0 + 4 * u) + 4 * kg;
+      const int k = 16 * (c0 + nw * u) + 4 * kg;
       if (A_KMAJ) {                               // K % 4 == 0: a quad is inside or outside as a whole
         const bool ok = k < g.K;
         a[u] = *reinterpret_cast<const f32x4g*>(arow + (ok ? k : 0));
@@ -399,7 +400,11 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
   }
   __syncthreads();
   if (wave != 0) return;
-  if (do_colsum && kg == 0 && m0 + i < g.M) g.colsum[m0 + i] = (cred[0][i] + cred[1][i]) + (cred[2][i] + cred[3][i]);
+  if (do_colsum && kg == 0 && m0 + i < g.M) {
+    float cs = cred[0][i];
+    for (int w = 1; w < nw; ++w) cs += cred[w][i];
+    g.colsum[m0 + i] = cs;
+  }
   const int gn = n0 + i;
   if (gn >= g.N) return;
   const float bv = g.bias != nullptr ? g.bias[gn] : 0.f;
@@ -407,7 +412,8 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
   for (int r = 0; r < 4; ++r) {
     const int gm = m0 + 4 * kg + r;
     if (gm < g.M) {
-      float v = ((acc[r] + red[0][lane][r]) + red[1][lane][r]) + red[2][lane][r];
+      float v = acc[r];
+      for (int w = 0; w + 1 < nw; ++w) v += red[w][lane][r];          // wave order: deterministic
       v = apply_act(v + bv, g.act);
       if (g.mask != nullptr && !(g.mask[(size_t)gm * g.ldc + gn] > 0.f)) v = 0.f;
       g.C[(size_t)gm * g.ldc + gn] = v;
@@ -416,7 +422,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
 }
 
 template <bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmArgs g) {
   gemm_skinny_body<A_KMAJ, B_KMAJ>(g, blockIdx.x, blockIdx.y);
 }
 
@@ -433,7 +439,7 @@ static bool skinny_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
 }
 
 template <bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(256) void gemm_skinny_grouped_kernel(const GemmGroup grp) {
+__global__ __launch_bounds__(512) void gemm_skinny_grouped_kernel(const GemmGroup grp) {
   int p = 0;
   while (p + 1 < grp.n && (int)blockIdx.x >= grp.tile0[p + 1]) ++p;        // flat tile index -> (problem, tile)
   const GemmArgs& g = grp.g[p];
@@ -500,10 +506,11 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   if (skinny_ok(g, a_kmajor, b_kmajor)) {
     g.C = C;
     const dim3 sgrid(ceil_div(N, 16), ceil_div(M, 16));
-    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), sgrid, dim3(256), 0, st, g);
-    else if (a_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), sgrid, dim3(256), 0, st, g);
-    else if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), sgrid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), sgrid, dim3(256), 0, st, g);
+    const dim3 sblock(K >= 512 ? 512 : 256);          // long K: eight waves share the K range of a tile
+    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), sgrid, sblock, 0, st, g);
+    else if (a_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), sgrid, sblock, 0, st, g);
+    else if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), sgrid, sblock, 0, st, g);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), sgrid, sblock, 0, st, g);
     AVA_CHECK_LAUNCH();
     return AVA_OK;
   }

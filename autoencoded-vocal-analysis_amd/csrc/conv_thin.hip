@@ -661,7 +661,9 @@ int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
   if (mode != MODE_S1 || Wi != THIN_W || Hi % THIN_TH != 0) return 0;
   if (!((Cin == 1 && Cout == 8) || (Cin == 8 && Cout == 1))) return 0;
   const int nt = B * (Hi / THIN_TH);
-  const int cap = Cin == 1 ? 768 : 512;                  // resident workgroups (3 resp. 2 per CU): one wave of them
+  static const int env1 = [] { const char* e = getenv("AVA_THIN_GRID1"); return (e && atoi(e) >= 8) ? atoi(e) : 768; }();
+  static const int env8 = [] { const char* e = getenv("AVA_THIN_GRID8"); return (e && atoi(e) >= 8) ? atoi(e) : 512; }();
+  const int cap = Cin == 1 ? env1 : env8;                // resident workgroups (3 resp. 2 per CU): one wave of them
   return nt < cap ? nt : cap;
 }
 

@@ -1,0 +1,248 @@
+// Wave-specialised forward convolution (default for the forward layers; AVA_CONV_WS=0 falls back to
+// conv3x3_mfma_kernel).  512 threads per workgroup: waves 0-3 only stage
+// tiles (global -> registers -> BatchNorm prologue -> LDS), waves 4-7 only multiply (weights in registers, MFMA,
+// bias/ReLU/statistics epilogue), on two LDS tile buffers.  Every SIMD then hosts one staging wave and one matrix-core
+// wave of the workgroup, so the VALU/LDS-write work of tile k+1 runs beside the MFMAs of tile k instead of before them.
+// Same arguments, tiles, MSPLIT / PAIR variants and partial-row format as conv3x3_mfma_kernel (EPI_FWD, PRO_BN).
+// Measured: 3-8 % per kernel, 27 us per step over the eleven forward shapes.
+#include <stdlib.h>
+#include <type_traits>
+#include "conv_mfma.h"
+
+template <int CIN, int COUT, int MODE, int TW, int TH, bool MSPLIT, bool PAIR>
+__global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) {
+  using G = Geom<MODE, TW, TH>;
+  constexpr int IR = G::IR, IC = G::IC;
+  constexpr int MTA = (COUT + 15) / 16;             // cout tiles of the layer
+  constexpr int MT = MSPLIT ? 1 : MTA;              // cout tiles of one matrix-core wave (see conv3x3_mfma_kernel)
+  static_assert(!MSPLIT || MTA == 2, "MSPLIT deals exactly two cout tiles to the wave pairs");
+  static_assert(!PAIR || (MODE == MODE_S1 && COUT == 8 && !MSPLIT && TH % 2 == 0), "PAIR: stride 1, 8 output channels");
+  constexpr int NCLS = n_classes<MODE>();
+  constexpr int TILE_F = IR * IC * CIN;
+  extern __shared__ __align__(16) float smem[];
+  float* tile0 = smem;                      // two tile buffers
+  float* coef = smem + 2 * TILE_F;          // [3][32]
+  float* red = coef + 96;                   // [4][2*16*MTA]
+
+  const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
+  const bool stager = wave8 < 4;
+  const int wave = wave8 & 3;
+  const int n = lane & 15, kg = lane >> 4;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
+    coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
+  }
+  auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
+    b = tl / (a.tiles_y * a.tiles_x);
+    const int rem = tl - b * (a.tiles_y * a.tiles_x);
+    oy0 = (rem / a.tiles_x) * TH;
+    ox0 = (rem % a.tiles_x) * TW;
+    if (MODE == MODE_S1) { gy0 = oy0 - 1; gx0 = ox0 - 1; }
+    else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
+    else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
+  };
+  TileWalk walk(a.ntiles);
+  __syncthreads();                          // coef[] visible
+
+  if (stager) {
+    // ---------------- staging waves (threadIdx.x 0..255, exactly what TileStager assumes) ----------------
+    TileStager<CIN, PRO_BN, IR, IC> stg;
+    stg.init();
+    int b, oy0, ox0, gy0, gx0;
+    if (walk.valid()) {
+      origin(walk.cur, b, oy0, ox0, gy0, gx0);
+      stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+      stg.store(tile0, coef);                                   // tile 0 -> buffer 0
+      if (walk.has_next()) {
+        origin(walk.next(), b, oy0, ox0, gy0, gx0);
+        stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);         // tile 1 in flight
+      }
+    }
+    __syncthreads();                                            // (A) tile 0 ready
+    int it = 0;
+    for (; walk.valid(); walk.advance(), ++it) {
+      // while the matrix-core waves multiply tile `it`, store tile it+1 and fetch tile it+2
+      if (walk.has_next()) {
+        stg.store(tile0 + ((it + 1) & 1) * TILE_F, coef);
+        const int nn = walk.next() + walk.step;
+        if (nn < walk.end) {
+          origin(nn, b, oy0, ox0, gy0, gx0);
+          stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+        }
+      }
+      __syncthreads();                                          // (B) tile it consumed, tile it+1 ready
+    }
+    if (MSPLIT) __syncthreads();                                // (Z) zero-fill barrier of the matrix-core waves
+    __syncthreads();                                            // (C) matches the statistics barrier below
+    __syncthreads();
+    return;
+  }
+
+  // ---------------- matrix-core waves ----------------
+  const int mtb = MSPLIT ? (wave & 1) : 0;  // first cout tile of this wave
+  const int wp = wave >> 1;                 // MSPLIT: which half of the pixel groups
+  typename std::conditional<PAIR, PairFrag<CIN, IC>, ClassFrag<CIN, COUT, MODE, 0, IC, MT>>::type f0;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT> f1;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT> f2;
+  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT> f3;
+  constexpr int SP = MODE == MODE_DOWN ? 2 : 1;
+  f0.init(a.G, lane, SP * n * CIN, mtb);
+  if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
+  const int lane_out = PAIR ? ((kg >> 1) * a.Wo + n) * COUT + 4 * (kg & 1) : (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
+  const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;
+  float bias[MT][4], s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * (mtb + mt) + cq + r;
+      bias[mt][r] = co < COUT ? a.bias[co] : 0.f;
+      s1[mt][r] = s2[mt][r] = 0.f;
+      asm volatile("" ::"v"(bias[mt][r]));
+    }
+  constexpr int GROUPS = PAIR ? (TH / 2) * (TW / 16) : ((MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16));
+  constexpr int GPW = MSPLIT ? GROUPS / 2 : GROUPS / 4;
+  static_assert(GROUPS % 4 == 0 && (!MSPLIT || MODE != MODE_UP || GROUPS % 8 == 0), "tile must split evenly");
+  auto group_of = [&](int gi) -> int {
+    if (!MSPLIT) return wave * GPW + gi;
+    if (MODE == MODE_UP) return 8 * (gi >> 2) + 4 * wp + (gi & 3);
+    return wp + 2 * gi;
+  };
+  auto group_out = [&](int g) -> int {
+    if (MODE == MODE_UP) return (((2 * (g >> 2)) + ((g & 3) >> 1)) * a.Wo + (g & 1)) * COUT;
+    constexpr int GPR = TW / 16;
+    return (((PAIR ? 2 : 1) * (g / GPR)) * a.Wo + 16 * (g % GPR)) * COUT;
+  };
+  __syncthreads();                                              // (A)
+  int it = 0;
+  for (; walk.valid(); walk.advance(), ++it) {
+    int b, oy0, ox0, gy0, gx0;
+    origin(walk.cur, b, oy0, ox0, gy0, gx0);
+    const float* tile = tile0 + (it & 1) * TILE_F;
+    const size_t tile_pix = ((size_t)b * a.Ho + oy0) * a.Wo + ox0;
+    float* __restrict__ obase = a.out + tile_pix * COUT;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int g = group_of(gi);
+      f32x4 acc[2][MT];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MODE == MODE_UP) {
+        const int cls = gi & 3, r = g >> 2;
+        const float* px = tile + r * IC * CIN;
+        if (cls == 0) f0.run(px, acc);
+        else if (cls == 1) f1.run(px, acc);
+        else if (cls == 2) f2.run(px, acc);
+        else f3.run(px, acc);
+      } else {
+        constexpr int GPR = TW / 16;
+        constexpr int S = (MODE == MODE_S1 && !PAIR) ? 1 : 2;
+        constexpr int SX = MODE == MODE_DOWN ? 2 : 1;
+        f0.run(tile + (S * (g / GPR) * IC + SX * 16 * (g % GPR)) * CIN, acc);
+      }
+      const int gout = group_out(g) + lane_out;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb = 16 * (mtb + mt) + cq;
+        if (cb < COUT) {
+          f32x4 v = acc[0][mt] + acc[1][mt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = fmaxf(v[r] + bias[mt][r], 0.f);
+            v[r] = x;
+            s1[mt][r] += x;
+            s2[mt][r] = fmaf(x, x, s2[mt][r]);
+          }
+          *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    __syncthreads();                                            // (B)
+  }
+  // ---- per-workgroup partial statistics (matrix-core waves only) ----
+  if (MSPLIT) {                              // a wave only fills its own cout tile: the other slots must read as 0
+    const int tz = t - 256;
+    if (tz < 4 * 32 * MTA / 2) { red[tz] = 0.f; red[tz + 4 * 32 * MTA / 2] = 0.f; }
+    __syncthreads();                         // the staging waves take part: see (Z) in their branch
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v1 = s1[mt][r], v2 = s2[mt][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+      if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }
+      if (n == 0 && (!PAIR || kg < 2)) {
+        const int co = 16 * (mtb + mt) + cq + r;
+        red[wave * 32 * MTA + co] = v1;
+        red[wave * 32 * MTA + 16 * MTA + co] = v2;
+      }
+    }
+  __syncthreads();                                              // (C)
+  const int tc = t - 256;
+  if (tc < 2 * COUT && a.partials != nullptr) {
+    const int which = tc / COUT, co = tc - which * COUT;
+    const int idx = which * 16 * MTA + co;
+    a.partials[(size_t)blockIdx.x * 2 * COUT + tc] =
+        (red[idx] + red[32 * MTA + idx]) + (red[64 * MTA + idx] + red[96 * MTA + idx]);
+    for (int r = gridDim.x + blockIdx.x; r < a.part_rows; r += gridDim.x) a.partials[(size_t)r * 2 * COUT + tc] = 0.f;
+  }
+  __syncthreads();
+}
+
+template <int CIN, int COUT, int MODE, int TW, int TH>
+int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
+  using G = Geom<MODE, TW, TH>;
+  constexpr int MT = (COUT + 15) / 16;
+  constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // same rules as launch_mfma
+  constexpr bool PAIR = MODE == MODE_S1 && COUT == 8;
+  const size_t lds = (size_t)(2 * G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, TW, TH, MSPLIT, PAIR>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return AVA_ELAUNCH;
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.tiles_y = a.Ho / TH;
+  b.tiles_x = a.Wo / TW;
+  b.ntiles = a.B * b.tiles_y * b.tiles_x;
+  int per_cu = 1;
+  static int resident = 0;
+  if (resident == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, TW, TH, MSPLIT, PAIR>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    resident = per_cu * 256;
+  }
+  b.part_rows = grid;
+  if (grid > b.ntiles) grid = b.ntiles;
+  if (grid > resident) grid = resident;
+  { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
+  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, TW, TH, MSPLIT, PAIR>), dim3(grid), dim3(512), lds, st, b);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+// shapes tried: the 8/16-channel forward layers without row pairing / cout split
+int ava_conv3x3_mfma_ws(const ConvArgs& a, int grid, int Cin, int Cout, int mode, hipStream_t st) {
+  const int tw = a.Wo >= 32 ? 32 : 16;
+#define AVA_WS_CASE(ci, co, md, tww, thh) \
+  if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_mfma_ws<ci, co, md, tww, thh>(a, grid, st);
+  AVA_WS_CASE(8, 8, MODE_DOWN, 32, 4)
+  AVA_WS_CASE(8, 16, MODE_S1, 32, 8)
+  AVA_WS_CASE(16, 16, MODE_DOWN, 32, 4)
+  AVA_WS_CASE(16, 24, MODE_S1, 32, 4)
+  AVA_WS_CASE(24, 24, MODE_DOWN, 16, 4)
+  AVA_WS_CASE(32, 24, MODE_S1, 16, 8)
+  AVA_WS_CASE(24, 24, MODE_UP, 32, 8)
+  AVA_WS_CASE(24, 16, MODE_S1, 32, 4)
+  AVA_WS_CASE(16, 16, MODE_UP, 32, 8)
+  AVA_WS_CASE(16, 8, MODE_S1, 32, 8)
+  AVA_WS_CASE(8, 8, MODE_UP, 32, 8)
+#undef AVA_WS_CASE
+  return AVA_EINVAL;
+}

@@ -9,7 +9,7 @@
 #include <type_traits>
 #include "conv_mfma.h"
 
-template <int CIN, int COUT, int MODE, int TW, int TH, bool MSPLIT, bool PAIR>
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR>
 __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) {
   using G = Geom<MODE, TW, TH>;
   constexpr int IR = G::IR, IC = G::IC;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
 
   if (stager) {
     // ---------------- staging waves (threadIdx.x 0..255, exactly what TileStager assumes) ----------------
-    TileStager<CIN, PRO_BN, IR, IC> stg;
+    TileStager<CIN, PRO, IR, IC> stg;
     stg.init();
     int b, oy0, ox0, gy0, gx0;
     if (walk.valid()) {
@@ -91,15 +91,17 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
   const int lane_out = PAIR ? ((kg >> 1) * a.Wo + n) * COUT + 4 * (kg & 1) : (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
   const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;
-  float bias[MT][4], s1[MT][4], s2[MT][4];
+  float bias[MT][4], emean[MT][4], einv[MT][4], s1[MT][4], s2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = 16 * (mtb + mt) + cq + r;
-      bias[mt][r] = co < COUT ? a.bias[co] : 0.f;
+      bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
+      emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
+      einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
       s1[mt][r] = s2[mt][r] = 0.f;
-      asm volatile("" ::"v"(bias[mt][r]));
+      asm volatile("" ::"v"(bias[mt][r]), "v"(emean[mt][r]), "v"(einv[mt][r]));
     }
   constexpr int GROUPS = PAIR ? (TH / 2) * (TW / 16) : ((MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16));
   constexpr int GPW = MSPLIT ? GROUPS / 2 : GROUPS / 4;
@@ -114,6 +116,23 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     constexpr int GPR = TW / 16;
     return (((PAIR ? 2 : 1) * (g / GPR)) * a.Wo + 16 * (g % GPR)) * COUT;
   };
+  // EPI_BWD: raw x at this lane's output pixels (BatchNorm-backward sums), fetched one tile ahead by the matrix-core
+  // waves themselves (they hold no staging registers)
+  avaf4 exn[EPI == EPI_BWD ? GPW * MT : 1];
+  auto load_ex = [&](int tl) {
+    int b, oy0, ox0, gy0, gx0;
+    origin(tl, b, oy0, ox0, gy0, gx0);
+    const float* __restrict__ xb = a.epi_x + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * COUT;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb = 16 * (mtb + mt) + cq;
+        exn[gi * MT + mt] = *reinterpret_cast<const avaf4*>(
+            xb + group_out(group_of(gi)) + (cb < COUT ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
+      }
+  };
+  if (EPI == EPI_BWD && walk.valid()) load_ex(walk.cur);
   __syncthreads();                                              // (A)
   int it = 0;
   for (; walk.valid(); walk.advance(), ++it) {
@@ -121,7 +140,13 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     origin(walk.cur, b, oy0, ox0, gy0, gx0);
     const float* tile = tile0 + (it & 1) * TILE_F;
     const size_t tile_pix = ((size_t)b * a.Ho + oy0) * a.Wo + ox0;
-    float* __restrict__ obase = a.out + tile_pix * COUT;
+    float* __restrict__ obase = a.out != nullptr ? a.out + tile_pix * COUT : nullptr;
+    avaf4 ex[GPW * MT];
+    if (EPI == EPI_BWD) {
+#pragma unroll
+      for (int i = 0; i < GPW * MT; ++i) ex[i] = exn[i];
+      if (walk.has_next()) load_ex(walk.next());
+    }
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       const int g = group_of(gi);
@@ -149,14 +174,25 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         const int cb = 16 * (mtb + mt) + cq;
         if (cb < COUT) {
           f32x4 v = acc[0][mt] + acc[1][mt];
+          if (EPI == EPI_FWD) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x = fmaxf(v[r] + bias[mt][r], 0.f);
-            v[r] = x;
-            s1[mt][r] += x;
-            s2[mt][r] = fmaf(x, x, s2[mt][r]);
+            for (int r = 0; r < 4; ++r) {
+              const float x = fmaxf(v[r] + bias[mt][r], 0.f);
+              v[r] = x;
+              s1[mt][r] += x;
+              s2[mt][r] = fmaf(x, x, s2[mt][r]);
+            }
+          } else {
+            const avaf4 xr = ex[gi * MT + mt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float xh = (xr[r] - emean[mt][r]) * einv[mt][r];
+              s1[mt][r] += v[r];
+              s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+            }
           }
-          *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+          if (obase != nullptr)
+            *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -194,7 +230,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   __syncthreads();
 }
 
-template <int CIN, int COUT, int MODE, int TW, int TH>
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
 int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   constexpr int MT = (COUT + 15) / 16;
@@ -203,7 +239,7 @@ int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
   const size_t lds = (size_t)(2 * G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, TW, TH, MSPLIT, PAIR>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
@@ -215,28 +251,37 @@ int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
   int per_cu = 1;
   static int resident = 0;
   if (resident == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, TW, TH, MSPLIT, PAIR>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     resident = per_cu * 256;
   }
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
   if (grid > resident) grid = resident;
   { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
-  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, TW, TH, MSPLIT, PAIR>), dim3(grid), dim3(512), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
-// shapes tried: the 8/16-channel forward layers without row pairing / cout split
-int ava_conv3x3_mfma_ws(const ConvArgs& a, int grid, int Cin, int Cout, int mode, hipStream_t st) {
+template <int CIN, int COUT, int MODE, int TW, int TH>
+static int launch_ws_pe(const ConvArgs& a, int grid, int pro, int epi, hipStream_t st) {
+  if (pro == PRO_BN && epi == EPI_FWD) return launch_mfma_ws<CIN, COUT, MODE, PRO_BN, EPI_FWD, TW, TH>(a, grid, st);
+  if (pro == PRO_BWD && epi == EPI_BWD) return launch_mfma_ws<CIN, COUT, MODE, PRO_BWD, EPI_BWD, TW, TH>(a, grid, st);
+  if (pro == PRO_ID && epi == EPI_BWD) return launch_mfma_ws<CIN, COUT, MODE, PRO_ID, EPI_BWD, TW, TH>(a, grid, st);
+  return AVA_EINVAL;
+}
+
+// the same shape table as ava_conv3x3_mfma
+int ava_conv3x3_mfma_ws(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
   const int tw = a.Wo >= 32 ? 32 : 16;
 #define AVA_WS_CASE(ci, co, md, tww, thh) \
-  if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_mfma_ws<ci, co, md, tww, thh>(a, grid, st);
+  if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_ws_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
   AVA_WS_CASE(8, 8, MODE_DOWN, 32, 4)
   AVA_WS_CASE(8, 16, MODE_S1, 32, 8)
   AVA_WS_CASE(16, 16, MODE_DOWN, 32, 4)
   AVA_WS_CASE(16, 24, MODE_S1, 32, 4)
   AVA_WS_CASE(24, 24, MODE_DOWN, 16, 4)
+  AVA_WS_CASE(24, 32, MODE_S1, 16, 8)
   AVA_WS_CASE(32, 24, MODE_S1, 16, 8)
   AVA_WS_CASE(24, 24, MODE_UP, 32, 8)
   AVA_WS_CASE(24, 16, MODE_S1, 32, 4)

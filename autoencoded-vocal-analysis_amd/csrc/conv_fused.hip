@@ -303,19 +303,329 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
   for (int e = t; e < NW + CO; e += 256) prow[e] = wacc[e];
 }
 
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
+__global__ __launch_bounds__(512) void conv3x3_bwd_fused_ws_kernel(const FusedArgs a) {
+  using FG = FGeom<LMODE, TW, TH>;
+  constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
+  constexpr int BMODE = LMODE == MODE_S1 ? MODE_S1 : (LMODE == MODE_DOWN ? MODE_UP : MODE_DOWN);   // gather pattern of dx
+  constexpr int MT = (CI + 15) / 16;        // dx channel tiles
+  constexpr int NT = (CO + 15) / 16;        // dG column tiles
+  constexpr int NW = 9 * CI * CO;
+  constexpr int BCLS = n_classes<BMODE>(), WCLS = n_classes<LMODE>();
+  // stride-1 layers with 8 input channels: the data gradient has 8 output channels -> two dx rows per MFMA tile
+  constexpr bool PAIR = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
+  extern __shared__ __align__(16) float smem[];
+  // two buffers of {x tile [XR*XC*CI], dU tile [DR*DC*CO] + 16 floats of zero pad}
+  constexpr int XF = XR * XC * CI, BUF_F = XF + DR * DC * CO + 16;
+  float* cx = smem + 2 * BUF_F;              // [3][32]
+  float* cd = cx + 96;                       // [3][32]
+  float* red = cd + 96;                      // [4][32*MT]
+
+  const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
+  const bool stager = wave8 < 4;             // waves 0-3 stage tiles, waves 4-7 run the two matrix-core phases
+  const int wave = wave8 & 3;
+  const int n = lane & 15, kg = lane >> 4;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
+    cx[t] = (sx != nullptr && c < CI) ? sx[c] : 0.f;
+    cd[t] = (sd != nullptr && c < CO) ? sd[c] : 0.f;
+  }
+  if (t < 32) smem[(t >> 4) * BUF_F + XF + DR * DC * CO + (t & 15)] = 0.f;
+
+  // tile -> image, low-resolution origin, window origins
+  auto origin = [&](int tl, int& b, int& y0, int& x0) {
+    b = tl / (a.tiles_y * a.tiles_x);
+    const int rem = tl - b * (a.tiles_y * a.tiles_x);
+    y0 = (rem / a.tiles_x) * TH;
+    x0 = (rem % a.tiles_x) * TW;
+  };
+  auto x_origin = [&](int y0, int x0, int& gy, int& gx) {
+    if (LMODE == MODE_S1) { gy = y0 - 1; gx = x0 - 1; }
+    else if (LMODE == MODE_DOWN) { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
+    else { gy = y0; gx = x0; }
+  };
+  auto d_origin = [&](int y0, int x0, int& gy, int& gx) {
+    if (LMODE == MODE_S1) { gy = y0 - 1; gx = x0 - 1; }
+    else if (LMODE == MODE_DOWN) { gy = y0; gx = x0; }
+    else { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
+  };
+  TileWalk walk(a.ntiles);
+  __syncthreads();                           // cx / cd / zero pads visible
+
+  if (stager) {
+    // ---------------- staging waves (threadIdx.x 0..255: what TileStager assumes) ----------------
+    TileStager<CI, PRO_BN, XR, XC> sx;
+    TileStager<CO, DYPRO, DR, DC> sd;
+    sx.init();
+    sd.init();
+    auto prefetch = [&](int tl) {
+      int b, y0, x0, gy, gx;
+      origin(tl, b, y0, x0);
+      x_origin(y0, x0, gy, gx);
+      sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy, gx);
+      d_origin(y0, x0, gy, gx);
+      sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
+    };
+    if (walk.valid()) {
+      prefetch(walk.cur);
+      sx.store(smem, cx);
+      sd.store(smem + XF, cd);
+      if (walk.has_next()) prefetch(walk.next());
+    }
+    __syncthreads();                                            // (A) tile 0 ready
+    int it = 0;
+    for (; walk.valid(); walk.advance(), ++it) {
+      if (walk.has_next()) {                                    // tile it+1 -> the other buffer, tile it+2 in flight
+        float* nb = smem + ((it + 1) & 1) * BUF_F;
+        sx.store(nb, cx);
+        sd.store(nb + XF, cd);
+        const int nn = walk.next() + walk.step;
+        if (nn < walk.end) prefetch(nn);
+      }
+      __syncthreads();                                          // (B)
+    }
+    for (int i = 0; i < 7; ++i) __syncthreads();                // the seven barriers of the reductions below
+    return;
+  }
+
+  // ---------------- matrix-core waves ----------------
+  // ---- backward-data fragments: the flipped/packed weights stay in registers for the whole kernel ----
+  constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
+  typename std::conditional<PAIR, PairFrag<CO, DC>, ClassFrag<CO, CI, BMODE, 0, DC>>::type f0;
+  ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC> f1;
+  ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 2 : 0), DC> f2;
+  ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 3 : 0), DC> f3;
+  f0.init(a.Gb, lane, SPB * n * CO);
+  if (BCLS > 1) { f1.init(a.Gb, lane, n * CO); f2.init(a.Gb, lane, n * CO); f3.init(a.Gb, lane, n * CO); }
+  const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
+  const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
+  float emean[MT][4], einv[MT][4], s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = 16 * mt + cq + r;
+      emean[mt][r] = ci < CI ? a.mean[ci] : 0.f;
+      einv[mt][r] = ci < CI ? a.invstd[ci] : 0.f;
+      s1[mt][r] = s2[mt][r] = 0.f;
+      asm volatile("" ::"v"(emean[mt][r]), "v"(einv[mt][r]));      // retire before the tile loop (see ClassFrag::init)
+    }
+
+  // ---- weight-gradient accumulators (persist over all tiles of this workgroup) ----
+  WClass<CI, CO, LMODE, 0, XC> w0;
+  WClass<CI, CO, LMODE, (WCLS > 1 ? 1 : 0), XC> w1;
+  WClass<CI, CO, LMODE, (WCLS > 1 ? 2 : 0), XC> w2;
+  WClass<CI, CO, LMODE, (WCLS > 1 ? 3 : 0), XC> w3;
+  w0.init(lane);
+  if (WCLS > 1) { w1.init(lane); w2.init(lane); w3.init(lane); }
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  // pixel groups of the dx region: 16 consecutive pixels of a row (UP pattern: of one parity class)
+  constexpr int CB = FG::OW / (BMODE == MODE_UP ? 32 : 16);          // column blocks
+  constexpr int GROUPS = PAIR ? (FG::OH / 2) * CB : (BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB);
+  constexpr int GPW = GROUPS / 4;
+  static_assert(GROUPS % 4 == 0 && (BMODE != MODE_UP || GPW % 4 == 0), "tile must split evenly over the 4 waves");
+  // offset (floats, relative to the dx region's first pixel) and LDS pixel base of group g
+  auto group_out = [&](int g) -> int {
+    if (BMODE == MODE_UP) {
+      const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
+      return ((2 * r + (cls >> 1)) * a.Wi + 32 * cb + (cls & 1)) * CI;
+    }
+    return (((PAIR ? 2 : 1) * (g / CB)) * a.Wi + 16 * (g % CB)) * CI;
+  };
+
+  // raw x at this lane's dx pixels (BatchNorm-backward sums).  Loaded one tile ahead, AFTER the tile's data-gradient
+  // phase has consumed the previous values: the lines were requested by the window prefetch a moment earlier, so
+  // this hits L2, and the loads ride under the weight-gradient phase.
+  avaf4 ex[GPW * MT];
+  auto load_ex = [&](int tl) {
+    int b, y0, x0;
+    origin(tl, b, y0, x0);
+    const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+    const float* __restrict__ xb = a.x + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb4 = 16 * mt + cq;
+        // lanes whose 4-channel slot lies beyond CI re-read slot 0: stays in bounds
+        ex[gi * MT + mt] = *reinterpret_cast<const avaf4*>(
+            xb + group_out(wave * GPW + gi) + (cb4 < CI ? lane_out + 16 * mt : lane_out - 4 * kg));
+      }
+  };
+
+  if (walk.valid()) load_ex(walk.cur);
+  __syncthreads();                                              // (A)
+  int it = 0;
+  for (; walk.valid(); walk.advance(), ++it) {
+    int b, y0, x0;
+    origin(walk.cur, b, y0, x0);
+    const float* xt = smem + (it & 1) * BUF_F;
+    const float* dut = xt + XF;
+    const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+    const size_t tile_pix = ((size_t)b * a.Hi + oy0) * a.Wi + ox0;
+    float* __restrict__ obase = a.dx + tile_pix * CI;
+
+    // ---- phase 1: data gradient of the tile + BatchNorm-backward sums ----
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int g = wave * GPW + gi;
+      f32x4 acc[2][MT];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (BMODE == MODE_UP) {
+        const int cls = gi & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;   // GPW % 4 == 0: cls is compile-time
+        const float* px = dut + (r * DC + 16 * cb) * CO;
+        if (cls == 0) f0.run(px, acc);
+        else if (cls == 1) f1.run(px, acc);
+        else if (cls == 2) f2.run(px, acc);
+        else f3.run(px, acc);
+      } else {
+        constexpr int S = (BMODE == MODE_S1 && !PAIR) ? 1 : 2;        // PAIR: a group is a pair of dx rows
+        constexpr int SX = BMODE == MODE_DOWN ? 2 : 1;
+        f0.run(dut + (S * (g / CB) * DC + SX * 16 * (g % CB)) * CO, acc);
+      }
+      const int gout = group_out(g) + lane_out;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cb4 = 16 * mt + cq;
+        if (cb4 < CI) {
+          const f32x4 v = acc[0][mt] + acc[1][mt];
+          const avaf4 xr = ex[gi * MT + mt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xh = (xr[r] - emean[mt][r]) * einv[mt][r];
+            s1[mt][r] += v[r];
+            s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+          }
+          *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+
+    if (walk.has_next()) load_ex(walk.next());
+
+    // ---- phase 2: weight / bias gradient over the tile's interior dU pixels ----
+    if (LMODE == MODE_UP) {
+      // x-space rows r = wave + 4 rr, columns c = 4 s + kg; the four output-parity classes of each x pixel
+#pragma unroll 1
+      for (int rr = 0; rr < TH / 4; ++rr) {
+        const int r = wave + 4 * rr;
+#pragma unroll 1
+        for (int s = 0; s < TW / 4; ++s) {
+          const int c = 4 * s + kg;
+          const float* xa = xt + (r * XC + c) * CI;
+#pragma unroll
+          for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            const float* bp = dut + ((2 * r + py + DOFF) * DC + 2 * c + px + DOFF) * CO + n;
+            float bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (16 * nt + n < CO) ? bf[nt] : 0.f; }
+            if (cls == 0) w0.step(xa, bf);
+            else if (cls == 1) w1.step(xa, bf);
+            else if (cls == 2) w2.step(xa, bf);
+            else w3.step(xa, bf);
+          }
+        }
+      }
+    } else {
+      constexpr int S = LMODE == MODE_S1 ? 1 : 2;
+      constexpr int RPW = TH / 4;                 // dU rows per wave
+#pragma unroll 1
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int ty = wave * RPW + rr;
+#pragma unroll 1
+        for (int s = 0; s < TW / 4; ++s) {
+          const int x = 4 * s + kg;
+          const float* bp = dut + ((ty + DOFF) * DC + x + DOFF) * CO + n;
+          float bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { bf[nt] = bp[16 * nt]; bsum[nt] += (16 * nt + n < CO) ? bf[nt] : 0.f; }
+          w0.step(xt + ((S * ty) * XC + S * x) * CI, bf);
+        }
+      }
+    }
+    __syncthreads();                                            // (B)
+  }
+
+  // ---- BatchNorm-backward partial sums: over the 16 pixel lanes, then over the 4 waves (fixed order) ----
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v1 = s1[mt][r], v2 = s2[mt][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+      if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair
+      if (n == 0 && (!PAIR || kg < 2)) {
+        const int ci = 16 * mt + cq + r;
+        red[wave * 32 * MT + ci] = v1;
+        red[wave * 32 * MT + 16 * MT + ci] = v2;
+      }
+    }
+  __syncthreads();
+  const int tc = t - 256;
+  if (tc < 2 * CI) {
+    const int which = tc / CI, ci = tc - which * CI;
+    const int idx = which * 16 * MT + ci;
+    a.bn_partials[(size_t)blockIdx.x * 2 * CI + tc] =
+        (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]);
+  }
+  __syncthreads();
+
+  // ---- weight-gradient partial row: the four waves summed through LDS in a fixed order ----
+  float* wacc = smem;                             // [NW + CO], aliases the tiles (all reads are done)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsum[nt] += __shfl_xor(bsum[nt], 16, 64);
+    bsum[nt] += __shfl_xor(bsum[nt], 32, 64);
+  }
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      w0.flush(wacc, lane, w == 0);
+      if (WCLS > 1) { w1.flush(wacc, lane, w == 0); w2.flush(wacc, lane, w == 0); w3.flush(wacc, lane, w == 0); }
+      if (kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = 16 * nt + n;
+          if (co < CO) wacc[NW + co] = (w == 0) ? bsum[nt] : wacc[NW + co] + bsum[nt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* prow = a.wg_partials + (size_t)blockIdx.x * (NW + CO);
+  for (int e = tc; e < NW + CO; e += 256) prow[e] = wacc[e];
+}
+
 // ------------------------------------------------------------------------------------------------
+static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap);
+
 template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
 static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int MT = (CI + 15) / 16;
-  const size_t tiles_f = (size_t)FG::XR * FG::XC * CI + FG::DR * FG::DC * CO + 16 + 192 + 4 * 32 * MT;
+  // wave-specialised variant (staging waves beside matrix-core waves, two tile buffers) where it wins: fused_defaults
+  bool ws; int cap_unused;
+  fused_defaults(CI, CO, LMODE, &ws, &cap_unused);
+  const size_t buf_f = (size_t)FG::XR * FG::XC * CI + FG::DR * FG::DC * CO + 16;
+  const size_t tiles_f = (ws ? 2 : 1) * buf_f + 192 + 4 * 32 * MT;
   const size_t red_f = (size_t)9 * CI * CO + CO;
   const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
+  const void* kfn = ws ? reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>)
+                       : reinterpret_cast<const void*>(&conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return AVA_ELAUNCH;
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVA_ELAUNCH;
     attr_set = true;
   }
   FusedArgs b = a;
@@ -325,7 +635,8 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   b.tiles_x = wl / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
-  hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(256), lds, st, b);
+  if (ws) hipLaunchKernelGGL((conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(512), lds, st, b);
+  else hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
@@ -352,6 +663,21 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   X(8, 8, MODE_UP, 1, 16, 4, 3)    \
   X(8, 8, MODE_UP, 2, 32, 4, 3)
 
+// Which shapes run the wave-specialised kernel, and with how many workgroups (= partial rows).  Measured at batch 256
+// (tools/fused_bench.py): the 8->8 layers gain 10-25 % (their matrix-core waves drop to 116-154 VGPRs), conv4 4 %,
+// the other three lose a few percent and stay on the plain kernel.  AVA_FUSED_WS=0 / 1 forces all off / on.
+static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap) {
+  *ws = false; *cap = 512;
+  if (Cin == 8 && Cout == 8 && mode == MODE_DOWN) { *ws = true; *cap = 256; }
+  if (Cin == 8 && Cout == 8 && mode == MODE_UP) { *ws = true; *cap = 512; }
+  if (Cin == 16 && Cout == 16 && mode == MODE_DOWN) { *ws = true; *cap = 256; }
+  static const int force = [] { const char* e = getenv("AVA_FUSED_WS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  if (force == 0) { *ws = false; *cap = 512; }
+  if (force == 1) *ws = true;
+  static const int gcap = [] { const char* e = getenv("AVA_FUSED_GRID"); return (e && atoi(e) >= 8) ? atoi(e) : 0; }();
+  if (gcap > 0) *cap = gcap;
+}
+
 static int fused_variant() {
   static const int v = [] { const char* e = getenv("AVA_FUSED_VAR"); return e ? atoi(e) : 0; }();
   return v;
@@ -374,8 +700,9 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
   const int hl = mode == MODE_DOWN ? Hi / 2 : Hi, wl = mode == MODE_DOWN ? Wi / 2 : Wi;
   if (hl % th != 0 || wl % tw != 0) return 0;
   const int nt = B * (hl / th) * (wl / tw);
-  static const int cap = [] { const char* e = getenv("AVA_FUSED_GRID"); return (e && atoi(e) >= 8) ? atoi(e) : 512; }();
-  return nt < cap ? nt : cap;                 // 512 = two resident workgroups per CU (sweep: 384 / 768 / 1024 are slower)
+  bool ws; int cap;
+  fused_defaults(Cin, Cout, mode, &ws, &cap);   // 512 = two resident 256-thread workgroups per CU (384 / 768 / 1024 are slower)
+  return nt < cap ? nt : cap;
 }
 
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {

@@ -644,8 +644,8 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
 // shapes with a fused instantiation: (cin, cout, mode, variant) -> low-resolution tile, occupancy hint.
 // Variant 0 is the one the model driver runs; the others are kept for tools/fused_bench.py (AVA_FUSED_VAR=n).
 #define AVA_FUSED_SHAPES(X)        \
-  X(8, 8, MODE_DOWN, 0, 32, 4, 2)  \
-  X(8, 8, MODE_DOWN, 1, 16, 4, 2)  \
+  X(8, 8, MODE_DOWN, 0, 16, 4, 2)  \
+  X(8, 8, MODE_DOWN, 1, 32, 4, 2)  \
   X(8, 8, MODE_DOWN, 2, 16, 4, 3)  \
   X(8, 16, MODE_S1, 0, 32, 8, 2)   \
   X(8, 16, MODE_S1, 1, 16, 8, 2)   \
@@ -653,8 +653,8 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   X(16, 16, MODE_DOWN, 0, 16, 4, 2) \
   X(16, 16, MODE_DOWN, 1, 32, 4, 2) \
   X(16, 16, MODE_DOWN, 2, 16, 8, 2) \
-  X(16, 16, MODE_UP, 0, 32, 4, 2)  \
-  X(16, 16, MODE_UP, 1, 16, 4, 2)  \
+  X(16, 16, MODE_UP, 0, 16, 4, 2)  \
+  X(16, 16, MODE_UP, 1, 32, 4, 2)  \
   X(16, 16, MODE_UP, 2, 16, 4, 3)  \
   X(16, 8, MODE_S1, 0, 32, 8, 2)   \
   X(16, 8, MODE_S1, 1, 16, 8, 2)   \
@@ -664,13 +664,14 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   X(8, 8, MODE_UP, 2, 32, 4, 3)
 
 // Which shapes run the wave-specialised kernel, and with how many workgroups (= partial rows).  Measured at batch 256
-// (tools/fused_bench.py): the 8->8 layers gain 10-25 % (their matrix-core waves drop to 116-154 VGPRs), conv4 4 %,
-// the other three lose a few percent and stay on the plain kernel.  AVA_FUSED_WS=0 / 1 forces all off / on.
+// (tools/fused_bench.py): the 8->8 layers gain 10-25 % (their matrix-core waves drop to 116-154 VGPRs), conv4 / convt4 4-15 %,
+// conv3 and convt5 lose a few percent and stay on the plain kernel.  AVA_FUSED_WS=0 / 1 forces all off / on.
 static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap) {
   *ws = false; *cap = 512;
-  if (Cin == 8 && Cout == 8 && mode == MODE_DOWN) { *ws = true; *cap = 256; }
+  if (Cin == 8 && Cout == 8 && mode == MODE_DOWN) { *ws = true; *cap = 512; }    // 16x4 tiles: 126 VGPRs, 2 workgroups / CU
   if (Cin == 8 && Cout == 8 && mode == MODE_UP) { *ws = true; *cap = 512; }
   if (Cin == 16 && Cout == 16 && mode == MODE_DOWN) { *ws = true; *cap = 256; }
+  if (Cin == 16 && Cout == 16 && mode == MODE_UP) { *ws = true; *cap = 512; }    // 16x4 tiles: 128 VGPRs
   static const int force = [] { const char* e = getenv("AVA_FUSED_WS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
   if (force == 0) { *ws = false; *cap = 512; }
   if (force == 1) *ws = true;

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
 }
 
 template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
-__global__ __launch_bounds__(512) void conv3x3_bwd_fused_ws_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(512, (CI == 16 && CO == 16 && LMODE == MODE_DOWN) ? 2 : 4) void conv3x3_bwd_fused_ws_kernel(const FusedArgs a) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
   constexpr int BMODE = LMODE == MODE_S1 ? MODE_S1 : (LMODE == MODE_DOWN ? MODE_UP : MODE_DOWN);   // gather pattern of dx
@@ -647,31 +647,32 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   X(8, 8, MODE_DOWN, 0, 16, 4, 2)  \
   X(8, 8, MODE_DOWN, 1, 32, 4, 2)  \
   X(8, 8, MODE_DOWN, 2, 16, 4, 3)  \
-  X(8, 16, MODE_S1, 0, 32, 8, 2)   \
+  X(8, 16, MODE_S1, 0, 32, 4, 2)   \
   X(8, 16, MODE_S1, 1, 16, 8, 2)   \
-  X(8, 16, MODE_S1, 2, 32, 4, 2)   \
+  X(8, 16, MODE_S1, 2, 32, 8, 2)   \
   X(16, 16, MODE_DOWN, 0, 16, 4, 2) \
   X(16, 16, MODE_DOWN, 1, 32, 4, 2) \
   X(16, 16, MODE_DOWN, 2, 16, 8, 2) \
   X(16, 16, MODE_UP, 0, 16, 4, 2)  \
   X(16, 16, MODE_UP, 1, 32, 4, 2)  \
   X(16, 16, MODE_UP, 2, 16, 4, 3)  \
-  X(16, 8, MODE_S1, 0, 32, 8, 2)   \
+  X(16, 8, MODE_S1, 0, 32, 4, 2)   \
   X(16, 8, MODE_S1, 1, 16, 8, 2)   \
-  X(16, 8, MODE_S1, 2, 32, 4, 2)   \
+  X(16, 8, MODE_S1, 2, 32, 8, 2)   \
   X(8, 8, MODE_UP, 0, 32, 4, 2)    \
   X(8, 8, MODE_UP, 1, 16, 4, 3)    \
   X(8, 8, MODE_UP, 2, 32, 4, 3)
 
 // Which shapes run the wave-specialised kernel, and with how many workgroups (= partial rows).  Measured at batch 256
-// (tools/fused_bench.py): the 8->8 layers gain 10-25 % (their matrix-core waves drop to 116-154 VGPRs), conv4 / convt4 4-15 %,
-// conv3 and convt5 lose a few percent and stay on the plain kernel.  AVA_FUSED_WS=0 / 1 forces all off / on.
+// (tools/fused_bench.py): every shape gains 4-25 % once its 512-thread workgroup fits 128 VGPRs, so that two are resident per
+// CU (launch bounds (512, 4); conv4's 16->16 DOWN needs 200 and runs one per CU).  AVA_FUSED_WS=0 / 1 forces all off / on.
 static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap) {
   *ws = false; *cap = 512;
   if (Cin == 8 && Cout == 8 && mode == MODE_DOWN) { *ws = true; *cap = 512; }    // 16x4 tiles: 126 VGPRs, 2 workgroups / CU
   if (Cin == 8 && Cout == 8 && mode == MODE_UP) { *ws = true; *cap = 512; }
   if (Cin == 16 && Cout == 16 && mode == MODE_DOWN) { *ws = true; *cap = 256; }
   if (Cin == 16 && Cout == 16 && mode == MODE_UP) { *ws = true; *cap = 512; }    // 16x4 tiles: 128 VGPRs
+  if (mode == MODE_S1) { *ws = true; *cap = 512; }                                // 32x4 tiles: 126 / 128 VGPRs (12 B spill for 16->8)
   static const int force = [] { const char* e = getenv("AVA_FUSED_WS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
   if (force == 0) { *ws = false; *cap = 512; }
   if (force == 1) *ws = true;

@@ -106,24 +106,27 @@ __device__ __forceinline__ avaf4 ava_load_f4_async(const float* p) {
 template <int N>
 __device__ __forceinline__ void ava_wait_vm0(avaf4 (&r)[N]) {}
 
-template <int CIN, int PRO, int R, int C, bool PLANES = false>
+template <int CIN, int PRO, int R, int C, bool PLANES = false, int NT = 256>
 struct TileStager {
   static_assert(CIN % 4 == 0, "vector staging needs a multiple of 4 channels");
   static constexpr int Q = CIN / 4;
   static constexpr int NV = R * C * Q;
-  static constexpr int NPF = (NV + 255) / 256;
+  static constexpr int NPF = (NV + NT - 1) / NT;
+  static_assert(NPF <= 32, "element masks are 32 bits wide");
   avaf4 v[NPF];
   avaf4 v2[PRO == PRO_BWD ? NPF : 1];
   int rc[NPF];          // (r << 16) | c of the owned window element (clamped duplicate for idle lanes)
   int q4[NPF];          // 4 * channel quad
   unsigned live;        // bit i: element i exists (idx < NV)
   unsigned inb;         // bit i: element i of the CURRENT register contents is inside the image
+  int tid;              // index of this thread among the NT staging threads
 
-  __device__ __forceinline__ void init() {
+  __device__ __forceinline__ void init(int tid_ = (int)threadIdx.x) {
     live = 0u;
+    tid = tid_;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      int idx = threadIdx.x + 256 * i;
+      int idx = tid + NT * i;
       if (idx < NV) live |= 1u << i;
       else idx = NV - 1;
       const int pix = idx / Q, q = idx - pix * Q;
@@ -158,7 +161,7 @@ struct TileStager {
     if (PRO == PRO_BWD) ava_wait_vm0(v2);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int idx = threadIdx.x + 256 * i;
+      const int idx = tid + NT * i;
       const float* ca = coef + q4[i];
       const avaf4 x = v[i];
       const avaf4 y = PRO == PRO_BWD ? v2[i] : x;

@@ -54,6 +54,25 @@ struct ThinWeights {
   }
 };
 
+// Packed-FMA helpers: two fp32 lanes per instruction (v_pk_fma_f32).  ThinPairWeights keeps the 72 weights of an
+// 8 -> 1 layer as 36 channel pairs in VECTOR registers (every lane the same value): as scalar-register pairs they do
+// not fit beside the kernel's other scalars and hipcc spills them to VGPR lanes (125 v_readlane + 89 v_writelane per tile
+// in the first version); the empty asm keeps hipcc from re-reading them from memory inside the tile loop.
+typedef float avaf2 __attribute__((ext_vector_type(2)));
+struct ThinPairWeights {
+  avaf2 w[9][4];                                        // [tap][channel pair]
+  __device__ __forceinline__ explicit ThinPairWeights(const float* __restrict__ G) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        avaf2 v = {G[tap * 8 + 2 * q], G[tap * 8 + 2 * q + 1]};
+        asm volatile("" : "+v"(v));
+        w[tap][q] = v;
+      }
+  }
+};
+
 // stage a 1-channel [10 x 130] window (origin row gy0, column -1) with the prologue applied
 template <int PRO>
 __device__ __forceinline__ void thin_stage1(float* __restrict__ lds, const float* __restrict__ in,
@@ -234,6 +253,123 @@ __global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
   }
   const float sv[2] = {s1, s2};
   thin_block_reduce<2>(sv, red, a.partials != nullptr ? a.partials + (size_t)blockIdx.x * 2 : nullptr);
+  thin_zero_rows<2>(a.partials, a.part_rows);
+}
+
+// Wave-specialised variant (512 threads, one workgroup per CU): waves 0-3 stage tile k+1 (global -> registers ->
+// prologue -> LDS buffer (k+1)&1) while waves 4-7 multiply tile k out of buffer k&1; one barrier per tile.  At the
+// barrier of tile k the staging waves have filled buffer k&1 and the compute waves have left buffer (k-1)&1, which
+// is the one the staging waves write next.  The next window's loads are issued right after the LDS writes, so they
+// are in flight for the whole period of a tile instead of being waited for back to back.
+template <int PRO, int EPI, int NS>
+__global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int TILE_F = THIN_IR * THIN_IC * 8;
+  float* coef = smem + 2 * TILE_F;                      // [3][32]
+  float* red = coef + 96;                               // [4][2]
+  const int t = threadIdx.x;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
+    coef[t] = (src != nullptr && c < 8) ? src[c] : 0.f;
+  }
+  const int tiles_y = a.Ho / THIN_TH;
+  float s1 = 0.f, s2 = 0.f;
+  if (t < NS) {
+    // ---- staging waves ----
+    TileStager<8, PRO, THIN_IR, THIN_IC, false, NS> stg;
+    stg.init(t);
+    TileWalk walk(a.ntiles);
+    if (walk.valid()) {
+      const int b = walk.cur / tiles_y, oy0 = (walk.cur - b * tiles_y) * THIN_TH;
+      stg.load(a.in, a.in2, b, a.Hi, a.Wi, oy0 - 1, -1);
+    }
+    __syncthreads();                                    // coefficients visible
+    for (int k = 0; walk.valid(); walk.advance(), k ^= 1) {
+      stg.store(smem + k * TILE_F, coef);
+      if (walk.has_next()) {
+        const int tn = walk.next();
+        const int b = tn / tiles_y, oy0 = (tn - b * tiles_y) * THIN_TH;
+        stg.load(a.in, a.in2, b, a.Hi, a.Wi, oy0 - 1, -1);
+      }
+      __syncthreads();                                  // buffer k full
+    }
+  } else {
+    // ---- compute waves ----
+    const int tc = t - NS, ty0 = (tc >> 7) * 4, x = tc & 127;
+    const ThinPairWeights W(a.G);                       // [9][8][1] as channel pairs
+    const float bias0 = EPI == EPI_SSE ? ava_uniform(a.bias[0]) : 0.f;
+    const float em0 = EPI == EPI_BWD ? ava_uniform(a.epi_mean[0]) : 0.f, ei0 = EPI == EPI_BWD ? ava_uniform(a.epi_invstd[0]) : 0.f;
+    __syncthreads();
+    int k = 0;
+    for (TileWalk walk(a.ntiles); walk.valid(); walk.advance(), k ^= 1) {
+      const int tl = walk.cur;
+      const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
+      const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+      float ex[4] = {0.f, 0.f, 0.f, 0.f};               // epilogue operand, requested before the wait for the tile
+      if (a.epi_x != nullptr) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ex[p] = a.epi_x[opix0 + (size_t)p * THIN_W];
+      }
+      __syncthreads();                                  // buffer k full
+      const float* tile = smem + k * TILE_F;
+      avaf2 acc2[4];                                    // even / odd input channels of the 4 output pixels
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc2[p] = avaf2{0.f, 0.f};
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        __builtin_amdgcn_sched_barrier(0);              // one tap column at a time (register pressure)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float* px = tile + ((ty0 + j) * THIN_IC + x + kx) * 8;
+          const avaf4 u = *reinterpret_cast<const avaf4*>(px);
+          const avaf4 v = *reinterpret_cast<const avaf4*>(px + 4);
+          const avaf2 in2[4] = {avaf2{u[0], u[1]}, avaf2{u[2], u[3]}, avaf2{v[0], v[1]}, avaf2{v[2], v[3]}};
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int p = j - ky;                       // output row fed by input row j through tap ky
+            if (p >= 0 && p < 4) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc2[p] = __builtin_elementwise_fma(in2[q], W.w[ky * 3 + kx][q], acc2[p]);
+            }
+          }
+        }
+      }
+      float acc[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[p] = acc2[p][0] + acc2[p][1];
+      if (EPI == EPI_SSE) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const size_t opix = opix0 + (size_t)p * THIN_W;
+          const float v = acc[p] + bias0;
+          if (a.epi_x != nullptr) {
+            const float r = v - ex[p];
+            a.out2[opix] = a.prec * r;
+            s1 = fmaf(r, r, s1);
+          }
+          if (a.out != nullptr) a.out[opix] = v;
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const size_t opix = opix0 + (size_t)p * THIN_W;
+          s1 += acc[p];
+          s2 = fmaf(acc[p], (ex[p] - em0) * ei0, s2);
+          if (a.out != nullptr) a.out[opix] = acc[p];
+        }
+      }
+    }
+  }
+  // ---- workgroup sums (compute waves 4..7 hold them), fixed order ----
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6;
+  const float r1 = wave_sum(s1), r2 = wave_sum(s2);
+  constexpr int W0 = NS / 64;                            // first compute wave
+  if (wave >= W0 && lane == 0) { red[(wave - W0) * 2] = r1; red[(wave - W0) * 2 + 1] = r2; }
+  __syncthreads();
+  if (t < 2 && a.partials != nullptr)
+    a.partials[(size_t)blockIdx.x * 2 + t] = (red[t] + red[2 + t]) + (red[4 + t] + red[6 + t]);
   thin_zero_rows<2>(a.partials, a.part_rows);
 }
 
@@ -559,11 +695,12 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
   }
   const float da = DYPRO == PRO_BWD ? a.da[0] : 0.f, db = DYPRO == PRO_BWD ? a.db[0] : 0.f,
               dc = DYPRO == PRO_BWD ? a.dc[0] : 0.f;
-  float acc[9][8], T = 0.f, R = 0.f, Cc = 0.f, K = 0.f;
+  avaf2 acc2[9][4];                                     // channel pairs: the 288 FMAs per tile issue as 144 v_pk_fma_f32
+  float T = 0.f, R = 0.f, Cc = 0.f, K = 0.f;
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
-    for (int ci = 0; ci < 8; ++ci) acc[k][ci] = 0.f;
+    for (int q = 0; q < 4; ++q) acc2[k][q] = avaf2{0.f, 0.f};
   const bool edge_col = x == 0 || x == THIN_W - 1;
   TileStager<8, PRO_BN, THIN_IR, THIN_IC, (THIN_PLANES != 0)> stg;
   stg.init();
@@ -592,20 +729,24 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
       K += edge_col ? v : 0.f;
     }
     Cc += edge_col ? strip : 0.f;
+    avaf2 dd[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dd[p] = avaf2{du[p], du[p]};
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const float* px = tile + ((ty0 + j) * THIN_IC + x + kx) * (THIN_PLANES ? 4 : 8);
-        const float4 u = *reinterpret_cast<const float4*>(px);
-        const float4 w4 = *reinterpret_cast<const float4*>(px + (THIN_PLANES ? THIN_IR * THIN_IC * 4 : 4));
-        const float in[8] = {u.x, u.y, u.z, u.w, w4.x, w4.y, w4.z, w4.w};
+        const avaf4 u = *reinterpret_cast<const avaf4*>(px);
+        const avaf4 v = *reinterpret_cast<const avaf4*>(px + (THIN_PLANES ? THIN_IR * THIN_IC * 4 : 4));
+        const avaf2 in2[4] = {avaf2{u[0], u[1]}, avaf2{u[2], u[3]}, avaf2{v[0], v[1]}, avaf2{v[2], v[3]}};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const int p = j - ky;
           if (p >= 0 && p < 4) {
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci) acc[ky * 3 + kx][ci] = fmaf(in[ci], du[p], acc[ky * 3 + kx][ci]);
+            for (int q = 0; q < 4; ++q)
+              acc2[ky * 3 + kx][q] = __builtin_elementwise_fma(in2[q], dd[p], acc2[ky * 3 + kx][q]);
           }
         }
       }
@@ -614,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
-    for (int ci = 0; ci < 8; ++ci) sv[k * 8 + ci] = acc[k][ci];
+    for (int ci = 0; ci < 8; ++ci) sv[k * 8 + ci] = acc2[k][ci >> 1][ci & 1];
   sv[72] = T;
   float* tot = smem + 4 * 73;                           // [73] behind the reduction scratch (tiles are dead)
   thin_block_reduce<73>(sv, smem, tot);
@@ -655,6 +796,11 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
     for (int tap = 0; tap < 9; ++tap) s += scratch[72 * which + tap * 8 + ci];
     a.bn_partials[(size_t)blockIdx.x * 16 + t] = s;
   }
+}
+
+static int thin_ws_mode() {
+  static const int ws = [] { const char* e = getenv("AVA_THIN_WS"); return e ? atoi(e) : 1; }();
+  return ws;
 }
 
 int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
@@ -708,6 +854,7 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
 // dispatch (called from conv.hip before the generic kernels); AVA_EINVAL = shape not handled here
 // ---------------------------------------------------------------------------------------------------------
 static const size_t kThin8Lds = (size_t)(THIN_IR * THIN_IC * 8 + 96 + 8) * sizeof(float);
+static const size_t kThin8WsLds = (size_t)(2 * THIN_IR * THIN_IC * 8 + 96 + 8) * sizeof(float);
 
 template <typename K>
 static int thin_set_lds(K kernel) {
@@ -735,7 +882,18 @@ int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, 
         return AVA_ELAUNCH;
       attr = true;
     }
-    if (pro == PRO_BN && epi == EPI_SSE) hipLaunchKernelGGL((thin_8to1_kernel<PRO_BN, EPI_SSE>), dim3(grid), dim3(256), kThin8Lds, st, a);
+    const int ws = thin_ws_mode();
+    if (ws != 0 && pro == PRO_BN && epi == EPI_SSE) {
+      static bool attr_ws = false;
+      if (!attr_ws) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThin8WsLds) != hipSuccess)
+          return AVA_ELAUNCH;
+        attr_ws = true;
+      }
+      const int g = grid < 256 ? grid : 256;              // one workgroup per CU
+      hipLaunchKernelGGL((thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>), dim3(g), dim3(512), kThin8WsLds, st, a);
+    } else if (pro == PRO_BN && epi == EPI_SSE) hipLaunchKernelGGL((thin_8to1_kernel<PRO_BN, EPI_SSE>), dim3(grid), dim3(256), kThin8Lds, st, a);
     else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<PRO_BWD, EPI_BWD>), dim3(grid), dim3(256), kThin8Lds, st, a);
     else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<PRO_ID, EPI_BWD>), dim3(grid), dim3(256), kThin8Lds, st, a);
     else return AVA_EINVAL;

@@ -29,7 +29,15 @@ for name, fin, fout in fc:
         for _ in range(n): run()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
+        # headroom probe: the vendor library (torch.mm -> rocBLAS / hipBLASLt) on the same product
+        At = A.view(M, K) if ak else A.view(K, M).t()
+        Bt = Bm.view(N, K).t() if bk else Bm.view(K, N)
+        for _ in range(3): torch.mm(At, Bt, out=C)
+        e0.record()
+        for _ in range(n): torch.mm(At, Bt, out=C)
+        e1.record(); torch.cuda.synchronize()
+        us_lib = e0.elapsed_time(e1) * 1e3 / n
         mult = 3 if name in ("fc4x",) else 1
         tot[kind] += us * mult
-        print("%-5s %-3s M=%5d N=%5d K=%5d  %7.1f us  %6.1f TFLOP/s  ws=%d MB" % (name, kind, M, N, K, us, 2.0 * M * N * K / us / 1e6, nbytes >> 20))
+        print("%-5s %-3s M=%5d N=%5d K=%5d  %7.1f us  %6.1f TFLOP/s  ws=%d MB   torch.mm %7.1f us" % (name, kind, M, N, K, us, 2.0 * M * N * K / us / 1e6, nbytes >> 20, us_lib))
 print(tot, sum(tot.values()))

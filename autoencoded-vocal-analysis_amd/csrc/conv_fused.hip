@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
 }
 
 template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
-__global__ __launch_bounds__(512, (CI == 16 && CO == 16 && LMODE == MODE_DOWN) ? 2 : 4) void conv3x3_bwd_fused_ws_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMODE == MODE_DOWN)) ? 2 : 4) void conv3x3_bwd_fused_ws_kernel(const FusedArgs a) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
   constexpr int BMODE = LMODE == MODE_S1 ? MODE_S1 : (LMODE == MODE_DOWN ? MODE_UP : MODE_DOWN);   // gather pattern of dx
@@ -660,6 +660,10 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   X(16, 8, MODE_S1, 1, 16, 8, 2)   \
   X(16, 8, MODE_S1, 2, 32, 8, 2)   \
   X(8, 8, MODE_UP, 0, 32, 4, 2)    \
+  X(16, 24, MODE_S1, 0, 32, 4, 1)  \
+  X(16, 24, MODE_S1, 1, 16, 4, 1)  \
+  X(24, 16, MODE_S1, 0, 32, 4, 1)  \
+  X(24, 16, MODE_S1, 1, 16, 4, 1)  \
   X(8, 8, MODE_UP, 1, 16, 4, 3)    \
   X(8, 8, MODE_UP, 2, 32, 4, 3)
 
@@ -673,6 +677,7 @@ static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap) {
   if (Cin == 16 && Cout == 16 && mode == MODE_DOWN) { *ws = true; *cap = 256; }
   if (Cin == 16 && Cout == 16 && mode == MODE_UP) { *ws = true; *cap = 512; }    // 16x4 tiles: 128 VGPRs
   if (mode == MODE_S1) { *ws = true; *cap = 512; }                                // 32x4 tiles: 126 / 128 VGPRs (12 B spill for 16->8)
+  if (mode == MODE_S1 && Cin * Cout > 256) { *ws = true; *cap = 256; }            // conv5 / convt3: one workgroup per CU
   static const int force = [] { const char* e = getenv("AVA_FUSED_WS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
   if (force == 0) { *ws = false; *cap = 512; }
   if (force == 1) *ws = true;

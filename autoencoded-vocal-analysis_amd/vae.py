@@ -29,6 +29,7 @@ from . import _lib
 from . import dist as _dist
 from .layout import X_SHAPE, X_DIM, param_specs, checkpoint_layer_order
 from .optim import FlatAdam
+from .feed import DeviceFeeder
 
 __all__ = ["VAE", "X_SHAPE", "X_DIM"]
 
@@ -79,6 +80,7 @@ class VAE(nn.Module):
         self.loss = {'train': {}, 'test': {}}
         # noise for rsample: None -> device counter RNG; or callable(B, z_dim) -> (eps_W [B,1], eps_D [B,z])
         self.noise_source = None
+        self.prefetch = True          # prefetch the next batch to the device on a copy stream in the epoch loops (feed.py)
         self._rng_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         self._rng_offset = 0
         self._handle = None
@@ -246,6 +248,13 @@ class VAE(nn.Module):
         self._max_batch = cap
         self._eps = torch.empty(cap * (self.z_dim + 1), dtype=torch.float32, device=self.device)
 
+    def _feed(self, loader):
+        """Batches of ``loader`` on the device, one batch ahead on a copy stream (``feed.DeviceFeeder``), unless
+        ``self.prefetch`` is False, in which case every batch is moved synchronously like vae.py:349 does."""
+        if getattr(self, "prefetch", True) and self.device.type == "cuda":
+            return DeviceFeeder(loader, self.device)
+        return loader
+
     def _prep_x(self, x):
         x = x.to(device=self.device, dtype=torch.float32)
         assert x.dim() == 3 and tuple(x.shape[1:]) == X_SHAPE, "expected [batch,128,128] spectrograms"
@@ -362,7 +371,7 @@ class VAE(nn.Module):
         self.train()
         self._loss_acc.zero_()
         batch_idx = -1
-        for batch_idx, data in enumerate(train_loader):
+        for batch_idx, data in enumerate(self._feed(train_loader)):
             self.optimizer.zero_grad()
             data = self._prep_x(data)
             self._forward_device(data, need_grad=True, accumulate=True)
@@ -380,7 +389,7 @@ class VAE(nn.Module):
         self.eval()
         self._loss_acc.zero_()
         with torch.no_grad():
-            for i, data in enumerate(test_loader):
+            for i, data in enumerate(self._feed(test_loader)):
                 data = self._prep_x(data)
                 self._forward_device(data, need_grad=False, accumulate=True)
         self._check_status()
@@ -454,7 +463,7 @@ class VAE(nn.Module):
         Like the reference this does not switch to eval mode."""
         latent = np.zeros((len(loader.dataset), self.z_dim))
         i = 0
-        for data in loader:
+        for data in self._feed(loader):
             with torch.no_grad():
                 mu, _, _ = self.encode(data)
             mu = mu.detach().cpu().numpy()

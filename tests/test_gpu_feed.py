@@ -1,0 +1,99 @@
+"""Pinned double-buffered host -> device feeding of the epoch loops (ava_amd/feed.py; replaces the synchronous
+``data.to(self.device)`` of vae.py:349 / 374 / 540).  The feeder must hand over bit-identical batches in loader
+order, cope with ragged / float64 / uint8 batches and early exits, surface loader errors, and leave the epoch
+loops' results bit-identical to the synchronous path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import build_model
+from ava_amd import synthetic as syn
+from ava_amd.feed import DeviceFeeder
+
+
+class _Loader:
+    """Minimal loader: an iterable of CPU tensors with ``.dataset`` (what train_epoch needs)."""
+
+    def __init__(self, batches):
+        self.batches = batches
+        self.dataset = list(range(sum(len(b) for b in batches)))
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def _batches(sizes, dtype=torch.float32):
+    out, start = [], 0
+    for n in sizes:
+        out.append(torch.from_numpy(syn.spectrograms(n, start_item=start)).to(dtype))
+        start += n
+    return out
+
+
+def test_feeder_yields_identical_batches_in_order():
+    sizes = [16, 16, 16, 16, 16, 16, 16, 5]                # more batches than slots, ragged tail
+    batches = _batches(sizes)
+    feeder = DeviceFeeder(_Loader(batches), "cuda", depth=2)
+    assert len(feeder) == len(batches) and len(feeder.dataset) == sum(sizes)
+    seen = []
+    for dev in feeder:
+        assert dev.is_cuda and dev.dtype == torch.float32
+        seen.append(dev.clone())                           # the slot is recycled after the next() call
+    assert len(seen) == len(batches)
+    for got, want in zip(seen, batches):
+        assert torch.equal(got.cpu(), want)
+
+
+def test_feeder_converts_dtypes_and_grows():
+    b64 = _batches([4, 9], torch.float64)                  # second batch larger than the first: slots regrow
+    got = [d.clone() for d in DeviceFeeder(_Loader(b64), "cuda")]
+    for g, w in zip(got, b64):
+        assert torch.equal(g.cpu(), w.to(torch.float32))
+    u8 = [(torch.rand(3, 128, 128) * 255).to(torch.uint8)]
+    got = [d.clone() for d in DeviceFeeder(_Loader(u8), "cuda")]
+    assert torch.equal(got[0].cpu(), u8[0].to(torch.float32))
+
+
+def test_feeder_early_exit_and_errors():
+    feeder = DeviceFeeder(_Loader(_batches([8] * 6)), "cuda", depth=2)
+    for i, dev in enumerate(feeder):
+        if i == 1:
+            break                                          # generator closed with batches still queued: no hang
+    def bad():
+        yield torch.zeros(2, 128, 128)
+        raise RuntimeError("loader failed")
+    class Bad:
+        dataset = [0, 1]
+        def __iter__(self):
+            return bad()
+    with pytest.raises(RuntimeError, match="loader failed"):
+        for _ in DeviceFeeder(Bad(), "cuda"):
+            pass
+    with pytest.raises(ValueError):
+        for _ in DeviceFeeder(_Loader([torch.zeros(2, 16384)]), "cuda"):
+            pass
+
+
+def test_epoch_loops_identical_with_and_without_prefetch():
+    B, nb, z = 8, 5, 32
+    batches = _batches([B] * (nb - 1) + [3])
+    results = []
+    for prefetch in (False, True):
+        model = build_model(z)
+        model.prefetch = prefetch
+        noise = [syn.noise(len(b), z, 2002 + k, 3003 + k) for k, b in enumerate(batches)] * 2
+        model.noise_source = lambda b, zz: noise.pop(0)
+        train = model.train_epoch(_Loader(batches))
+        test = model.test_epoch(_Loader(batches))
+        model.noise_source = None
+        lat = model.get_latent(_Loader(batches))
+        results.append((train, test, lat, model._params.detach().cpu().clone()))
+    (t0, e0, l0, p0), (t1, e1, l1, p1) = results
+    assert t0 == t1 and e0 == e1                            # same kernels, same inputs: bit-identical
+    assert np.array_equal(l0, l1) and l0.shape == (sum(len(b) for b in batches), z) and l0.dtype == np.float64
+    assert torch.equal(p0, p1)

@@ -67,16 +67,12 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
   if (BCLS > 1) { f1.init(a.Gb, lane, n * CO); f2.init(a.Gb, lane, n * CO); f3.init(a.Gb, lane, n * CO); }
   const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
   const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
-  float emean[MT][4], einv[MT][4], s1[MT][4], s2[MT][4];
+  float s1[MT][4], s2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ci = 16 * mt + cq + r;
-      emean[mt][r] = ci < CI ? a.mean[ci] : 0.f;
-      einv[mt][r] = ci < CI ? a.invstd[ci] : 0.f;
       s1[mt][r] = s2[mt][r] = 0.f;
-      asm volatile("" ::"v"(emean[mt][r]), "v"(einv[mt][r]));      // retire before the tile loop (see ClassFrag::init)
     }
 
   // ---- weight-gradient accumulators (persist over all tiles of this workgroup) ----
@@ -198,9 +194,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
           const avaf4 xr = ex[gi * MT + mt];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float xh = (xr[r] - emean[mt][r]) * einv[mt][r];
             s1[mt][r] += v[r];
-            s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+            s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
           }
           *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -259,6 +254,12 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v1 = s1[mt][r], v2 = s2[mt][r];
+      {
+        // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here: sum g*xhat = invstd * (sum g*x - mean * sum g)
+        const int cc = 16 * mt + cq + r;
+        const float mu = cc < CI ? a.mean[cc] : 0.f, is = cc < CI ? a.invstd[cc] : 0.f;
+        v2 = fmaf(-mu, v1, v2) * is;
+      }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
       if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair
@@ -401,16 +402,12 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   if (BCLS > 1) { f1.init(a.Gb, lane, n * CO); f2.init(a.Gb, lane, n * CO); f3.init(a.Gb, lane, n * CO); }
   const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
   const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
-  float emean[MT][4], einv[MT][4], s1[MT][4], s2[MT][4];
+  float s1[MT][4], s2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ci = 16 * mt + cq + r;
-      emean[mt][r] = ci < CI ? a.mean[ci] : 0.f;
-      einv[mt][r] = ci < CI ? a.invstd[ci] : 0.f;
       s1[mt][r] = s2[mt][r] = 0.f;
-      asm volatile("" ::"v"(emean[mt][r]), "v"(einv[mt][r]));      // retire before the tile loop (see ClassFrag::init)
     }
 
   // ---- weight-gradient accumulators (persist over all tiles of this workgroup) ----
@@ -500,9 +497,8 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
           const avaf4 xr = ex[gi * MT + mt];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float xh = (xr[r] - emean[mt][r]) * einv[mt][r];
             s1[mt][r] += v[r];
-            s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+            s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
           }
           *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -562,6 +558,12 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v1 = s1[mt][r], v2 = s2[mt][r];
+      {
+        // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here: sum g*xhat = invstd * (sum g*x - mean * sum g)
+        const int cc = 16 * mt + cq + r;
+        const float mu = cc < CI ? a.mean[cc] : 0.f, is = cc < CI ? a.invstd[cc] : 0.f;
+        v2 = fmaf(-mu, v1, v2) * is;
+      }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
       if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   if (!(a.dbg & 8)) f0.init(a.G, lane, SP * n * CIN, mtb);
   if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
   // epilogue constants for this lane's 4 output channels per cout tile
-  float bias[MT][4], emean[MT][4], einv[MT][4];
+  float bias[MT][4];
   float s1[MT][4], s2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -114,11 +114,9 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
     for (int r = 0; r < 4; ++r) {
       const int co = 16 * (mtb + mt) + cq + r;
       bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
-      emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
-      einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
       s1[mt][r] = s2[mt][r] = 0.f;
       // retire these loop-invariant loads before the tile loop (see ClassFrag::init)
-      asm volatile("" ::"v"(bias[mt][r]), "v"(emean[mt][r]), "v"(einv[mt][r]));
+      asm volatile("" ::"v"(bias[mt][r]));
     }
 
   for (; walk.valid(); walk.advance()) {
@@ -186,9 +184,8 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
             const float xv[4] = {xr[0], xr[1], xr[2], xr[3]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float xh = (xv[r] - emean[mt][r]) * einv[mt][r];
               s1[mt][r] += v[r];
-              s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+              s2[mt][r] = fmaf(v[r], xv[r], s2[mt][r]);      // raw x: centred after the loop
             }
           }
           if (obase != nullptr && !(a.dbg & 4))
@@ -219,6 +216,12 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v1 = s1[mt][r], v2 = s2[mt][r];
+      if (EPI == EPI_BWD) {
+        // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here: sum g*xhat = invstd * (sum g*x - mean * sum g)
+        const int cc = 16 * (mtb + mt) + cq + r;
+        const float mu = cc < COUT ? a.epi_mean[cc] : 0.f, is = cc < COUT ? a.epi_invstd[cc] : 0.f;
+        v2 = fmaf(-mu, v1, v2) * is;
+      }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
       if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair

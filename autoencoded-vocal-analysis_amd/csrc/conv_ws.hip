@@ -91,17 +91,15 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
   const int lane_out = PAIR ? ((kg >> 1) * a.Wo + n) * COUT + 4 * (kg & 1) : (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
   const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;
-  float bias[MT][4], emean[MT][4], einv[MT][4], s1[MT][4], s2[MT][4];
+  float bias[MT][4], s1[MT][4], s2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = 16 * (mtb + mt) + cq + r;
       bias[mt][r] = (EPI == EPI_FWD && co < COUT) ? a.bias[co] : 0.f;
-      emean[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_mean[co] : 0.f;
-      einv[mt][r] = (EPI == EPI_BWD && co < COUT) ? a.epi_invstd[co] : 0.f;
       s1[mt][r] = s2[mt][r] = 0.f;
-      asm volatile("" ::"v"(bias[mt][r]), "v"(emean[mt][r]), "v"(einv[mt][r]));
+      asm volatile("" ::"v"(bias[mt][r]));
     }
   constexpr int GROUPS = PAIR ? (TH / 2) * (TW / 16) : ((MODE == MODE_UP) ? TH * TW / 16 : TH * (TW / 16));
   constexpr int GPW = MSPLIT ? GROUPS / 2 : GROUPS / 4;
@@ -186,9 +184,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
             const avaf4 xr = ex[gi * MT + mt];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float xh = (xr[r] - emean[mt][r]) * einv[mt][r];
               s1[mt][r] += v[r];
-              s2[mt][r] = fmaf(v[r], xh, s2[mt][r]);
+              s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);      // raw x: centred after the loop
             }
           }
           if (obase != nullptr)
@@ -209,6 +206,12 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v1 = s1[mt][r], v2 = s2[mt][r];
+      if (EPI == EPI_BWD) {
+        // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here: sum g*xhat = invstd * (sum g*x - mean * sum g)
+        const int cc = 16 * (mtb + mt) + cq + r;
+        const float mu = cc < COUT ? a.epi_mean[cc] : 0.f, is = cc < COUT ? a.epi_invstd[cc] : 0.f;
+        v2 = fmaf(-mu, v1, v2) * is;
+      }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
       if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }

@@ -10,7 +10,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libava_hip.so")
+# AVA_HIP_LIB_TAG=x loads csrc/libava_hip_x.so instead: same-box A/B of two builds (tools/ab_prof.sh), nothing else
+_TAG = os.environ.get("AVA_HIP_LIB_TAG", "")
+LIB_PATH = os.path.join(CSRC, "libava_hip_%s.so" % _TAG if _TAG else "libava_hip.so")
 
 _ERR = {-1: "AVA_EINVAL (bad argument / unsupported shape)", -2: "AVA_ELAUNCH (HIP launch failure)",
         -3: "AVA_EWORKSPACE (workspace too small)"}

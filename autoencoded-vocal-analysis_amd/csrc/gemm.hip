@@ -171,23 +171,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   float csum = 0.f;   // column sum of A (bias gradient), thread t < BM owns column t
   const bool do_colsum = g.colsum != nullptr && bx == 0;
 
-  // software pipeline: tile k+1 travels global -> registers while tile k is multiplied out of LDS buffer
-  // (k & 1); it is written to the other buffer after the MFMAs, one barrier per K step.
+  // software pipeline: while K step k is multiplied out of LDS buffer (k & 1), tile k+1 (requested during step k-1)
+  // is written to the other buffer in the MIDDLE of the step's MFMA stream and the loads of tile k+2 are issued
+  // right behind it, so (i) the LDS writes and their wait for the loads sit under matrix-core work instead of
+  // between the last MFMA and the barrier, and (ii) a tile has 1.5 K steps (~2.5 us) to arrive.  Loads are
+  // unconditional (clamped addresses; tiles past the end are zeroed by the K mask at store time), which keeps
+  // hipcc's vmcnt accounting exact.  One barrier per K step.
+  const int kq = lane >> 5, li = lane & 31;
   if (kbeg < kend) {
     la.load(g.A, g.lda, g.M, kbeg, kend, g.K);
     lb.load(g.B, g.ldb, g.N, kbeg, kend, g.K);
     la.template store<LDA_S>(As2[0]);
     lb.template store<LDB_S>(Bs2[0]);
+    la.load(g.A, g.lda, g.M, kbeg + BK, kend, g.K);
+    lb.load(g.B, g.ldb, g.N, kbeg + BK, kend, g.K);
   }
   __syncthreads();
   int cur = 0;
-  const int kq = lane >> 5, li = lane & 31;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {
-      la.load(g.A, g.lda, g.M, k0 + BK, kend, g.K);
-      lb.load(g.B, g.ldb, g.N, k0 + BK, kend, g.K);
-    }
     const float* As = As2[cur];
     const float* Bs = Bs2[cur];
     if (do_colsum && t < BM) {
@@ -214,10 +215,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      la.template store<LDA_S>(As2[cur ^ 1]);
-      lb.template store<LDB_S>(Bs2[cur ^ 1]);
+      if (kk == BK / 2 - 2) {
+        // tile k+1 -> the other buffer (nobody reads it during this step), then request tile k+2
+        la.template store<LDA_S>(As2[cur ^ 1]);
+        lb.template store<LDB_S>(Bs2[cur ^ 1]);
+        la.load(g.A, g.lda, g.M, k0 + 2 * BK, kend, g.K);
+        lb.load(g.B, g.ldb, g.N, k0 + 2 * BK, kend, g.K);
+      }
     }
     __syncthreads();
     cur ^= 1;

@@ -461,12 +461,13 @@ class VAE(nn.Module):
     def get_latent(self, loader):
         """Latent means of everything in ``loader`` as float64 ``[N,z]`` (vae.py:519-547).
         Like the reference this does not switch to eval mode."""
-        latent = np.zeros((len(loader.dataset), self.z_dim))
+        n_total = len(loader.dataset)
+        latent_dev = torch.zeros(n_total, self.z_dim, device=self.device)     # one D2H copy at the end, no per-batch sync
         i = 0
         for data in self._feed(loader):
             with torch.no_grad():
                 mu, _, _ = self.encode(data)
-            mu = mu.detach().cpu().numpy()
-            latent[i:i + len(mu)] = mu
+            latent_dev[i:i + len(mu)] = mu
             i += len(mu)
+        latent = latent_dev.cpu().numpy().astype(np.float64)
         return latent

@@ -93,24 +93,39 @@ __device__ __forceinline__ void thin_stage1(float* __restrict__ lds, const float
 // ---------------------------------------------------------------------------------------------------------
 // 1 -> 8 channels: conv1 forward (PRO_BN, EPI_FWD), convt7 backward-data (PRO_ID, EPI_BWD)
 // ---------------------------------------------------------------------------------------------------------
+// Thread mapping: lane pair (2x, 2x+1) shares pixel column x of the 8-row tile; thread (x, h) owns output channels
+// 4h..4h+3 of all 8 rows.  Every store instruction of a wave is then 64 contiguous 16-byte slots (1 KB, full
+// lines); with one thread per pixel and two 16-byte stores per pixel each instruction wrote every other 16-byte
+// slot and the layer ran at 3.8 TB/s of a possible ~5.  Weights depend on h, so they live in vector registers
+// (36 per thread) as channel pairs for v_pk_fma_f32.
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];
-  __shared__ float red[4 * 16];
-  const int t = threadIdx.x, ty0 = (t >> 7) * 4, x = t & 127;      // pixels (ty0 + p, x), p = 0..3
+  __shared__ float red[4][2][8];
+  const int t = threadIdx.x, h = t & 1, x = t >> 1, lane = t & 63, wave = t >> 6;
   const float ca = a.pa ? a.pa[0] : 0.f, cb = a.pb ? a.pb[0] : 0.f, cc = a.pc ? a.pc[0] : 0.f;
-  const ThinWeights W(a.G);                          // [9][1][8]
-  float bias[8], emean[8], einv[8];                  // wave-uniform epilogue constants, read once (scalar registers)
+  avaf2 w2[9][2];                                    // [tap][channel pair of this half]
 #pragma unroll
-  for (int co = 0; co < 8; ++co) {
-    bias[co] = EPI == EPI_FWD ? ava_uniform(a.bias[co]) : 0.f;
-    emean[co] = EPI == EPI_BWD ? ava_uniform(a.epi_mean[co]) : 0.f;
-    einv[co] = EPI == EPI_BWD ? ava_uniform(a.epi_invstd[co]) : 0.f;
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      avaf2 v = {a.G[tap * 8 + 4 * h + 2 * q], a.G[tap * 8 + 4 * h + 2 * q + 1]};
+      asm volatile("" : "+v"(v));                    // read once: stores below may alias G as far as hipcc knows
+      w2[tap][q] = v;
+    }
+  avaf2 bias2[2], s1[2], s2[2];
+  float emean[4], einv[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    bias2[q] = EPI == EPI_FWD ? avaf2{a.bias[4 * h + 2 * q], a.bias[4 * h + 2 * q + 1]} : avaf2{0.f, 0.f};
+    s1[q] = s2[q] = avaf2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    emean[c] = EPI == EPI_BWD ? a.epi_mean[4 * h + c] : 0.f;
+    einv[c] = EPI == EPI_BWD ? a.epi_invstd[4 * h + c] : 0.f;
   }
   const bool relu = a.relu != 0;
-  float s1[8], s2[8];
-#pragma unroll
-  for (int co = 0; co < 8; ++co) s1[co] = s2[co] = 0.f;
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
     const int tl = walk.cur;
@@ -118,61 +133,61 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
     __syncthreads();
     thin_stage1<PRO>(tile, a.in, a.in2, ca, cb, cc, b, a.Hi, oy0 - 1);
     __syncthreads();
-    float acc[4][8];
+    avaf2 acc[THIN_TH][2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int co = 0; co < 8; ++co) acc[p][co] = 0.f;
+    for (int p = 0; p < THIN_TH; ++p) acc[p][0] = acc[p][1] = avaf2{0.f, 0.f};
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      float in[6];
+      float in[THIN_IR];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) in[j] = tile[(ty0 + j) * THIN_IC + x + kx];
+      for (int j = 0; j < THIN_IR; ++j) in[j] = tile[j * THIN_IC + x + kx];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int co = 0; co < 8; ++co) {
-          const float w = W.w[(ky * 3 + kx) * 8 + co];
+        for (int p = 0; p < THIN_TH; ++p) {
+          const avaf2 iv = {in[p + ky], in[p + ky]};
 #pragma unroll
-          for (int p = 0; p < 4; ++p) acc[p][co] = fmaf(in[p + ky], w, acc[p][co]);
+          for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_elementwise_fma(iv, w2[ky * 3 + kx][q], acc[p][q]);
         }
     }
-    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+    const size_t o0 = (((size_t)b * a.Ho + oy0) * THIN_W + x) * 8 + 4 * h;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const size_t opix = opix0 + (size_t)p * THIN_W - p;      // "+ p" below walks rows, not columns
+    for (int p = 0; p < THIN_TH; ++p) {
+      const size_t off = o0 + (size_t)p * THIN_W * 8;
+      avaf2 v0 = acc[p][0], v1 = acc[p][1];
       if (EPI == EPI_FWD) {
-#pragma unroll
-        for (int co = 0; co < 8; ++co) {
-          float v = acc[p][co] + bias[co];
-          if (relu) v = fmaxf(v, 0.f);
-          acc[p][co] = v;
-          s1[co] += v;
-          s2[co] = fmaf(v, v, s2[co]);
-        }
+        v0 += bias2[0]; v1 += bias2[1];
+        if (relu) { v0 = avaf2{fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)}; v1 = avaf2{fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)}; }
+        s1[0] += v0; s1[1] += v1;
+        s2[0] = __builtin_elementwise_fma(v0, v0, s2[0]);
+        s2[1] = __builtin_elementwise_fma(v1, v1, s2[1]);
       } else if (EPI == EPI_BWD) {
-        const float4 xa = *reinterpret_cast<const float4*>(a.epi_x + (opix + p) * 8);
-        const float4 xb = *reinterpret_cast<const float4*>(a.epi_x + (opix + p) * 8 + 4);
-        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-        for (int co = 0; co < 8; ++co) {
-          const float xh = (xv[co] - emean[co]) * einv[co];
-          s1[co] += acc[p][co];
-          s2[co] = fmaf(acc[p][co], xh, s2[co]);
-        }
+        const avaf4 xr = *reinterpret_cast<const avaf4*>(a.epi_x + off);
+        const avaf2 xh0 = {(xr[0] - emean[0]) * einv[0], (xr[1] - emean[1]) * einv[1]};
+        const avaf2 xh1 = {(xr[2] - emean[2]) * einv[2], (xr[3] - emean[3]) * einv[3]};
+        s1[0] += v0; s1[1] += v1;
+        s2[0] = __builtin_elementwise_fma(v0, xh0, s2[0]);
+        s2[1] = __builtin_elementwise_fma(v1, xh1, s2[1]);
       }
-      if (a.out != nullptr) {
-        float4* o = reinterpret_cast<float4*>(a.out + (opix + p) * 8);
-        o[0] = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
-        o[1] = make_float4(acc[p][4], acc[p][5], acc[p][6], acc[p][7]);
-      }
+      if (a.out != nullptr) *reinterpret_cast<avaf4*>(a.out + off) = avaf4{v0[0], v0[1], v1[0], v1[1]};
     }
   }
   if (EPI == EPI_NONE) return;
-  float sv[16];
+  // ---- per-channel sums: lanes of equal parity hold the same 4 channels; waves, then workgroup, fixed order ----
+  float sv[8] = {s1[0][0], s1[0][1], s1[1][0], s1[1][1], s2[0][0], s2[0][1], s2[1][0], s2[1][1]};
+  __syncthreads();
 #pragma unroll
-  for (int co = 0; co < 8; ++co) { sv[co] = s1[co]; sv[8 + co] = s2[co]; }
-  thin_block_reduce<16>(sv, red, a.partials != nullptr ? a.partials + (size_t)blockIdx.x * 16 : nullptr);
+  for (int i = 0; i < 8; ++i) {
+    float v = sv[i];
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane < 2) red[wave][lane][i] = v;              // lane = h
+  }
+  __syncthreads();
+  if (t < 16 && a.partials != nullptr) {
+    const int which = t >> 3, co = t & 7, hh = co >> 2, i = which * 4 + (co & 3);
+    a.partials[(size_t)blockIdx.x * 16 + t] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);
+  }
   thin_zero_rows<16>(a.partials, a.part_rows);
 }
 
@@ -831,7 +846,8 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
   ConvArgs c = {};
   c.in = a.dy; c.in2 = a.dy2; c.pa = a.da; c.pb = a.db; c.pc = a.dc; c.G = a.Gb; c.out = a.dx;
   c.B = a.B; c.Hi = a.Ho; c.Wi = a.Wo; c.Ho = a.Hi; c.Wo = a.Wi; c.ntiles = a.ntiles;
-  const int dgrid = a.ntiles < 2048 ? a.ntiles : 2048;   // no partial rows: free to use more, lighter workgroups
+  static const int dcap = [] { const char* e = getenv("AVA_THIN_DGRID"); return (e && atoi(e) >= 8) ? atoi(e) : 2048; }();
+  const int dgrid = a.ntiles < dcap ? a.ntiles : dcap;   // no partial rows: free to use more, lighter workgroups
   if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BWD, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
   else hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
   AVA_CHECK_LAUNCH();

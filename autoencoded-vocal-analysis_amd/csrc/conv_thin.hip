@@ -846,8 +846,14 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
   ConvArgs c = {};
   c.in = a.dy; c.in2 = a.dy2; c.pa = a.da; c.pb = a.db; c.pc = a.dc; c.G = a.Gb; c.out = a.dx;
   c.B = a.B; c.Hi = a.Ho; c.Wi = a.Wo; c.Ho = a.Hi; c.Wo = a.Wi; c.ntiles = a.ntiles;
-  static const int dcap = [] { const char* e = getenv("AVA_THIN_DGRID"); return (e && atoi(e) >= 8) ? atoi(e) : 2048; }();
-  const int dgrid = a.ntiles < dcap ? a.ntiles : dcap;   // no partial rows: free to use more, lighter workgroups
+  // no partial rows here, so the grid is free: one resident wave of workgroups (6 per CU at 76 VGPRs) is the fastest
+  // (in-step rocprof A/B: 768 / 1024 / 1536 / 2048 / 4096 workgroups -> 33.5 / 33.1 / 30.7 / 35.1 / 39.8 us)
+  static const int dcap = [] {
+    const char* e = getenv("AVA_THIN_DGRID");
+    if (e && atoi(e) >= 8) return atoi(e);
+    return ava_resident_grid(&thin_1to8_kernel<PRO_ID, EPI_NONE>, 0);
+  }();
+  const int dgrid = a.ntiles < dcap ? a.ntiles : dcap;
   if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BWD, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
   else hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
   AVA_CHECK_LAUNCH();

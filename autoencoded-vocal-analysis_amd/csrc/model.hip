@@ -36,11 +36,20 @@ enum { CAT_CONV_FWD = 0, CAT_CONV_BWD_DATA, CAT_CONV_WGRAD, CAT_BN, CAT_GEMM, CA
 #define PROF_MAX_EVENTS 1024
 struct Prof {
   bool on = false;
+  int mode = 0;                   // 1: an event after every launch group; 2: only where the kernel FAMILY changes
   int n = 0;
   hipEvent_t ev[PROF_MAX_EVENTS];
   int cat[PROF_MAX_EVENTS];
   int created = 0;
+  // family (conv+BatchNorm+pack = 0, everything else = 1, call begin = -1) of every mark of a step, learnt in mode 1
+  int seq_fam[PROF_MAX_EVENTS];
+  int seq_n = 0;
+  int idx = 0;                    // position in seq_fam of the next mark (mode 2)
 };
+static inline int prof_family(int cat) {
+  if (cat < 0) return -1;
+  return (cat == CAT_CONV_FWD || cat == CAT_CONV_BWD_DATA || cat == CAT_CONV_WGRAD || cat == CAT_BN || cat == CAT_PACK) ? 0 : 1;
+}
 
 struct ConvLayer {
   int cin, cout, mode, hi;        // forward gather mode, input height (= width)
@@ -289,6 +298,16 @@ extern "C" const float* ava_debug_buffer(ava_model* m, const char* name, int64_t
 static inline void mark(ava_model* m, int cat, hipStream_t st) {
   Prof& p = m->prof;
   if (!p.on || p.n >= PROF_MAX_EVENTS) return;
+  if (p.mode == 2) {
+    // coarse pass: ~100 event records per step stretch the step by 10-15 %; here an event is recorded only after the
+    // last launch group of a run of same-family kernels (sequence learnt by a mode-1 step), ~20 per step
+    const int i = p.idx++;
+    const bool known = i < p.seq_n && p.seq_fam[i] == prof_family(cat);
+    const bool boundary = !known || cat < 0 || i + 1 >= p.seq_n || p.seq_fam[i + 1] != p.seq_fam[i];
+    if (!boundary) return;
+  } else if (p.n < PROF_MAX_EVENTS) {
+    p.seq_fam[p.n] = prof_family(cat);
+  }
   if (p.n >= p.created) { if (hipEventCreate(&p.ev[p.created]) != hipSuccess) return; p.created++; }
   hipEventRecord(p.ev[p.n], st);
   p.cat[p.n] = cat;
@@ -298,7 +317,9 @@ static inline void mark(ava_model* m, int cat, hipStream_t st) {
 extern "C" int ava_profile_enable(ava_model* m, int on) {
   if (m == nullptr) return AVA_EINVAL;
   m->prof.on = on != 0;
+  m->prof.mode = on == 2 ? 2 : 1;
   m->prof.n = 0;
+  m->prof.idx = 0;
   return AVA_OK;
 }
 // synchronises on the last event, sums elapsed ms per category into ms[NCAT] (adds to it), returns the
@@ -315,7 +336,9 @@ extern "C" int ava_profile_read(ava_model* m, float* ms, int* launches) {
       if (launches) launches[p.cat[i]] += 1;
     }
   }
+  if (p.mode == 1 && p.n > 0) p.seq_n = p.n;      // the family sequence of one whole step, for the coarse mode
   p.n = 0;
+  p.idx = 0;
   return NCAT;
 }
 

@@ -91,7 +91,11 @@ const float* ava_debug_buffer(ava_model* m, const char* name, int64_t* floats);
 /* Optional timing of the driver's launches with HIP events recorded on the launch stream
  * (bench.py's roofline leg).  Categories, in order: conv forward, conv backward-data, conv weight-grad
  * (+ its reduction), BatchNorm statistics/finalise, GEMM, layout hand-offs, latent+ELBO, Adam, weight pack.
- * ava_profile_read adds elapsed milliseconds (and launch-group counts) per category and clears the list. */
+ * ava_profile_read adds elapsed milliseconds (and launch-group counts) per category and clears the list.
+ * on = 1: an event after every launch group (~100 per step; the records stretch the step by 10-15 %).
+ * on = 2: coarse pass, after at least one step was read in mode 1: events only where the kernel FAMILY changes
+ * (conv + BatchNorm + pack vs everything else, ~20 per step); a run's time is added to the category of its last
+ * launch group, so only the family sums are meaningful -- they are the un-stretched figures the roofline uses. */
 #define AVA_PROFILE_CATEGORIES 9
 int ava_profile_enable(ava_model* m, int on);
 int ava_profile_read(ava_model* m, float* ms, int* launches);

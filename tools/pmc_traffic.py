@@ -3,7 +3,8 @@
 MI355X_MICROARCH.md prescribes).  Counter values are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
 bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16 B/lane stores.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> > profiles/rNN/pmc_traffic.json
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [steps] > profiles/rNN/pmc_traffic.json
+(steps defaults to the number of adam_flat_kernel launches in the trace)
 """
 import collections, csv, json, sys
 
@@ -24,7 +25,8 @@ def per_kernel(path, counter):
 def main():
     fd = per_kernel(sys.argv[1], "FETCH_SIZE")
     wd = per_kernel(sys.argv[2], "WRITE_SIZE")
-    steps = int(sys.argv[3])
+    # steps in the trace = launches of the once-per-step Adam kernel (warm-up + timed + the event-instrumented passes of bench.py)
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else max(fd.get("adam_flat_kernel", [0])[0], wd.get("adam_flat_kernel", [0])[0])
     kernels = {}
     for k in sorted(set(fd) | set(wd)):
         calls = max(fd.get(k, [0, 0])[0], wd.get(k, [0, 0])[0])

@@ -255,6 +255,53 @@ def test_backward_in_parts_equals_whole():
     assert lib.ava_grad_bucket(model._handle, nparts, ctypes.byref(o), ctypes.byref(c)) != 0
 
 
+def test_profile_passes_agree():
+    """ava_profile_enable(1) brackets every launch group with HIP events, ava_profile_enable(2) only the runs of
+    same-family kernels (what bench.py's roofline uses): the coarse pass must record far fewer events, leave the results
+    untouched and attribute about the same time to the conv family (the fine pass is stretched by its own events)."""
+    import ctypes
+    from ava_amd import _lib
+    lib = _lib.load()
+    B, z = 64, 32
+    x = torch.from_numpy(syn.spectrograms(B)).cuda()
+    model = build_model(z)
+    fixed_noise(model, B, z)
+    model.train()
+
+    def step():
+        model.optimizer.zero_grad()
+        model._forward_device(x, need_grad=True)
+        model._backward_device(x)
+        model.optimizer.step()
+
+    step()
+    fam = (0, 1, 2, 3, 8)                                 # conv fwd / bwd-data / wgrad, BatchNorm, pack
+    out = {}
+    for mode in (1, 2):
+        ms = (ctypes.c_float * 16)()
+        cnt = (ctypes.c_int * 16)()
+        assert lib.ava_profile_enable(model._handle, mode) == 0
+        for _ in range(5):
+            step()
+            assert lib.ava_profile_read(model._handle, ms, cnt) == 9
+        lib.ava_profile_enable(model._handle, 0)
+        out[mode] = (sum(ms[i] for i in fam) / 5, sum(ms[i] for i in range(9)) / 5, sum(cnt[i] for i in range(9)) // 5)
+    (conv1, all1, n1), (conv2, all2, n2) = out[1], out[2]
+    assert n1 > 60 and 4 <= n2 <= 30, (n1, n2)
+    assert 0 < conv2 <= conv1 * 1.05 and conv2 > 0.6 * conv1, (conv1, conv2)
+    assert 0 < all2 <= all1 * 1.05, (all1, all2)
+    loss_profiled = float(model._loss_buf[0].item())
+    ref = build_model(z)
+    fixed_noise(ref, B, z)
+    ref.train()
+    for _ in range(11):
+        ref.optimizer.zero_grad()
+        ref._forward_device(x, need_grad=True)
+        ref._backward_device(x)
+        ref.optimizer.step()
+    assert float(ref._loss_buf[0].item()) == loss_profiled   # timing never changes results
+
+
 def test_harness_train_loop_checkpoint_golden(tmp_path):
     """train_epoch / test_epoch / train_loop side effects and the checkpoint layout (vae.py:330-472)."""
     G = load_golden("harness.npz")

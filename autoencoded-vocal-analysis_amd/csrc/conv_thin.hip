@@ -813,6 +813,139 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
   }
 }
 
+// "Direct" form of thin_wgrad_stats_8to1_kernel: the same correlation, indexed by the INPUT pixel q instead of the
+// output pixel p,   dG'[tap][ci] = sum_q xhat[q][ci] * dU[q - tap]   (dU zero outside the image),
+// so the 8-channel tensor x needs no neighbourhood and is read straight from global memory into registers by the
+// thread that owns the pixel (lane pairs share a pixel column, thread (x, h) owns channels 4h..4h+3 of the 8 rows of
+// the tile, exactly like thin_bwd_fused_1to8_kernel), and only the 1-channel dU window goes through LDS (5 KB).
+// The LDS-staged form keeps one 41.6 KB window per workgroup in flight and runs at 2.7 TB/s; this one has no staging
+// role at all, more resident workgroups and eight independent 16-byte loads per thread in flight.
+template <int DYPRO>
+__global__ __launch_bounds__(256) void thin_wgrad_stats_8to1_direct_kernel(const FusedArgs a) {
+  __shared__ float tile[THIN_IR * THIN_IC];             // dU window (prologue applied, zero outside the image)
+  __shared__ float red[4][2][36];                       // per wave, per channel half: dG' [9][4]
+  __shared__ float sc[4][9];                            // per wave: T, Rt, Rb, Cl, Cr, Ktl, Ktr, Kbl, Kbr
+  __shared__ float tot[2][36];
+  __shared__ float stot[9];
+  __shared__ float scratch[2][72];
+  const int t = threadIdx.x, h = t & 1, x = t >> 1, wave = t >> 6, lane = t & 63;
+  float ha[4], hb[4];                                   // xhat = ha * x + hb for this half's channels
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float is = a.invstd[4 * h + c];
+    ha[c] = is;
+    hb[c] = -a.mean[4 * h + c] * is;
+  }
+  const float da = DYPRO == PRO_BWD ? a.da[0] : 0.f, db = DYPRO == PRO_BWD ? a.db[0] : 0.f,
+              dc = DYPRO == PRO_BWD ? a.dc[0] : 0.f;
+  avaf2 acc[9][2];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k][0] = acc[k][1] = avaf2{0.f, 0.f};
+  float T = 0.f, Rt = 0.f, Rb = 0.f, Cl = 0.f, Cr = 0.f, Ktl = 0.f, Ktr = 0.f, Kbl = 0.f, Kbr = 0.f;
+  const float own = h == 0 ? 1.f : 0.f;                 // the scalar sums of dU are taken by one lane of each pair
+  const int tiles_y = a.Hi / THIN_TH;
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
+    const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
+    __syncthreads();
+    thin_stage1<DYPRO>(tile, a.dy, a.dy2, da, db, dc, b, a.Ho, oy0 - 1);
+    const size_t o0 = (((size_t)b * a.Hi + oy0) * THIN_W + x) * 8 + 4 * h;
+    avaf2 xh[THIN_TH][2];
+#pragma unroll
+    for (int r = 0; r < THIN_TH; ++r) {
+      const avaf4 v = *reinterpret_cast<const avaf4*>(a.x + o0 + (size_t)r * THIN_W * 8);
+      xh[r][0] = avaf2{fmaf(ha[0], v[0], hb[0]), fmaf(ha[1], v[1], hb[1])};
+      xh[r][1] = avaf2{fmaf(ha[2], v[2], hb[2]), fmaf(ha[3], v[3], hb[3])};
+    }
+    __syncthreads();
+    // sums of dU over this thread's column of the tile and the image-border rows / columns / corners
+    {
+      float col = 0.f;
+#pragma unroll
+      for (int r = 0; r < THIN_TH; ++r) col += tile[(r + 1) * THIN_IC + x + 1];
+      const float top = oy0 == 0 ? tile[1 * THIN_IC + x + 1] : 0.f;
+      const float bot = oy0 + THIN_TH == a.Ho ? tile[THIN_TH * THIN_IC + x + 1] : 0.f;
+      T += own * col;
+      Rt += own * top;
+      Rb += own * bot;
+      if (x == 0) { Cl += own * col; Ktl += own * top; Kbl += own * bot; }
+      if (x == THIN_W - 1) { Cr += own * col; Ktr += own * top; Kbr += own * bot; }
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float d[THIN_IR];
+#pragma unroll
+      for (int j = 0; j < THIN_IR; ++j) d[j] = tile[j * THIN_IC + x + 2 - kx];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int r = 0; r < THIN_TH; ++r) {
+          const avaf2 dv = {d[r + 2 - ky], d[r + 2 - ky]};
+#pragma unroll
+          for (int q = 0; q < 2; ++q) acc[ky * 3 + kx][q] = __builtin_elementwise_fma(xh[r][q], dv, acc[ky * 3 + kx][q]);
+        }
+    }
+  }
+  // ---- workgroup totals: dG' per channel half over lanes of equal parity, the nine scalar sums over all lanes ----
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float v = acc[k][q][e];
+#pragma unroll
+        for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane < 2) red[wave][lane][k * 4 + 2 * q + e] = v;
+      }
+  {
+    const float sv[9] = {T, Rt, Rb, Cl, Cr, Ktl, Ktr, Kbl, Kbr};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float r = wave_sum(sv[i]);
+      if (lane == 0) sc[wave][i] = r;
+    }
+  }
+  __syncthreads();
+  if (t < 72) {
+    const int hh = t / 36, i = t - 36 * hh;
+    tot[hh][i] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);
+  } else if (t < 81) {
+    const int i = t - 72;
+    stot[i] = (sc[0][i] + sc[1][i]) + (sc[2][i] + sc[3][i]);
+  }
+  __syncthreads();
+  if (t < 72) {
+    const int tap = t >> 3, ci = t & 7, hh = ci >> 2, c = ci & 3, ky = tap / 3, kx = tap - 3 * ky;
+    float S = stot[0];
+    if (ky == 0) S -= stot[1];
+    if (ky == 2) S -= stot[2];
+    if (kx == 0) S -= stot[3];
+    if (kx == 2) S -= stot[4];
+    if (ky == 0 && kx == 0) S += stot[5];
+    if (ky == 0 && kx == 2) S += stot[6];
+    if (ky == 2 && kx == 0) S += stot[7];
+    if (ky == 2 && kx == 2) S += stot[8];
+    const float xa = a.xa[ci], xb = a.xb[ci], mean = a.mean[ci], invstd = a.invstd[ci];
+    const float gamma = xa / invstd, beta = fmaf(mean, xa, xb);
+    const float dgp = tot[hh][tap * 4 + c];
+    a.wg_partials[(size_t)blockIdx.x * 73 + t] = fmaf(gamma, dgp, beta * S);
+    const float w = a.Gb[(8 - tap) * 8 + ci];            // forward gather weight G[tap][ci] out of the backward pack
+    scratch[0][t] = w * S;
+    scratch[1][t] = w * dgp;
+  } else if (t == 72) {
+    a.wg_partials[(size_t)blockIdx.x * 73 + 72] = stot[0];                    // bias gradient = T
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int which = t >> 3, ci = t & 7;
+    float s = 0.f;
+    for (int tap = 0; tap < 9; ++tap) s += scratch[which][tap * 8 + ci];
+    a.bn_partials[(size_t)blockIdx.x * 16 + t] = s;
+  }
+}
+
 static int thin_ws_mode() {
   static const int ws = [] { const char* e = getenv("AVA_THIN_WS"); return e ? atoi(e) : 1; }();
   return ws;
@@ -823,8 +956,15 @@ int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
   if (!((Cin == 1 && Cout == 8) || (Cin == 8 && Cout == 1))) return 0;
   const int nt = B * (Hi / THIN_TH);
   static const int env1 = [] { const char* e = getenv("AVA_THIN_GRID1"); return (e && atoi(e) >= 8) ? atoi(e) : 768; }();
-  static const int env8 = [] { const char* e = getenv("AVA_THIN_GRID8"); return (e && atoi(e) >= 8) ? atoi(e) : 512; }();
-  const int cap = Cin == 1 ? env1 : env8;                // resident workgroups (3 resp. 2 per CU): one wave of them
+  static const int env8 = [] {
+    const char* e = getenv("AVA_THIN_GRID8");
+    if (e && atoi(e) >= 8) return atoi(e);
+    const char* d = getenv("AVA_THIN_STATS_DIRECT");
+    if (d && atoi(d) == 0) return 512;                    // LDS-staged form: two workgroups per CU
+    // direct form: one resident wave (3 per CU at 138 VGPRs; in-step A/B 512 / 768 / 1024 -> 48.0 / 42.4 / 55.7 us)
+    return ava_resident_grid(&thin_wgrad_stats_8to1_direct_kernel<PRO_ID>, 0);
+  }();
+  const int cap = Cin == 1 ? env1 : env8;                // one resident wave of workgroups (3 per CU each)
   return nt < cap ? nt : cap;
 }
 
@@ -865,6 +1005,13 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess)
       return AVA_ELAUNCH;
     attr = true;
+  }
+  static const int direct = [] { const char* e = getenv("AVA_THIN_STATS_DIRECT"); return e ? atoi(e) : 1; }();
+  if (direct != 0) {
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
+    AVA_CHECK_LAUNCH();
+    return AVA_OK;
   }
   if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_BWD>), dim3(grid), dim3(256), kThinStatsLds, st, a);
   else hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_ID>), dim3(grid), dim3(256), kThinStatsLds, st, a);

@@ -388,6 +388,102 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
   thin_zero_rows<2>(a.partials, a.part_rows);
 }
 
+// "Direct" form of the 8 -> 1 forward (convt7 + SSE epilogue): the 8-channel input needs no LDS window.  Thread (x, h)
+// of a lane pair reads channels 4h..4h+3 of its pixel column straight from global memory (10 rows: the 8 rows of the
+// tile and one halo row on each side), applies BatchNorm (zero outside the image) and reduces over its channels and
+// over ky in registers:   u[r][kx] = sum_ky sum_c W[ky][kx][c] * x_n[r + ky - 1][c].
+// Only these 24 partial sums per thread cross lanes, through a 25 KB LDS array with zero border columns:
+//   y[r][x] = bias + sum_h sum_kx u_h[r][kx] at column x + kx - 1.
+// No staging role, three workgroups per CU resident, ten independent 16-byte loads per thread in flight; the
+// LDS-staged wave-specialised form kept one 41.6 KB window per workgroup in flight.
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void thin_8to1_direct_kernel(const ConvArgs a) {
+  static_assert(PRO == PRO_BN && EPI == EPI_SSE, "only convt7's forward uses this form");
+  __shared__ float U[2][3][THIN_TH][THIN_IC];           // [half][kx][row][column + 1]; columns 0 and 129 stay zero
+  __shared__ float red[4][2];
+  const int t = threadIdx.x, h = t & 1, x = t >> 1, lane = t & 63, wave = t >> 6;
+  if (t < 2 * 3 * THIN_TH) {                            // zero borders, once
+    float* row = &U[0][0][0][0] + t * THIN_IC;
+    row[0] = 0.f;
+    row[THIN_IC - 1] = 0.f;
+  }
+  float ca[4], cb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { ca[c] = a.pa[4 * h + c]; cb[c] = a.pb[4 * h + c]; }
+  avaf2 w2[9][2];                                       // [tap][channel pair of this half], G is [9][8][1]
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      avaf2 v = {a.G[tap * 8 + 4 * h + 2 * q], a.G[tap * 8 + 4 * h + 2 * q + 1]};
+      asm volatile("" : "+v"(v));
+      w2[tap][q] = v;
+    }
+  const float bias0 = a.bias[0];
+  const int xo = t & 127, r0 = (t >> 7) * 4;            // phase 2: output pixels (r0 + p, xo)
+  float s1 = 0.f;
+  const int tiles_y = a.Ho / THIN_TH;
+  for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
+    const int tl = walk.cur;
+    const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
+    // ---- phase 1: own pixel column, 10 rows ----
+    const float* __restrict__ xin = a.in + ((size_t)b * a.Hi * THIN_W + x) * 8 + 4 * h;
+    avaf2 xn[THIN_IR][2];
+#pragma unroll
+    for (int j = 0; j < THIN_IR; ++j) {
+      const int gy = oy0 - 1 + j;
+      const bool ok = gy >= 0 && gy < a.Hi;             // wave-uniform
+      const avaf4 v = *reinterpret_cast<const avaf4*>(xin + (size_t)min(max(gy, 0), a.Hi - 1) * THIN_W * 8);
+      xn[j][0] = ok ? avaf2{fmaf(ca[0], v[0], cb[0]), fmaf(ca[1], v[1], cb[1])} : avaf2{0.f, 0.f};
+      xn[j][1] = ok ? avaf2{fmaf(ca[2], v[2], cb[2]), fmaf(ca[3], v[3], cb[3])} : avaf2{0.f, 0.f};
+    }
+    const size_t opix0 = ((size_t)b * a.Ho + oy0 + r0) * THIN_W + xo;
+    float ex[4] = {0.f, 0.f, 0.f, 0.f};                 // epilogue operand of this thread's output pixels
+    if (a.epi_x != nullptr) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) ex[p] = a.epi_x[opix0 + (size_t)p * THIN_W];
+    }
+    float u[THIN_TH][3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int r = 0; r < THIN_TH; ++r) {
+        avaf2 sacc = {0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) sacc = __builtin_elementwise_fma(xn[r + ky][q], w2[ky * 3 + kx][q], sacc);
+        u[r][kx] = sacc[0] + sacc[1];
+      }
+    __syncthreads();                                    // the previous tile's phase 2 has read U
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int r = 0; r < THIN_TH; ++r) U[h][kx][r][x + 1] = u[r][kx];
+    __syncthreads();
+    // ---- phase 2: 4 output pixels per thread ----
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float v = bias0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) v += U[0][kx][r0 + p][xo + kx] + U[1][kx][r0 + p][xo + kx];
+      const size_t opix = opix0 + (size_t)p * THIN_W;
+      if (a.epi_x != nullptr) {
+        const float r = v - ex[p];
+        a.out2[opix] = a.prec * r;
+        s1 = fmaf(r, r, s1);
+      }
+      if (a.out != nullptr) a.out[opix] = v;
+    }
+  }
+  const float r1 = wave_sum(s1);
+  if (lane == 0) { red[wave][0] = r1; red[wave][1] = 0.f; }
+  __syncthreads();
+  if (t < 2 && a.partials != nullptr)
+    a.partials[(size_t)blockIdx.x * 2 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  thin_zero_rows<2>(a.partials, a.part_rows);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // weight gradients.  dy-side prologue is applied on the fly to each thread's own 4 pixels (no LDS needed for dy)
 // ---------------------------------------------------------------------------------------------------------
@@ -1052,7 +1148,15 @@ int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, 
       attr = true;
     }
     const int ws = thin_ws_mode();
-    if (ws != 0 && pro == PRO_BN && epi == EPI_SSE) {
+    static const int direct = [] { const char* e = getenv("AVA_THIN_FWD_DIRECT"); return e ? atoi(e) : 1; }();
+    if (direct != 0 && pro == PRO_BN && epi == EPI_SSE) {
+      static const int resident = ava_resident_grid(&thin_8to1_direct_kernel<PRO_BN, EPI_SSE>, 0);
+      int g = a.part_rows < resident ? a.part_rows : resident;   // at most one resident wave; rows beyond the grid are zero-filled
+      if (g > 512) g = 512;                               // in-step A/B: 512 / 768 / 1023 workgroups -> 34.1 / 34.7 / 37.0 us
+      { const char* e = getenv("AVA_THIN_FWD_GRID"); if (e && atoi(e) >= 8 && atoi(e) < a.part_rows) g = atoi(e); }
+      if (g > a.ntiles) g = a.ntiles;
+      hipLaunchKernelGGL((thin_8to1_direct_kernel<PRO_BN, EPI_SSE>), dim3(g), dim3(256), 0, st, a);
+    } else if (ws != 0 && pro == PRO_BN && epi == EPI_SSE) {
       static bool attr_ws = false;
       if (!attr_ws) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>),

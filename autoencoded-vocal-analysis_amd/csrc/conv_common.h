@@ -198,9 +198,11 @@ static inline int ava_resident_grid(K kernel, size_t lds_bytes) {
 // from HBM once per XCD.  Falls back to the plain strided walk when the grid or tile count is not a multiple of 8.
 struct TileWalk {
   int cur, end, step;
-  __device__ __forceinline__ explicit TileWalk(int ntiles) {
+  // chunked: each XCD (workgroup index mod 8) walks its own contiguous eighth of the tile list, so that tiles sharing
+  // halo rows share an L2; otherwise the workgroups sweep the list together (better for halo-free, store-heavy kernels)
+  __device__ __forceinline__ explicit TileWalk(int ntiles, bool chunked = true) {
     const int g = (int)gridDim.x, w = (int)blockIdx.x;
-    if (((g | ntiles) & 7) == 0) {
+    if (chunked && ((g | ntiles) & 7) == 0) {
       const int chunk = ntiles >> 3, xcd = w & 7;
       cur = xcd * chunk + (w >> 3);
       end = (xcd + 1) * chunk;

@@ -284,9 +284,15 @@ static int launch_mfma_pe(const ConvArgs& a, int grid, int pro, int epi, hipStre
 // `grid` = number of workgroups = number of partial rows (the caller's ava_conv_grid value)
 int ava_conv3x3_mfma_ws(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st);   // conv_ws.hip
 
+int ava_conv3x3_up88_direct(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st);
+
 int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
   const int tw = a.Wo >= 32 ? 32 : 16;
   if (epi == EPI_FWD && !a.relu) return AVA_EINVAL;        // the fused epilogue always applies the ReLU
+  {                                                        // convt6 forward: direct packed-FMA kernel (conv_thin.hip)
+    const int rc = ava_conv3x3_up88_direct(a, grid, Cin, Cout, mode, pro, epi, st);
+    if (rc != AVA_EINVAL) return rc;
+  }
   // forward layers run the wave-specialised kernel (conv_ws.hip; -27 us/step); AVA_CONV_WS=0 selects the plain one
   static const bool ws = [] { const char* e = getenv("AVA_CONV_WS"); return e == nullptr || atoi(e) != 0; }();
   static const bool ws_bwd = [] { const char* e = getenv("AVA_CONV_WS_BWD"); return e == nullptr || atoi(e) != 0; }();

@@ -1042,6 +1042,129 @@ __global__ __launch_bounds__(256) void thin_wgrad_stats_8to1_direct_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// convt6 forward (8 -> 8 channels, stride-2 transposed conv, 64x64 -> 128x128) in the direct form of the thin
+// kernels.  On the matrix cores half of every MFMA of this layer is padding (8 of 16 rows) and a staging role is
+// needed; its 0.6 GMAC fit the packed-FMA rate many times over, so the layer is HBM-bound if nothing else is in
+// the way.  Thread (xo, h) of a lane pair owns output column xo (low-resolution column c = xo >> 1, parity px) and
+// output channels 4h..4h+3 of the 8 output rows of a tile; it reads the 5 x 2 low-resolution input pixels it needs
+// straight from global memory (BatchNorm applied, zero beyond the image), and the per-lane weight set -- which taps
+// exist depends on px, which channels on h -- comes from a 3 KB LDS table as 16-byte reads (4 distinct addresses per
+// wave).  out(2r+py, 2c+px) = bias + sum over ky with (ky != 1) == py, kx with (kx != 1) == px of
+// G[ky][kx] . x_n(r + (ky == 0), c + (kx == 0));  every store instruction writes 1 KB of full lines.
+// ---------------------------------------------------------------------------------------------------------
+#define UP88_WSTRIDE 49     // float4 per (px, h) weight set: 48 used, padded so the four sets start in different banks
+__global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
+  __shared__ __align__(16) float wt[4 * UP88_WSTRIDE * 4];   // [px][h][ky][slot][ci] x 4 output channels
+  __shared__ float red[4][2][8];
+  const int t = threadIdx.x, h = t & 1, xo = t >> 1, c = xo >> 1, px = xo & 1, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < 4 * 48 * 4; i += 256) {
+    const int co4 = i & 3, e = i >> 2, set = e / 48, r = e - 48 * set;       // r = (ky*2 + slot)*8 + ci
+    const int spx = set >> 1, sh = set & 1, ky = r / 16, slot = (r >> 3) & 1, ci = r & 7;
+    const int kx = slot == 0 ? (spx ? 2 : 1) : 0;                              // slot 0: column c, slot 1: column c + 1
+    const bool exists = slot == 0 || spx == 1;
+    wt[(set * UP88_WSTRIDE + r) * 4 + co4] = exists ? a.G[((ky * 3 + kx) * 8 + ci) * 8 + 4 * sh + co4] : 0.f;
+  }
+  float sca[8], shf[8];
+#pragma unroll
+  for (int ci = 0; ci < 8; ++ci) { sca[ci] = ava_uniform(a.pa[ci]); shf[ci] = ava_uniform(a.pb[ci]); }   // scalar registers
+  avaf2 bias2[2] = {avaf2{a.bias[4 * h], a.bias[4 * h + 1]}, avaf2{a.bias[4 * h + 2], a.bias[4 * h + 3]}};
+  avaf2 s1[2] = {avaf2{0.f, 0.f}, avaf2{0.f, 0.f}}, s2[2] = {avaf2{0.f, 0.f}, avaf2{0.f, 0.f}};
+  const float* wl = wt + ((px * 2 + h) * UP88_WSTRIDE) * 4;
+  const bool colB = c + 1 < a.Wi;
+  const int tiles_y = a.Ho / 8;
+  __syncthreads();
+  for (TileWalk walk(a.ntiles, false); walk.valid(); walk.advance()) {     // sweeping walk: 40.6 vs 42.3 us chunked
+    const int tl = walk.cur;
+    const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * 8, r0 = oy0 >> 1;
+    avaf2 acc[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = avaf2{0.f, 0.f};
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      // ---- input pixels of this column slot: rows r0 .. r0+4, column c + slot, all 8 channels ----
+      float xn[5][8];
+      const bool colok = slot == 0 || colB;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int gy = r0 + j;
+        const bool ok = colok && gy < a.Hi;
+        const float* __restrict__ pp = a.in + (((size_t)b * a.Hi + min(gy, a.Hi - 1)) * a.Wi + min(c + slot, a.Wi - 1)) * 8;
+        const avaf4 v0 = *reinterpret_cast<const avaf4*>(pp), v1 = *reinterpret_cast<const avaf4*>(pp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xn[j][e] = ok ? fmaf(sca[e], v0[e], shf[e]) : 0.f;
+          xn[j][4 + e] = ok ? fmaf(sca[4 + e], v1[e], shf[4 + e]) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int ci = 0; ci < 8; ++ci) {
+        __builtin_amdgcn_sched_barrier(0);              // one (slot, ci) at a time: hoisting all 48 weight reads costs 192 VGPRs
+        const avaf4 w0 = *reinterpret_cast<const avaf4*>(wl + ((0 * 2 + slot) * 8 + ci) * 4);   // ky = 0: row r + 1, odd output rows
+        const avaf4 w1 = *reinterpret_cast<const avaf4*>(wl + ((1 * 2 + slot) * 8 + ci) * 4);   // ky = 1: row r, even output rows
+        const avaf4 w2 = *reinterpret_cast<const avaf4*>(wl + ((2 * 2 + slot) * 8 + ci) * 4);   // ky = 2: row r, odd output rows
+        const avaf2 w0a = {w0[0], w0[1]}, w0b = {w0[2], w0[3]}, w1a = {w1[0], w1[1]}, w1b = {w1[2], w1[3]},
+                    w2a = {w2[0], w2[1]}, w2b = {w2[2], w2[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const avaf2 x0 = {xn[r][ci], xn[r][ci]}, x1 = {xn[r + 1][ci], xn[r + 1][ci]};
+          acc[2 * r][0] = __builtin_elementwise_fma(x0, w1a, acc[2 * r][0]);
+          acc[2 * r][1] = __builtin_elementwise_fma(x0, w1b, acc[2 * r][1]);
+          acc[2 * r + 1][0] = __builtin_elementwise_fma(x0, w2a, acc[2 * r + 1][0]);
+          acc[2 * r + 1][1] = __builtin_elementwise_fma(x0, w2b, acc[2 * r + 1][1]);
+          acc[2 * r + 1][0] = __builtin_elementwise_fma(x1, w0a, acc[2 * r + 1][0]);
+          acc[2 * r + 1][1] = __builtin_elementwise_fma(x1, w0b, acc[2 * r + 1][1]);
+        }
+      }
+    }
+    const size_t o0 = (((size_t)b * a.Ho + oy0) * a.Wo + xo) * 8 + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      avaf2 v0 = acc[j][0] + bias2[0], v1 = acc[j][1] + bias2[1];
+      v0 = avaf2{fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)};
+      v1 = avaf2{fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)};
+      s1[0] += v0; s1[1] += v1;
+      s2[0] = __builtin_elementwise_fma(v0, v0, s2[0]);
+      s2[1] = __builtin_elementwise_fma(v1, v1, s2[1]);
+      *reinterpret_cast<avaf4*>(a.out + o0 + (size_t)j * a.Wo * 8) = avaf4{v0[0], v0[1], v1[0], v1[1]};
+    }
+  }
+  // ---- per-channel sums: lanes of equal parity hold the same 4 channels; waves, then workgroup, fixed order ----
+  float sv[8] = {s1[0][0], s1[0][1], s1[1][0], s1[1][1], s2[0][0], s2[0][1], s2[1][0], s2[1][1]};
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = sv[i];
+#pragma unroll
+    for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane < 2) red[wave][lane][i] = v;               // lane = h
+  }
+  __syncthreads();
+  if (t < 16 && a.partials != nullptr) {
+    const int which = t >> 3, co = t & 7, hh = co >> 2, i = which * 4 + (co & 3);
+    a.partials[(size_t)blockIdx.x * 16 + t] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);
+  }
+  thin_zero_rows<16>(a.partials, a.part_rows);
+}
+
+// convt6 forward in the direct form; AVA_EINVAL: not this layer / switched off (AVA_UP88_DIRECT=0)
+int ava_conv3x3_up88_direct(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("AVA_UP88_DIRECT"); return e ? atoi(e) : 1; }();
+  if (!on || Cin != 8 || Cout != 8 || mode != MODE_UP || pro != PRO_BN || epi != EPI_FWD || !a0.relu || a0.out2 != nullptr ||
+      a0.Wo != 128 || a0.Wi != 64 || a0.Ho % 8 != 0 || a0.out == nullptr)
+    return AVA_EINVAL;
+  ConvArgs a = a0;
+  a.ntiles = a.B * (a.Ho / 8);
+  a.part_rows = grid;
+  static const int resident = ava_resident_grid(&up88_direct_kernel, 0);
+  int g = grid < resident ? grid : resident;
+  { const char* e = getenv("AVA_UP88_GRID"); if (e && atoi(e) >= 8 && atoi(e) < g) g = atoi(e); }
+  if (g > a.ntiles) g = a.ntiles;
+  hipLaunchKernelGGL(up88_direct_kernel, dim3(g), dim3(256), 0, st, a);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
 static int thin_ws_mode() {
   static const int ws = [] { const char* e = getenv("AVA_THIN_WS"); return e ? atoi(e) : 1; }();
   return ws;

@@ -19,6 +19,7 @@ struct FusedArgs {
   float* wg_partials;    // [grid][9*CI*CO + CO]
   int B, Hi, Wi, Ho, Wo;
   int tiles_y, tiles_x, ntiles;
+  int sweep;             // thin kernels: workgroups sweep the tile list together instead of per-XCD chunks
 };
 
 // 0 when (Cin, Cout, mode, size) has no fused instantiation

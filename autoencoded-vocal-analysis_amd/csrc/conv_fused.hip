@@ -743,7 +743,7 @@ extern "C" int ava_conv3x3_bwd_fused(const float* x, const float* xa, const floa
       mean == nullptr || invstd == nullptr || bn_partials == nullptr || wg_partials == nullptr || B < 1)
     return AVA_EINVAL;
   if (dy_pro == PRO_BWD && (dy2 == nullptr || da == nullptr || db == nullptr || dc == nullptr)) return AVA_EINVAL;
-  FusedArgs a;
+  FusedArgs a = {};
   a.x = x; a.xa = xa; a.xb = xb; a.dy = dy; a.dy2 = dy2; a.da = da; a.db = db; a.dc = dc; a.Gb = Gb; a.dx = dx;
   a.mean = mean; a.invstd = invstd; a.bn_partials = bn_partials; a.wg_partials = wg_partials;
   a.B = B; a.Hi = Hi; a.Wi = Wi;

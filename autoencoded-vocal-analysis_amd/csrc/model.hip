@@ -551,7 +551,7 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   // layers with a fused kernel: data gradient, BatchNorm-backward sums and weight/bias partials from one pass
   const int fgrid = fused_grid(l, B);
   if (fgrid > 0 && (gout != nullptr || l == 0)) {
-    FusedArgs a;
+    FusedArgs a = {};
     a.x = X; a.xa = bn_scale(m, l); a.xb = bn_shift(m, l);
     a.dy = gin; a.dy2 = gin2; a.da = ca; a.db = cb; a.dc = cc;
     a.Gb = m->Gb[l]; a.dx = gout; a.mean = bn_mean(m, l); a.invstd = bn_invstd(m, l);

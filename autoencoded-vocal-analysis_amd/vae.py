@@ -458,16 +458,30 @@ class VAE(nn.Module):
         grid_plot(all_specs, gap=gap, filename=save_filename)
         return specs, rec_specs
 
-    def get_latent(self, loader):
+    def get_latent(self, loader, bn_mode=None):
         """Latent means of everything in ``loader`` as float64 ``[N,z]`` (vae.py:519-547).
-        Like the reference this does not switch to eval mode."""
-        n_total = len(loader.dataset)
-        latent_dev = torch.zeros(n_total, self.z_dim, device=self.device)     # one D2H copy at the end, no per-batch sync
-        i = 0
-        for data in self._feed(loader):
-            with torch.no_grad():
-                mu, _, _ = self.encode(data)
-            latent_dev[i:i + len(mu)] = mu
-            i += len(mu)
-        latent = latent_dev.cpu().numpy().astype(np.float64)
+
+        ``bn_mode=None`` is the reference's behaviour: the module's current mode is used as is -- straight after
+        training that is TRAIN mode, so every batch is normalised with its own statistics and the running
+        statistics keep moving (the reference never calls ``eval()`` here).  ``bn_mode='eval'`` / ``'train'`` select
+        the mode explicitly for this call and restore the previous one afterwards (SURVEY section 8, row f2);
+        with ``'eval'`` the result no longer depends on how the loader batches the data."""
+        if bn_mode not in (None, 'eval', 'train'):
+            raise ValueError("bn_mode must be None, 'eval' or 'train'")
+        was_training = self.training
+        if bn_mode is not None:
+            self.train(bn_mode == 'train')
+        try:
+            n_total = len(loader.dataset)
+            latent_dev = torch.zeros(n_total, self.z_dim, device=self.device)   # one D2H copy at the end, no per-batch sync
+            i = 0
+            for data in self._feed(loader):
+                with torch.no_grad():
+                    mu, _, _ = self.encode(data)
+                latent_dev[i:i + len(mu)] = mu
+                i += len(mu)
+            latent = latent_dev.cpu().numpy().astype(np.float64)
+        finally:
+            if bn_mode is not None:
+                self.train(was_training)
         return latent

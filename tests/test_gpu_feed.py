@@ -97,3 +97,22 @@ def test_epoch_loops_identical_with_and_without_prefetch():
     assert t0 == t1 and e0 == e1                            # same kernels, same inputs: bit-identical
     assert np.array_equal(l0, l1) and l0.shape == (sum(len(b) for b in batches), z) and l0.dtype == np.float64
     assert torch.equal(p0, p1)
+
+
+def test_get_latent_bn_mode():
+    """bn_mode=None keeps the reference's quirk (current mode, here train: batch statistics, running stats move);
+    'eval' uses the running statistics, is independent of the batching and leaves mode and buffers untouched."""
+    z = 32
+    data = _batches([16, 16, 16, 16])
+    model = build_model(z)
+    model.train()
+    before = model._bn_running.clone()
+    a = model.get_latent(_Loader(data), bn_mode='eval')
+    assert model.training and torch.equal(model._bn_running, before)
+    merged = [torch.cat(data[:2]), torch.cat(data[2:])]
+    b = model.get_latent(_Loader(merged), bn_mode='eval')
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-5)                     # same statistics whatever the batching
+    c = model.get_latent(_Loader(data))                                 # reference behaviour: train mode
+    assert not torch.equal(model._bn_running, before) and not np.allclose(a, c, rtol=1e-3, atol=1e-4)
+    with pytest.raises(ValueError):
+        model.get_latent(_Loader(data), bn_mode='nope')

@@ -1,11 +1,21 @@
-// The four "thin" convolutions at full resolution (128x128, stride 1): conv1 (1 -> 8 channels) and convt7
-// (8 -> 1) forward, their backward-data counterparts (convt7's is again 1 -> 8, conv1's 8 -> 1) and both
-// weight gradients.  One side has a single channel, so the matrix cores would idle 15/16 of the time; these
-// are HBM-bound VALU kernels: a thread owns a vertical strip of 4 pixels (lanes run along x, so LDS reads of
-// neighbouring lanes are 4/32 bytes apart: no bank conflicts; 72 wave-uniform weights in scalar registers,
-// 288 FMAs per thread and tile), the input window is staged in LDS with the prologue
-// applied (zero padding after BatchNorm), outputs leave as 16-byte stores.  Same ConvArgs / WgradArgs /
-// partial-row conventions as conv.hip.
+// The "thin" convolutions at full resolution (128x128, stride 1) -- conv1 (1 -> 8 channels) and convt7 (8 -> 1)
+// forward, their backward-data counterparts and both weight gradients -- plus convt6's forward (8 -> 8, stride-2
+// transposed).  With 1 or 8 channels per side the matrix cores idle most of the time (15/16 resp. 1/2 of every MFMA
+// is padding); these are HBM-bound VALU kernels built on packed FMAs (v_pk_fma_f32).
+//
+// The kernels on the model's path are in the DIRECT form: lane pairs share a pixel column, thread (x, h) owns 4 of
+// the 8 channels of its column, the 8-channel tensor is read from / written to global memory by the thread that owns
+// the pixel (every 16-byte access of a wave is part of 1 KB of full lines), and only 1-channel windows or a few
+// partial sums go through LDS:
+//   thin_1to8_kernel                      conv1 forward, convt7 data gradient (1-channel window in LDS)
+//   thin_8to1_direct_kernel               convt7 forward + SSE epilogue (24 partial sums per thread through LDS)
+//   thin_bwd_fused_1to8_kernel            conv1 backward (weight gradient + BatchNorm sums; no data gradient needed)
+//   thin_wgrad_stats_8to1_direct_kernel   convt7 weight gradient + BatchNorm sums
+//   up88_direct_kernel                    convt6 forward
+// The earlier LDS-staged forms (thin_8to1_kernel, thin_8to1_ws_kernel, thin_wgrad_*_kernel, thin_wgrad_stats_8to1_kernel:
+// a thread owns a vertical strip of 4 pixels, the 8-channel window is staged in LDS with the prologue applied) remain
+// as alternatives behind environment switches (tools/README.md) and for the shapes the tests exercise through
+// ava_conv3x3 / ava_conv3x3_wgrad.  Same ConvArgs / WgradArgs / partial-row conventions as conv.hip.
 #include "conv_common.h"
 #include "conv_fused.h"
 

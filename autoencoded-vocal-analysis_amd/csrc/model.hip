@@ -361,7 +361,46 @@ __global__ void pack_all_kernel(const PackTable tab) {
     e.g[gi] = e.w[i];
   }
 }
-static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st) {
+// pack_all_kernel plus the statistics of the raw 1-channel input (bn1: its input has no producer kernel) in ONE launch:
+// blocks [0, nstats) sum x and x^2 exactly like bn_stats_kernel<1> (same grid-stride order, same partial rows), the
+// rest pack the weight tables.  Both are independent first kernels of a training forward; one launch less per step.
+__global__ __launch_bounds__(256) void pack_stats_kernel(const PackTable tab, const float* __restrict__ x, int64_t n,
+                                                         float* __restrict__ partials, int nstats) {
+  if ((int)blockIdx.x >= nstats) {
+    const int idx = blockIdx.x - nstats, by = idx / 7, bx = idx - 7 * by;
+    const PackEntry e = tab.e[by];
+    const int cnt = e.c0 * e.c1 * 9;
+    for (int i = bx * 256 + threadIdx.x; i < cnt; i += 7 * 256) {
+      const int tt = i % 9, r = i / 9, i1 = r % e.c1, i0 = r / e.c1;
+      const int tg = e.flip ? 8 - tt : tt;
+      const int gi = e.swap ? (tg * e.c1 + i1) * e.c0 + i0 : (tg * e.c0 + i0) * e.c1 + i1;
+      e.g[gi] = e.w[i];
+    }
+    return;
+  }
+  __shared__ float red[4][2];
+  float s1 = 0.f, s2 = 0.f;
+  const int64_t stride = (int64_t)nstats * 256, n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = x4[i];
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 * 4; i < n; ++i) { s1 += x[i]; s2 += x[i] * x[i]; }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const float r1 = wave_sum(s1), r2 = wave_sum(s2);
+  if (l == 0) { red[w][0] = r1; red[w][1] = r2; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    partials[(size_t)blockIdx.x * 2 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// x_stats != nullptr: also the bn1 input statistics of x_stats[n] (training forward); *nstats_out = partial rows written
+static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float* x_stats = nullptr, int64_t n = 0,
+                        int* nstats_out = nullptr) {
   PackTable tab;
   for (int l = 0; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
@@ -375,6 +414,19 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st) {
     tab.e[2 * l + 1] = {w, m->Gb[l], c0, c1, (kb == 5 || kb == 6) ? 1 : 0, (kb == 3) ? 1 : 0};
   }
   mark(m, -1, st);
+  static const bool fuse = [] { const char* e = getenv("AVA_PACK_STATS"); return e == nullptr || atoi(e) != 0; }();
+  if (x_stats != nullptr && nstats_out != nullptr && fuse && (reinterpret_cast<uintptr_t>(x_stats) & 15) == 0) {
+    int64_t work = n / 4;                                  // same grid rule as ava_bn_stats (C = 1)
+    int nstats = (int)((work + 256 * 8 - 1) / (256 * 8));
+    if (nstats < 1) nstats = 1;
+    if (nstats > 1024) nstats = 1024;
+    hipLaunchKernelGGL(pack_stats_kernel, dim3(nstats + 7 * 2 * NCONV), dim3(256), 0, st, tab, x_stats, n, m->bn_part, nstats);
+    AVA_CHECK_LAUNCH();
+    *nstats_out = nstats;
+    mark(m, CAT_PACK, st);
+    return AVA_OK;
+  }
+  if (nstats_out != nullptr) *nstats_out = 0;
   hipLaunchKernelGGL(pack_all_kernel, dim3(7, with_bwd ? 2 * NCONV : 2 * NCONV), dim3(256), 0, st, tab);
   AVA_CHECK_LAUNCH();
   mark(m, CAT_PACK, st);
@@ -432,12 +484,14 @@ static bool conv7_writes_nchw() {
 }
 
 static int encoder_forward(ava_model* m, const float* x, int B, int train, float* mu, float* u, float* logd_or_d,
-                           int last_act, hipStream_t st) {
+                           int last_act, hipStream_t st, int pre_nparts = 0) {
   const int z = m->z;
-  int nparts = 0;
+  int nparts = pre_nparts;                 // > 0: pack_stats_kernel already wrote the input statistics' partial rows
   if (train) {
-    TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, reinterpret_cast<ava_stream_t>(st)));
-    mark(m, CAT_BN, st);
+    if (nparts <= 0) {
+      TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, reinterpret_cast<ava_stream_t>(st)));
+      mark(m, CAT_BN, st);
+    }
     TRY(finalize_fwd(m, 0, nparts, (int64_t)B * 16384, st));
   } else {
     TRY(bn_eval_all(m, st));       // all 14 layers from the running statistics (also serves the decoder)
@@ -502,8 +556,9 @@ extern "C" int ava_forward(ava_model* m, const float* x, int B, const float* eps
   if (m == nullptr || x == nullptr || eps_w == nullptr || eps_d == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
   hipStream_t st = to_stream(s);
   const int z = m->z;
-  TRY(pack_weights(m, true, st));
-  TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st));
+  int pre = 0;
+  TRY(pack_weights(m, true, st, bn_train ? x : nullptr, (int64_t)B * 16384, &pre));
+  TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st, pre));
   mark(m, CAT_LAYOUT, st);
   TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
   m->eps_w_last = eps_w;          // backward reads the same noise: the caller keeps it alive until then

@@ -50,6 +50,7 @@ SIGNATURES = {
     "ava_model_create": (_i, [C.POINTER(_p), _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz]),
     "ava_model_destroy": (None, [_p]),
     "ava_forward": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
+    "ava_forward_noise": (_i, [_p, _p, _i, _p, C.c_uint64, C.c_uint64, _i, _p, _p, _p, _p]),
     "ava_backward": (_i, [_p, _p, _i, _p]),
     "ava_backward_num_parts": (_i, []),
     "ava_backward_part": (_i, [_p, _p, _i, _i, _p]),

@@ -28,3 +28,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Counter-based standard normal: splitmix64 finaliser + Box-Muller; matches ava_amd.synthetic.u01 / gauss (SURVEY
+// Appendix E) so that injected and device-generated noise agree to float rounding when seeded alike.  Element i of a
+// stream depends on (i + offset, seed) only, never on the launch geometry.
+#ifdef __HIPCC__
+__device__ __forceinline__ double ava_u01_hash(uint64_t i, uint64_t salt) {
+  uint64_t x = i + salt * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ float ava_normal_hash(uint64_t i, uint64_t seed) {
+  const double u1 = ava_u01_hash(i, seed), u2 = ava_u01_hash(i, seed + 7777);
+  return (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2));
+}
+#endif

@@ -124,20 +124,9 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
   }
 }
 
-// splitmix64 finaliser; matches ava_amd.synthetic.u01 / gauss so that injected and
-// device-generated noise agree to float rounding when seeded alike.
-__device__ __forceinline__ double u01_hash(uint64_t i, uint64_t salt) {
-  uint64_t x = i + salt * 0x9E3779B97F4A7C15ull;
-  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 27; x *= 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
-}
 __global__ void fill_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double u1 = u01_hash((uint64_t)i + offset, seed), u2 = u01_hash((uint64_t)i + offset, seed + 7777);
-    out[i] = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2));
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = ava_normal_hash((uint64_t)i + offset, seed);
 }
 
 extern "C" int ava_latent_fwd(const float* mu, const float* u, const float* logd, const float* eps_w,

@@ -365,7 +365,15 @@ __global__ void pack_all_kernel(const PackTable tab) {
 // blocks [0, nstats) sum x and x^2 exactly like bn_stats_kernel<1> (same grid-stride order, same partial rows), the
 // rest pack the weight tables.  Both are independent first kernels of a training forward; one launch less per step.
 __global__ __launch_bounds__(256) void pack_stats_kernel(const PackTable tab, const float* __restrict__ x, int64_t n,
-                                                         float* __restrict__ partials, int nstats) {
+                                                         float* __restrict__ partials, int nstats, float* __restrict__ eps,
+                                                         int64_t neps, uint64_t seed, uint64_t offset) {
+  constexpr int NPACK = 7 * 2 * NCONV;
+  if ((int)blockIdx.x >= nstats + NPACK) {              // third role: the step's rsample noise (ava_forward_noise)
+    const int nb = gridDim.x - nstats - NPACK, bi = blockIdx.x - nstats - NPACK;
+    for (int64_t i = (int64_t)bi * 256 + threadIdx.x; i < neps; i += (int64_t)nb * 256)
+      eps[i] = ava_normal_hash((uint64_t)i + offset, seed);
+    return;
+  }
   if ((int)blockIdx.x >= nstats) {
     const int idx = blockIdx.x - nstats, by = idx / 7, bx = idx - 7 * by;
     const PackEntry e = tab.e[by];
@@ -399,8 +407,10 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const PackTable tab, co
 }
 
 // x_stats != nullptr: also the bn1 input statistics of x_stats[n] (training forward); *nstats_out = partial rows written
+struct NoiseGen { float* eps; int64_t n; uint64_t seed, offset; };   // eps == nullptr: no noise to generate
+
 static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float* x_stats = nullptr, int64_t n = 0,
-                        int* nstats_out = nullptr) {
+                        int* nstats_out = nullptr, NoiseGen ng = NoiseGen{nullptr, 0, 0, 0}) {
   PackTable tab;
   for (int l = 0; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
@@ -420,13 +430,20 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
     int nstats = (int)((work + 256 * 8 - 1) / (256 * 8));
     if (nstats < 1) nstats = 1;
     if (nstats > 1024) nstats = 1024;
-    hipLaunchKernelGGL(pack_stats_kernel, dim3(nstats + 7 * 2 * NCONV), dim3(256), 0, st, tab, x_stats, n, m->bn_part, nstats);
+    int nnoise = ng.eps != nullptr ? (int)((ng.n + 255) / 256) : 0;
+    if (nnoise > 64) nnoise = 64;
+    hipLaunchKernelGGL(pack_stats_kernel, dim3(nstats + 7 * 2 * NCONV + nnoise), dim3(256), 0, st, tab, x_stats, n, m->bn_part,
+                       nstats, ng.eps, ng.n, ng.seed, ng.offset);
     AVA_CHECK_LAUNCH();
     *nstats_out = nstats;
     mark(m, CAT_PACK, st);
     return AVA_OK;
   }
   if (nstats_out != nullptr) *nstats_out = 0;
+  if (ng.eps != nullptr) {                                // not fused: the noise gets its own launch
+    TRY(ava_fill_normal(ng.eps, ng.n, ng.seed, ng.offset, reinterpret_cast<ava_stream_t>(st)));
+    mark(m, CAT_LATENT_LOSS, st);
+  }
   hipLaunchKernelGGL(pack_all_kernel, dim3(7, with_bwd ? 2 * NCONV : 2 * NCONV), dim3(256), 0, st, tab);
   AVA_CHECK_LAUNCH();
   mark(m, CAT_PACK, st);
@@ -551,13 +568,13 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
   return AVA_OK;
 }
 
-extern "C" int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d, int bn_train,
-                           float* loss_out, double* loss_accum, int* status_out, ava_stream_t s) {
+static int forward_impl(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d, int bn_train,
+                        float* loss_out, double* loss_accum, int* status_out, ava_stream_t s, NoiseGen ng) {
   if (m == nullptr || x == nullptr || eps_w == nullptr || eps_d == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
   hipStream_t st = to_stream(s);
   const int z = m->z;
   int pre = 0;
-  TRY(pack_weights(m, true, st, bn_train ? x : nullptr, (int64_t)B * 16384, &pre));
+  TRY(pack_weights(m, true, st, bn_train ? x : nullptr, (int64_t)B * 16384, &pre, ng));
   TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st, pre));
   mark(m, CAT_LAYOUT, st);
   TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
@@ -570,6 +587,20 @@ extern "C" int ava_forward(ava_model* m, const float* x, int B, const float* eps
   mark(m, CAT_LATENT_LOSS, st);
   m->lastB = B;
   return AVA_OK;
+}
+
+extern "C" int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d, int bn_train,
+                           float* loss_out, double* loss_accum, int* status_out, ava_stream_t s) {
+  return forward_impl(m, x, B, eps_w, eps_d, bn_train, loss_out, loss_accum, status_out, s, NoiseGen{nullptr, 0, 0, 0});
+}
+
+// ava_forward with the step's rsample noise drawn inside the first launch: eps[0..B) = eps_W, eps[B..B + B*z) = eps_D
+// are element i + offset of the counter stream ava_fill_normal(seed) produces (bit-identical to calling it first)
+extern "C" int ava_forward_noise(ava_model* m, const float* x, int B, float* eps, uint64_t seed, uint64_t offset,
+                                 int bn_train, float* loss_out, double* loss_accum, int* status_out, ava_stream_t s) {
+  if (m == nullptr || eps == nullptr || B < 1) return AVA_EINVAL;
+  const int64_t n = (int64_t)B * (m->z + 1);
+  return forward_impl(m, x, B, eps, eps + B, bn_train, loss_out, loss_accum, status_out, s, NoiseGen{eps, n, seed, offset});
 }
 
 extern "C" int ava_encode(ava_model* m, const float* x, int B, int bn_train, float* mu, float* u, float* d,

@@ -280,11 +280,21 @@ class VAE(nn.Module):
         loss to ``self._loss_acc`` on the device (the epoch loops' running sum)."""
         B = x.shape[0]
         self._ensure(B)
-        ew, ed = self._noise(B)
-        rc = _lib.load().ava_forward(self._handle, x.data_ptr(), B, ew.data_ptr(), ed.data_ptr(),
-                                     1 if self.training else 0, self._loss_buf.data_ptr(),
-                                     self._loss_acc.data_ptr() if accumulate else None,
-                                     self._status.data_ptr(), _lib.stream())
+        if self.noise_source is None:
+            # device counter RNG: the noise is drawn inside the forward's first launch (same stream as ava_fill_normal)
+            n = B * (self.z_dim + 1)
+            rc = _lib.load().ava_forward_noise(self._handle, x.data_ptr(), B, self._eps.data_ptr(), self._rng_seed,
+                                               self._rng_offset, 1 if self.training else 0, self._loss_buf.data_ptr(),
+                                               self._loss_acc.data_ptr() if accumulate else None,
+                                               self._status.data_ptr(), _lib.stream())
+            self._rng_offset += n
+            ew, ed = self._eps[:B], self._eps[B:n].view(B, self.z_dim)
+        else:
+            ew, ed = self._noise(B)
+            rc = _lib.load().ava_forward(self._handle, x.data_ptr(), B, ew.data_ptr(), ed.data_ptr(),
+                                         1 if self.training else 0, self._loss_buf.data_ptr(),
+                                         self._loss_acc.data_ptr() if accumulate else None,
+                                         self._status.data_ptr(), _lib.stream())
         _lib.check(rc, "ava_forward")
         self._last_x = x
         self._last_noise = (ew, ed)

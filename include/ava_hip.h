@@ -65,6 +65,12 @@ void ava_model_destroy(ava_model* m);
  * Leaves every intermediate needed by ava_backward in the workspace. */
 int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d,
                 int bn_train, float* loss_out, double* loss_accum, int* status_out, ava_stream_t s);
+/* The same with the noise of rsample() (vae.py:313) drawn by the device inside the forward's first launch instead of
+ * being passed in: eps (device, B*(z_dim+1) floats) receives eps_W [B] then eps_D [B,z_dim], elements offset ..
+ * offset + B*(z_dim+1) - 1 of the counter stream of ava_fill_normal(seed) -- bit-identical to ava_fill_normal(eps, ...)
+ * followed by ava_forward(m, x, B, eps, eps + B, ...), one launch less.  eps must stay valid until ava_backward. */
+int ava_forward_noise(ava_model* m, const float* x, int B, float* eps, uint64_t seed, uint64_t offset,
+                      int bn_train, float* loss_out, double* loss_accum, int* status_out, ava_stream_t s);
 /* loss.backward() (vae.py:352) for the forward that just ran: fills the gradient arena
  * (overwrites: the reference zero_grad()s before every step, vae.py:348). */
 int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);

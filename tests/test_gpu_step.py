@@ -255,6 +255,35 @@ def test_backward_in_parts_equals_whole():
     assert lib.ava_grad_bucket(model._handle, nparts, ctypes.byref(o), ctypes.byref(c)) != 0
 
 
+def test_forward_noise_equals_fill_normal_then_forward():
+    """ava_forward_noise draws the rsample noise inside the forward's first launch: same counter stream as
+    ava_fill_normal (bit for bit) and therefore the same loss as ava_forward fed with that noise."""
+    from ava_amd import _lib
+    lib = _lib.load()
+    B, z = 5, 32
+    x = torch.from_numpy(syn.spectrograms(B)).cuda()
+    n = B * (z + 1)
+    model = build_model(z)
+    model.train()
+    model.noise_source = None
+    model._rng_seed, model._rng_offset = 123, 1000
+    loss_a = float(model._forward_device(x, need_grad=True).item())
+    assert model._rng_offset == 1000 + n
+    eps_a = model._eps[:n].clone()
+    buf = torch.empty(n, device="cuda")
+    _lib.check(lib.ava_fill_normal(buf.data_ptr(), n, 123, 1000, _lib.stream()), "fill")
+    assert torch.equal(buf, eps_a)
+    assert abs(float(buf.mean())) < 0.5 and 0.5 < float(buf.std()) < 1.5
+    ref = build_model(z)
+    ref.train()
+    ref.noise_source = lambda b, zz: (buf[:B], buf[B:].view(B, z))
+    assert float(ref._forward_device(x, need_grad=True).item()) == loss_a
+    # eval mode (no statistics to fuse): the noise falls back to its own launch, same values
+    model.eval(); ref.eval()
+    model._rng_offset = 1000
+    assert float(model._forward_device(x, need_grad=False).item()) == float(ref._forward_device(x, need_grad=False).item())
+
+
 def test_profile_passes_agree():
     """ava_profile_enable(1) brackets every launch group with HIP events, ava_profile_enable(2) only the runs of
     same-family kernels (what bench.py's roofline uses): the coarse pass must record far fewer events, leave the results

@@ -77,7 +77,22 @@ __device__ void column_sums(const float* __restrict__ partials, int nparts, int 
   }
   scratch[t] = grp < groups ? s : 0.0;
   __syncthreads();
-  if (t < ncols) {
+  // with few columns there are hundreds of groups (bn1: 2 columns, 512 groups): 32 threads per column first sum
+  // every 32nd group, then one thread per column adds the 32 results -- fixed order, 16+32 dependent adds instead of 512
+  if (groups > 64) {
+    double part = 0.0;
+    const int col2 = t % ncols, j = t / ncols;
+    if (j < 32)
+      for (int gI = j; gI < groups; gI += 32) part += scratch[gI * ncols + col2];
+    __syncthreads();
+    if (j < 32) scratch[j * ncols + col2] = part;
+    __syncthreads();
+    if (t < ncols) {
+      double tot = 0.0;
+      for (int jj = 0; jj < 32; ++jj) tot += scratch[jj * ncols + t];
+      sums[t] = tot;
+    }
+  } else if (t < ncols) {
     double tot = 0.0;
     for (int gI = 0; gI < groups; ++gI) tot += scratch[gI * ncols + t];
     sums[t] = tot;

@@ -52,6 +52,7 @@ SIGNATURES = {
     "ava_forward": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ava_forward_noise": (_i, [_p, _p, _i, _p, C.c_uint64, C.c_uint64, _i, _p, _p, _p, _p]),
     "ava_backward": (_i, [_p, _p, _i, _p]),
+    "ava_set_backward_scale": (_i, [_p, _p]),
     "ava_backward_num_parts": (_i, []),
     "ava_backward_part": (_i, [_p, _p, _i, _i, _p]),
     "ava_grad_bucket": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -14,6 +14,10 @@
 #define BN_EPS AVA_BN_EPS
 #define BN_MOMENTUM AVA_BN_MOMENTUM
 
+int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* mean,
+                           const float* invstd, float* dgamma, float* dbeta, float* A, float* Bc, float* Cc, int eval,
+                           hipStream_t st);
+
 // ---- statistics of a raw tensor x[n][C] (used for bn1, whose input has no producer kernel) --------
 template <int C>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t n,
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
                                                                double n, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, float* dgamma,
-                                                               float* dbeta, float* A, float* Bc, float* Cc) {
+                                                               float* dbeta, float* A, float* Bc, float* Cc, int eval) {
   __shared__ double sums[64];
   __shared__ double scratch[1024];
   column_sums(partials, nparts, 2 * C, sums, scratch);
@@ -150,12 +154,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
     const double dG = sums[C + c];        // sum g * xhat
     const double is = (double)invstd[c], gm = (double)gamma[c], mu = (double)mean[c];
     const double a = gm * is;
-    const double b = -gm * is * is * dG / n;
+    // eval: the forward normalised with the (constant) running statistics -> dx = gamma*invstd*g, nothing else
+    const double b = eval ? 0.0 : -gm * is * is * dG / n;
     dgamma[c] = (float)dG;
     dbeta[c] = (float)dB;
     A[c] = (float)a;
     Bc[c] = (float)b;
-    Cc[c] = (float)(-a * dB / n - b * mu);
+    Cc[c] = eval ? 0.f : (float)(-a * dB / n - b * mu);
   }
 }
 
@@ -319,9 +324,15 @@ extern "C" int ava_bn_finalize(const float* partials, int nparts, int64_t n, int
 extern "C" int ava_bn_finalize_bwd(const float* partials, int nparts, int64_t n, int C, const float* gamma,
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* A,
                                    float* Bc, float* Cc, ava_stream_t s) {
+  return ava_bn_finalize_bwd_ex(partials, nparts, n, C, gamma, mean, invstd, dgamma, dbeta, A, Bc, Cc, 0, to_stream(s));
+}
+// eval = 1: backward of a BatchNorm that ran on its running statistics (module.eval())
+int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* mean,
+                           const float* invstd, float* dgamma, float* dbeta, float* A, float* Bc, float* Cc, int eval,
+                           hipStream_t st) {
   if (C < 1 || C > 32 || partials == nullptr || gamma == nullptr) return AVA_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(1024), 0, to_stream(s), partials, nparts, (double)n, C,
-                     gamma, mean, invstd, dgamma, dbeta, A, Bc, Cc);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(1024), 0, st, partials, nparts, (double)n, C,
+                     gamma, mean, invstd, dgamma, dbeta, A, Bc, Cc, eval);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/ava_hip.h"
 
 #define AVA_WAVE 64
@@ -13,6 +14,17 @@
   } while (0)
 
 static inline hipStream_t to_stream(ava_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Tuning switches (AVA_* environment variables, ablation bits, alternative tile shapes and the superseded kernels they
+// select) exist only in the lab build (`make lab` -> libava_hip_lab.so, -DAVA_LAB; tools/README.md).  The product
+// library has ONE code path per shape: ava_env() is a constant there and everything behind it folds away.
+#ifdef AVA_LAB
+static inline const char* ava_env(const char* name) { return getenv(name); }
+#define AVA_DBG_BIT(args, bit) (((args).dbg & (bit)) != 0)
+#else
+static inline const char* ava_env(const char*) { return nullptr; }
+#define AVA_DBG_BIT(args, bit) false
+#endif
 
 // sum over the 64 lanes of a wave; result valid in every lane
 __device__ __forceinline__ float wave_sum(float v) {

@@ -619,12 +619,19 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   // wave-specialised variant (staging waves beside matrix-core waves, two tile buffers) where it wins: fused_defaults
   bool ws; int cap_unused;
   fused_defaults(CI, CO, LMODE, &ws, &cap_unused);
+#ifndef AVA_LAB
+  if (!ws) return AVA_EINVAL;           // every shape of the library runs the wave-specialised kernel
+#endif
   const size_t buf_f = (size_t)FG::XR * FG::XC * CI + FG::DR * FG::DC * CO + 16;
   const size_t tiles_f = (ws ? 2 : 1) * buf_f + 192 + 4 * 32 * MT;
   const size_t red_f = (size_t)9 * CI * CO + CO;
   const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
+#ifdef AVA_LAB
   const void* kfn = ws ? reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>)
                        : reinterpret_cast<const void*>(&conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>);
+#else
+  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>);
+#endif
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVA_ELAUNCH;
@@ -637,37 +644,47 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   b.tiles_x = wl / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
-  if (ws) hipLaunchKernelGGL((conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(512), lds, st, b);
-  else hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(256), lds, st, b);
+#ifdef AVA_LAB
+  if (!ws) hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(256), lds, st, b);
+  else
+#endif
+  hipLaunchKernelGGL((conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
 // shapes with a fused instantiation: (cin, cout, mode, variant) -> low-resolution tile, occupancy hint.
-// Variant 0 is the one the model driver runs; the others are kept for tools/fused_bench.py (AVA_FUSED_VAR=n).
-#define AVA_FUSED_SHAPES(X)        \
-  X(8, 8, MODE_DOWN, 0, 16, 4, 2)  \
-  X(8, 8, MODE_DOWN, 1, 32, 4, 2)  \
-  X(8, 8, MODE_DOWN, 2, 16, 4, 3)  \
-  X(8, 16, MODE_S1, 0, 32, 4, 2)   \
-  X(8, 16, MODE_S1, 1, 16, 8, 2)   \
-  X(8, 16, MODE_S1, 2, 32, 8, 2)   \
+// Variant 0 is what the library runs.  The lab build (make lab) also compiles the tile shapes that lost the
+// tools/fused_bench.py comparison (AVA_FUSED_VAR=n), several of which spill.
+#define AVA_FUSED_SHAPES_DEFAULT(X) \
+  X(8, 8, MODE_DOWN, 0, 16, 4, 2)   \
+  X(8, 16, MODE_S1, 0, 32, 4, 2)    \
   X(16, 16, MODE_DOWN, 0, 16, 4, 2) \
+  X(16, 16, MODE_UP, 0, 16, 4, 2)   \
+  X(16, 8, MODE_S1, 0, 32, 4, 2)    \
+  X(8, 8, MODE_UP, 0, 32, 4, 2)     \
+  X(16, 24, MODE_S1, 0, 32, 4, 1)   \
+  X(24, 16, MODE_S1, 0, 32, 4, 1)
+#ifdef AVA_LAB
+#define AVA_FUSED_SHAPES(X)         \
+  AVA_FUSED_SHAPES_DEFAULT(X)       \
+  X(8, 8, MODE_DOWN, 1, 32, 4, 2)   \
+  X(8, 8, MODE_DOWN, 2, 16, 4, 3)   \
+  X(8, 16, MODE_S1, 1, 16, 8, 2)    \
+  X(8, 16, MODE_S1, 2, 32, 8, 2)    \
   X(16, 16, MODE_DOWN, 1, 32, 4, 2) \
   X(16, 16, MODE_DOWN, 2, 16, 8, 2) \
-  X(16, 16, MODE_UP, 0, 16, 4, 2)  \
-  X(16, 16, MODE_UP, 1, 32, 4, 2)  \
-  X(16, 16, MODE_UP, 2, 16, 4, 3)  \
-  X(16, 8, MODE_S1, 0, 32, 4, 2)   \
-  X(16, 8, MODE_S1, 1, 16, 8, 2)   \
-  X(16, 8, MODE_S1, 2, 32, 8, 2)   \
-  X(8, 8, MODE_UP, 0, 32, 4, 2)    \
-  X(16, 24, MODE_S1, 0, 32, 4, 1)  \
-  X(16, 24, MODE_S1, 1, 16, 4, 1)  \
-  X(24, 16, MODE_S1, 0, 32, 4, 1)  \
-  X(24, 16, MODE_S1, 1, 16, 4, 1)  \
-  X(8, 8, MODE_UP, 1, 16, 4, 3)    \
+  X(16, 16, MODE_UP, 1, 32, 4, 2)   \
+  X(16, 16, MODE_UP, 2, 16, 4, 3)   \
+  X(16, 8, MODE_S1, 1, 16, 8, 2)    \
+  X(16, 8, MODE_S1, 2, 32, 8, 2)    \
+  X(16, 24, MODE_S1, 1, 16, 4, 1)   \
+  X(24, 16, MODE_S1, 1, 16, 4, 1)   \
+  X(8, 8, MODE_UP, 1, 16, 4, 3)     \
   X(8, 8, MODE_UP, 2, 32, 4, 3)
+#else
+#define AVA_FUSED_SHAPES(X) AVA_FUSED_SHAPES_DEFAULT(X)
+#endif
 
 // Which shapes run the wave-specialised kernel, and with how many workgroups (= partial rows).  Measured at batch 256
 // (tools/fused_bench.py): every shape gains 4-25 % once its 512-thread workgroup fits 128 VGPRs, so that two are resident per
@@ -680,15 +697,15 @@ static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap) {
   if (Cin == 16 && Cout == 16 && mode == MODE_UP) { *ws = true; *cap = 512; }    // 16x4 tiles: 128 VGPRs
   if (mode == MODE_S1) { *ws = true; *cap = 512; }                                // 32x4 tiles: 126 / 128 VGPRs (12 B spill for 16->8)
   if (mode == MODE_S1 && Cin * Cout > 256) { *ws = true; *cap = 256; }            // conv5 / convt3: one workgroup per CU
-  static const int force = [] { const char* e = getenv("AVA_FUSED_WS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  static const int force = [] { const char* e = ava_env("AVA_FUSED_WS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
   if (force == 0) { *ws = false; *cap = 512; }
   if (force == 1) *ws = true;
-  static const int gcap = [] { const char* e = getenv("AVA_FUSED_GRID"); return (e && atoi(e) >= 8) ? atoi(e) : 0; }();
+  static const int gcap = [] { const char* e = ava_env("AVA_FUSED_GRID"); return (e && atoi(e) >= 8) ? atoi(e) : 0; }();
   if (gcap > 0) *cap = gcap;
 }
 
 static int fused_variant() {
-  static const int v = [] { const char* e = getenv("AVA_FUSED_VAR"); return e ? atoi(e) : 0; }();
+  static const int v = [] { const char* e = ava_env("AVA_FUSED_VAR"); return e ? atoi(e) : 0; }();
   return v;
 }
 

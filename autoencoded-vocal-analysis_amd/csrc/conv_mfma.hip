@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   }
   // Weights and epilogue constants are fetched AFTER the first tile's loads were issued: both round trips to
   // memory overlap instead of following each other at the start of every workgroup.
-  if (!(a.dbg & 8)) f0.init(a.G, lane, SP * n * CIN, mtb);
+  if (!AVA_DBG_BIT(a, 8)) f0.init(a.G, lane, SP * n * CIN, mtb);
   if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
   // epilogue constants for this lane's 4 output channels per cout tile
   float bias[MT][4];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
     int b, oy0, ox0, gy0, gx0;
     origin(walk.cur, b, oy0, ox0, gy0, gx0);
     __syncthreads();                       // previous tile fully consumed (and coef[] visible on the first pass)
-    if (!(a.dbg & 2)) stg.store(tile, coef);                 // s_waitcnt vmcnt(0): retires the prefetch (and exn) of this tile
+    if (!AVA_DBG_BIT(a, 2)) stg.store(tile, coef);                 // s_waitcnt vmcnt(0): retires the prefetch (and exn) of this tile
     if (EPI == EPI_BWD) ava_wait_vm0(exn);
     __syncthreads();
     // uniform (scalar) part of the addresses of this tile
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
 #pragma unroll
       for (int i = 0; i < GPW * MT; ++i) ex[i] = exn[i];
     }
-    if (walk.has_next() && !(a.dbg & 2)) {  // next tile's loads stay in flight during the MFMAs below
+    if (walk.has_next() && !AVA_DBG_BIT(a, 2)) {  // next tile's loads stay in flight during the MFMAs below
       int nb, noy0, nox0, ngy0, ngx0;
       origin(walk.next(), nb, noy0, nox0, ngy0, ngx0);
       stg.load(a.in, a.in2, nb, a.Hi, a.Wi, ngy0, ngx0);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (a.dbg & 1) {
+      if (AVA_DBG_BIT(a, 1)) {
       } else if (MODE == MODE_UP) {
         const int cls = gi & 3, r = g >> 2;       // == g & 3 (both group mappings keep the class in the low bits of gi)
         const float* px = tile + r * IC * CIN;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
               s2[mt][r] = fmaf(v[r], xv[r], s2[mt][r]);      // raw x: centred after the loop
             }
           }
-          if (obase != nullptr && !(a.dbg & 4))
+          if (obase != nullptr && !AVA_DBG_BIT(a, 4))
             *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
           if (EPI == EPI_FWD && MODE == MODE_S1 && !PAIR && a.out2 != nullptr) {
             // second copy in NCHW order (the flatten order of the fully connected layer that follows, vae.py:224):
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
     }
   }
 
-  if (a.dbg & 16) return;
+  if (AVA_DBG_BIT(a, 16)) return;
   // ---- per-workgroup partial statistics: reduce over the 16 pixel lanes, then over the 4 waves ----
   __syncthreads();
   if (MSPLIT) {                              // a wave only fills its own cout tile: the other slots must read as 0
@@ -266,12 +266,13 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
   if (grid > resident) grid = resident;
-  { const char* e = getenv("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
+  { const char* e = ava_env("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
   hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
+#ifdef AVA_LAB
 template <int CIN, int COUT, int MODE, int TW, int TH>
 static int launch_mfma_pe(const ConvArgs& a, int grid, int pro, int epi, hipStream_t st) {
   if (pro == PRO_BN && epi == EPI_FWD) return launch_mfma<CIN, COUT, MODE, PRO_BN, EPI_FWD, TW, TH>(a, grid, st);
@@ -279,6 +280,7 @@ static int launch_mfma_pe(const ConvArgs& a, int grid, int pro, int epi, hipStre
   if (pro == PRO_ID && epi == EPI_BWD) return launch_mfma<CIN, COUT, MODE, PRO_ID, EPI_BWD, TW, TH>(a, grid, st);
   return AVA_EINVAL;
 }
+#endif
 
 // returns AVA_EINVAL when the shape has no matrix-core instantiation (caller falls back to the VALU kernel)
 // `grid` = number of workgroups = number of partial rows (the caller's ava_conv_grid value)
@@ -294,12 +296,19 @@ int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, i
     if (rc != AVA_EINVAL) return rc;
   }
   // forward layers run the wave-specialised kernel (conv_ws.hip; -27 us/step); AVA_CONV_WS=0 selects the plain one
-  static const bool ws = [] { const char* e = getenv("AVA_CONV_WS"); return e == nullptr || atoi(e) != 0; }();
-  static const bool ws_bwd = [] { const char* e = getenv("AVA_CONV_WS_BWD"); return e == nullptr || atoi(e) != 0; }();
+  static const bool ws = [] { const char* e = ava_env("AVA_CONV_WS"); return e == nullptr || atoi(e) != 0; }();
+  static const bool ws_bwd = [] { const char* e = ava_env("AVA_CONV_WS_BWD"); return e == nullptr || atoi(e) != 0; }();
   if (ws && a.out2 == nullptr && (epi == EPI_FWD || (epi == EPI_BWD && ws_bwd))) {
     const int rc = ava_conv3x3_mfma_ws(a, grid, Cin, Cout, mode, pro, epi, st);
     if (rc != AVA_EINVAL) return rc;
   }
+#ifndef AVA_LAB
+  // Everything else runs the wave-specialised kernel above.  The plain 256-thread kernel is compiled for the one
+  // launch that needs its second output: conv7's forward, which also writes the NCHW-flatten copy fc1 reads.
+  if (a.out2 != nullptr && Cin == 24 && Cout == 32 && mode == MODE_S1 && tw == 16 && pro == PRO_BN && epi == EPI_FWD)
+    return launch_mfma<24, 32, MODE_S1, PRO_BN, EPI_FWD, 16, 8>(a, grid, st);
+  return AVA_EINVAL;
+#else
 #define AVA_MFMA_CASE(ci, co, md, tww, thh) \
   if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_mfma_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
   AVA_MFMA_CASE(8, 8, MODE_DOWN, 32, 4)
@@ -316,6 +325,7 @@ int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, i
   AVA_MFMA_CASE(8, 8, MODE_UP, 32, 8)
 #undef AVA_MFMA_CASE
   return AVA_EINVAL;
+#endif
 }
 
 // ================================================================================================
@@ -611,7 +621,7 @@ static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
   if (grid > b.ntiles) grid = b.ntiles;
   static const int resident = ava_resident_grid(kernel, lds);
   if (grid > resident) grid = resident;          // one resident wave of workgroups = partial rows written
-  { const char* e = getenv("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
+  { const char* e = ava_env("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (a.partials == nullptr) return grid;        // row-count query (ava_conv_wgrad_rows)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();

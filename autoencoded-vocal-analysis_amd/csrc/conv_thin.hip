@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
   thin_zero_rows<2>(a.partials, a.part_rows);
 }
 
+#ifdef AVA_LAB
 // Wave-specialised variant (512 threads, one workgroup per CU): waves 0-3 stage tile k+1 (global -> registers ->
 // prologue -> LDS buffer (k+1)&1) while waves 4-7 multiply tile k out of buffer k&1; one barrier per tile.  At the
 // barrier of tile k the staging waves have filled buffer k&1 and the compute waves have left buffer (k-1)&1, which
@@ -399,6 +400,8 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
     a.partials[(size_t)blockIdx.x * 2 + t] = (red[t] + red[2 + t]) + (red[4 + t] + red[6 + t]);
   thin_zero_rows<2>(a.partials, a.part_rows);
 }
+
+#endif  // AVA_LAB
 
 // "Direct" form of the 8 -> 1 forward (convt7 + SSE epilogue): the 8-channel input needs no LDS window.  Thread (x, h)
 // of a lane pair reads channels 4h..4h+3 of its pixel column straight from global memory (10 rows: the 8 rows of the
@@ -803,6 +806,7 @@ __global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArg
 // (S[tap] = sum of dU over the pixels whose tap lands inside the image), so the data-gradient kernel
 // (thin_1to8_kernel<.., EPI_NONE>) only has to write dx and never reads x; this kernel reads x once.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef AVA_LAB   // the LDS-staged form of this kernel (AVA_THIN_STATS_DIRECT=0); the library runs the direct form below
 template <int DYPRO>
 __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const FusedArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -920,6 +924,8 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
     a.bn_partials[(size_t)blockIdx.x * 16 + t] = s;
   }
 }
+
+#endif  // AVA_LAB
 
 // "Direct" form of thin_wgrad_stats_8to1_kernel: the same correlation, indexed by the INPUT pixel q instead of the
 // output pixel p,   dG'[tap][ci] = sum_q xhat[q][ci] * dU[q - tap]   (dU zero outside the image),
@@ -1161,7 +1167,7 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
 
 // convt6 forward in the direct form; AVA_EINVAL: not this layer / switched off (AVA_UP88_DIRECT=0)
 int ava_conv3x3_up88_direct(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
-  static const int on = [] { const char* e = getenv("AVA_UP88_DIRECT"); return e ? atoi(e) : 1; }();
+  static const int on = [] { const char* e = ava_env("AVA_UP88_DIRECT"); return e ? atoi(e) : 1; }();
   if (!on || Cin != 8 || Cout != 8 || mode != MODE_UP || pro != PRO_BN || epi != EPI_FWD || !a0.relu || a0.out2 != nullptr ||
       a0.Wo != 128 || a0.Wi != 64 || a0.Ho % 8 != 0 || a0.out == nullptr)
     return AVA_EINVAL;
@@ -1170,7 +1176,7 @@ int ava_conv3x3_up88_direct(const ConvArgs& a0, int grid, int Cin, int Cout, int
   a.part_rows = grid;
   static const int resident = ava_resident_grid(&up88_direct_kernel, 0);
   int g = grid < resident ? grid : resident;
-  { const char* e = getenv("AVA_UP88_GRID"); if (e && atoi(e) >= 8 && atoi(e) < g) g = atoi(e); }
+  { const char* e = ava_env("AVA_UP88_GRID"); if (e && atoi(e) >= 8 && atoi(e) < g) g = atoi(e); }
   if (g > a.ntiles) g = a.ntiles;
   hipLaunchKernelGGL(up88_direct_kernel, dim3(g), dim3(256), 0, st, a);
   AVA_CHECK_LAUNCH();
@@ -1178,7 +1184,7 @@ int ava_conv3x3_up88_direct(const ConvArgs& a0, int grid, int Cin, int Cout, int
 }
 
 static int thin_ws_mode() {
-  static const int ws = [] { const char* e = getenv("AVA_THIN_WS"); return e ? atoi(e) : 1; }();
+  static const int ws = [] { const char* e = ava_env("AVA_THIN_WS"); return e ? atoi(e) : 1; }();
   return ws;
 }
 
@@ -1186,11 +1192,11 @@ int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
   if (mode != MODE_S1 || Wi != THIN_W || Hi % THIN_TH != 0) return 0;
   if (!((Cin == 1 && Cout == 8) || (Cin == 8 && Cout == 1))) return 0;
   const int nt = B * (Hi / THIN_TH);
-  static const int env1 = [] { const char* e = getenv("AVA_THIN_GRID1"); return (e && atoi(e) >= 8) ? atoi(e) : 768; }();
+  static const int env1 = [] { const char* e = ava_env("AVA_THIN_GRID1"); return (e && atoi(e) >= 8) ? atoi(e) : 768; }();
   static const int env8 = [] {
-    const char* e = getenv("AVA_THIN_GRID8");
+    const char* e = ava_env("AVA_THIN_GRID8");
     if (e && atoi(e) >= 8) return atoi(e);
-    const char* d = getenv("AVA_THIN_STATS_DIRECT");
+    const char* d = ava_env("AVA_THIN_STATS_DIRECT");
     if (d && atoi(d) == 0) return 512;                    // LDS-staged form: two workgroups per CU
     // direct form: one resident wave (3 per CU at 138 VGPRs; in-step A/B 512 / 768 / 1024 -> 48.0 / 42.4 / 55.7 us)
     return ava_resident_grid(&thin_wgrad_stats_8to1_direct_kernel<PRO_ID>, 0);
@@ -1206,7 +1212,7 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
   a.ntiles = a.B * (a.Ho / THIN_TH);
   // the 8-channel tensors of these kernels have no halo: sweeping the tile list together beats per-XCD chunks
   // (in-step A/B: conv1 backward 68.0 -> 59.0 us, convt7 weight gradient 44.5 -> 42.9 us)
-  { static const int sw = [] { const char* e = getenv("AVA_THIN_SWEEP"); return e ? atoi(e) : 1; }(); a.sweep = sw; }
+  { static const int sw = [] { const char* e = ava_env("AVA_THIN_SWEEP"); return e ? atoi(e) : 1; }(); a.sweep = sw; }
   if (dy_pro != PRO_BWD && dy_pro != PRO_ID) return AVA_EINVAL;
   if (Cin == 1) {
     if (a.dx != nullptr) return AVA_EINVAL;              // this layer's data gradient is never formed
@@ -1223,7 +1229,7 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
   // no partial rows here, so the grid is free: one resident wave of workgroups (6 per CU at 76 VGPRs) is the fastest
   // (in-step rocprof A/B: 768 / 1024 / 1536 / 2048 / 4096 workgroups -> 33.5 / 33.1 / 30.7 / 35.1 / 39.8 us)
   static const int dcap = [] {
-    const char* e = getenv("AVA_THIN_DGRID");
+    const char* e = ava_env("AVA_THIN_DGRID");
     if (e && atoi(e) >= 8) return atoi(e);
     return ava_resident_grid(&thin_1to8_kernel<PRO_ID, EPI_NONE>, 0);
   }();
@@ -1231,24 +1237,26 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
   if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BWD, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
   else hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
   AVA_CHECK_LAUNCH();
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_BWD>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_ID>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess)
-      return AVA_ELAUNCH;
-    attr = true;
-  }
-  static const int direct = [] { const char* e = getenv("AVA_THIN_STATS_DIRECT"); return e ? atoi(e) : 1; }();
-  if (direct != 0) {
-    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
+#ifdef AVA_LAB
+  static const int direct = [] { const char* e = ava_env("AVA_THIN_STATS_DIRECT"); return e ? atoi(e) : 1; }();
+  if (direct == 0) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_BWD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_ID>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess)
+        return AVA_ELAUNCH;
+      attr = true;
+    }
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_BWD>), dim3(grid), dim3(256), kThinStatsLds, st, a);
+    else hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_ID>), dim3(grid), dim3(256), kThinStatsLds, st, a);
     AVA_CHECK_LAUNCH();
     return AVA_OK;
   }
-  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_BWD>), dim3(grid), dim3(256), kThinStatsLds, st, a);
-  else hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_ID>), dim3(grid), dim3(256), kThinStatsLds, st, a);
+#endif
+  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
@@ -1271,7 +1279,7 @@ int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, 
   a.ntiles = a.B * (a.Ho / THIN_TH);                     // workgroups beyond ntiles still write their (zero) partial row
   a.part_rows = grid;                                    // rows the caller sized; one resident wave is launched
   if (Cin == 8 && grid > 512) grid = 512;                // 8 -> 1: two workgroups per CU are resident (measured -3.5 us)
-  { const char* e = getenv("AVA_THIN_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
+  { const char* e = ava_env("AVA_THIN_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (Cin == 1 && Cout == 8) {
     if (pro == PRO_BN && epi == EPI_FWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BN, EPI_FWD>), dim3(grid), dim3(256), 0, st, a);
     else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_BWD>), dim3(grid), dim3(256), 0, st, a);
@@ -1286,14 +1294,16 @@ int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, 
       attr = true;
     }
     const int ws = thin_ws_mode();
-    static const int direct = [] { const char* e = getenv("AVA_THIN_FWD_DIRECT"); return e ? atoi(e) : 1; }();
+    (void)ws;
+    static const int direct = [] { const char* e = ava_env("AVA_THIN_FWD_DIRECT"); return e ? atoi(e) : 1; }();
     if (direct != 0 && pro == PRO_BN && epi == EPI_SSE) {
       static const int resident = ava_resident_grid(&thin_8to1_direct_kernel<PRO_BN, EPI_SSE>, 0);
       int g = a.part_rows < resident ? a.part_rows : resident;   // at most one resident wave; rows beyond the grid are zero-filled
       if (g > 512) g = 512;                               // in-step A/B: 512 / 768 / 1023 workgroups -> 34.1 / 34.7 / 37.0 us
-      { const char* e = getenv("AVA_THIN_FWD_GRID"); if (e && atoi(e) >= 8 && atoi(e) < a.part_rows) g = atoi(e); }
+      { const char* e = ava_env("AVA_THIN_FWD_GRID"); if (e && atoi(e) >= 8 && atoi(e) < a.part_rows) g = atoi(e); }
       if (g > a.ntiles) g = a.ntiles;
       hipLaunchKernelGGL((thin_8to1_direct_kernel<PRO_BN, EPI_SSE>), dim3(g), dim3(256), 0, st, a);
+#ifdef AVA_LAB
     } else if (ws != 0 && pro == PRO_BN && epi == EPI_SSE) {
       static bool attr_ws = false;
       if (!attr_ws) {
@@ -1304,6 +1314,7 @@ int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, 
       }
       const int g = grid < 256 ? grid : 256;              // one workgroup per CU
       hipLaunchKernelGGL((thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>), dim3(g), dim3(512), kThin8WsLds, st, a);
+#endif
     } else if (pro == PRO_BN && epi == EPI_SSE) hipLaunchKernelGGL((thin_8to1_kernel<PRO_BN, EPI_SSE>), dim3(grid), dim3(256), kThin8Lds, st, a);
     else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<PRO_BWD, EPI_BWD>), dim3(grid), dim3(256), kThin8Lds, st, a);
     else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<PRO_ID, EPI_BWD>), dim3(grid), dim3(256), kThin8Lds, st, a);

@@ -432,8 +432,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmArgs g) {
 
 // products the skinny kernel takes: small output, A k-major, 16-byte alignable operands, no bias-gradient column sums
 static bool skinny_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
-  static const bool on = [] { const char* e = getenv("AVA_GEMM_SKINNY"); return e == nullptr || atoi(e) != 0; }();
-  static const int kmax = [] { const char* e = getenv("AVA_GEMM_SKINNY_KMAX"); return e ? atoi(e) : 2048; }();
+  static const bool on = [] { const char* e = ava_env("AVA_GEMM_SKINNY"); return e == nullptr || atoi(e) != 0; }();
+  static const int kmax = [] { const char* e = ava_env("AVA_GEMM_SKINNY_KMAX"); return e ? atoi(e) : 2048; }();
   if (!on) return false;
   if (g.colsum != nullptr && a_kmajor) return false;         // column sums are taken from an m-major A
   if ((size_t)g.M * g.N > 262144 || g.K > kmax) return false;
@@ -465,7 +465,7 @@ static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
   }
-  { const char* e = getenv("AVA_GEMM_SPLITS"); if (e && tiles < 384) { s = atoi(e); if (s > K / 16) s = K / 16; if (s < 1) s = 1; } }
+  { const char* e = ava_env("AVA_GEMM_SPLITS"); if (e && tiles < 384) { s = atoi(e); if (s > K / 16) s = K / 16; if (s < 1) s = 1; } }
   int kl = ceil_div(ceil_div(K, s), 16) * 16;
   s = ceil_div(K, kl);
   *splits = s;
@@ -520,7 +520,7 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   }
   dim3 grid(ceil_div(N, bm), ceil_div(M, bm), splits);
   static int bk32 = -1;
-  if (bk32 < 0) { const char* e = getenv("AVA_GEMM_BK"); bk32 = (e && atoi(e) == 16) ? 0 : 1; }
+  if (bk32 < 0) { const char* e = ava_env("AVA_GEMM_BK"); bk32 = (e && atoi(e) == 16) ? 0 : 1; }
   if (!vec) {
     if (bm == 128) launch_gemm<128, 16, false>(g, a_kmajor, b_kmajor, grid, st);
     else launch_gemm<64, 16, false>(g, a_kmajor, b_kmajor, grid, st);

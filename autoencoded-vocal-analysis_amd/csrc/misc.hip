@@ -10,6 +10,12 @@
 
 #define LOG_2PI 1.8378770664093453
 
+int ava_latent_bwd_scaled(const float* z, const float* dz_dec, const float* u, const float* d, const float* eps_w,
+                          const float* eps_d, float* dmu, float* du, float* dlogd, int B, int zdim, const float* scale,
+                          hipStream_t st);
+int ava_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                          double eps, int step, const int* skip_if_set, hipStream_t st);
+
 // one wave per sample; lane j handles latent dims j, j+64
 __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ u,
                                                          const float* __restrict__ logd,
@@ -53,10 +59,13 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ eps_w,
                                                          const float* __restrict__ eps_d, float* __restrict__ dmu,
                                                          float* __restrict__ du, float* __restrict__ dlogd, int B,
-                                                         int zdim) {
+                                                         int zdim, const float* __restrict__ scale) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
+  // scale = d(result)/d(loss) of a caller that backpropagates something other than the loss itself (null: 1).  dz
+  // already carries it (the decoder's backward started from the scaled seed); the prior and entropy terms get it here.
+  const float sc = scale != nullptr ? scale[0] : 1.f;
   float su2d = 0.f;
   for (int j = lane; j < zdim; j += 64) {
     const size_t i = (size_t)b * zdim + j;
@@ -66,11 +75,11 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
   const float ew = eps_w[b];
   for (int j = lane; j < zdim; j += 64) {
     const size_t i = (size_t)b * zdim + j;
-    const float g = z[i] + dz[i];
+    const float g = fmaf(sc, z[i], dz[i]);
     const float uu = u[i], dd = d[i];
     dmu[i] = g;
-    du[i] = g * ew - (uu / dd) / K;
-    dlogd[i] = 0.5f * g * eps_d[i] * sqrtf(dd) - 0.5f * (1.f - uu * uu / (dd * K));
+    du[i] = g * ew - sc * ((uu / dd) / K);
+    dlogd[i] = 0.5f * g * eps_d[i] * sqrtf(dd) - sc * (0.5f * (1.f - uu * uu / (dd * K)));
   }
 }
 
@@ -106,7 +115,9 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* __restr
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                         float one_minus_b1, float b2, float one_minus_b2,
-                                                        float step_size, float sqrt_bc2, float eps) {
+                                                        float step_size, float sqrt_bc2, float eps,
+                                                        const int* __restrict__ skip_if_set) {
+  if (skip_if_set != nullptr && *skip_if_set != 0) return;     // the forward flagged d <= 0 / NaN: no update (vae.py:312)
   float4* p4 = reinterpret_cast<float4*>(p);
   const float4* g4 = reinterpret_cast<const float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);
@@ -142,8 +153,32 @@ extern "C" int ava_latent_bwd(const float* z, const float* dz_dec, const float* 
                               const float* eps_d, float* dmu, float* du, float* dlogd, int B, int zdim,
                               ava_stream_t s) {
   if (B <= 0 || zdim <= 0 || z == nullptr) return AVA_EINVAL;
-  hipLaunchKernelGGL(latent_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, to_stream(s), z, dz_dec, u, d, eps_w, eps_d,
-                     dmu, du, dlogd, B, zdim);
+  return ava_latent_bwd_scaled(z, dz_dec, u, d, eps_w, eps_d, dmu, du, dlogd, B, zdim, nullptr, to_stream(s));
+}
+int ava_latent_bwd_scaled(const float* z, const float* dz_dec, const float* u, const float* d, const float* eps_w,
+                          const float* eps_d, float* dmu, float* du, float* dlogd, int B, int zdim, const float* scale,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, z, dz_dec, u, d, eps_w, eps_d, dmu, du,
+                     dlogd, B, zdim, scale);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+// v[i] *= scale[0] (the seed gradient of a backward whose root is not the loss itself)
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ v, int64_t n4, const float* __restrict__ scale) {
+  const float sc = scale[0];
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 t = v4[i];
+    t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc;
+    v4[i] = t;
+  }
+}
+int ava_scale_inplace(float* v, int64_t n, const float* scale, hipStream_t st) {
+  if (v == nullptr || scale == nullptr || n % 4 != 0) return AVA_EINVAL;
+  int64_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3(blocks), dim3(256), 0, st, v, n4, scale);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
@@ -161,6 +196,10 @@ extern "C" int ava_elbo_finalize(const float* latent_sums, int B, const float* s
 }
 extern "C" int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                              double beta2, double eps, int step, ava_stream_t s) {
+  return ava_adam_flat_guarded(p, g, m, v, n, lr, beta1, beta2, eps, step, nullptr, to_stream(s));
+}
+int ava_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                          double eps, int step, const int* skip_if_set, hipStream_t st) {
   if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0 || n % 4 != 0 || step < 1)
     return AVA_EINVAL;
   const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
@@ -169,8 +208,8 @@ extern "C" int ava_adam_flat(float* p, const float* g, float* m, float* v, int64
   int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, to_stream(s), p, g, m, v, n4,
-                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, sqrt_bc2, (float)eps);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, sqrt_bc2, (float)eps, skip_if_set);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

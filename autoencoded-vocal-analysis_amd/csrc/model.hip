@@ -21,6 +21,15 @@ int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st);
 int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
                              float* out, int B, hipStream_t st);
+int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* mean,
+                           const float* invstd, float* dgamma, float* dbeta, float* A, float* Bc, float* Cc, int eval,
+                           hipStream_t st);
+int ava_latent_bwd_scaled(const float* z, const float* dz_dec, const float* u, const float* d, const float* eps_w,
+                          const float* eps_d, float* dmu, float* du, float* dlogd, int B, int zdim, const float* scale,
+                          hipStream_t st);
+int ava_scale_inplace(float* v, int64_t n, const float* scale, hipStream_t st);
+int ava_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                          double eps, int step, const int* skip_if_set, hipStream_t st);
 int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
                               int zdim, float prec, float* loss_out, double* loss_accum, hipStream_t st);
 
@@ -134,7 +143,10 @@ struct ava_model {
   const float* eps_w_last;
   const float* eps_d_last;  // noise of the last forward (caller-owned; needed again by backward)
   int sse_parts;
-  int lastB;
+  int lastB;                // batch of the forward whose intermediates are in the workspace; 0: none (ava_backward refuses)
+  int last_train;           // BatchNorm mode of that forward: backward uses the matching BatchNorm derivative
+  int* status_last;         // status word of that forward (ava_adam_step skips the update when it is set)
+  const float* bwd_scale;   // device scalar d(result)/d(loss) for the next backward (ava_set_backward_scale); null = 1
   Prof prof;
   std::map<std::string, std::pair<const float*, int64_t>> dbg;
 };
@@ -258,6 +270,9 @@ extern "C" int ava_model_create(ava_model** out, int z_dim, int max_batch, float
   carve(m, workspace, &need);
   if (need > workspace_bytes) { delete m; return AVA_EWORKSPACE; }
   m->lastB = 0;
+  m->last_train = 1;
+  m->status_last = nullptr;
+  m->bwd_scale = nullptr;
   m->sse_parts = 0;
   // the only device write outside a stream: the ticket counters start at zero (every launch leaves them at zero)
   const size_t B = max_batch;
@@ -424,7 +439,7 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
     tab.e[2 * l + 1] = {w, m->Gb[l], c0, c1, (kb == 5 || kb == 6) ? 1 : 0, (kb == 3) ? 1 : 0};
   }
   mark(m, -1, st);
-  static const bool fuse = [] { const char* e = getenv("AVA_PACK_STATS"); return e == nullptr || atoi(e) != 0; }();
+  static const bool fuse = [] { const char* e = ava_env("AVA_PACK_STATS"); return e == nullptr || atoi(e) != 0; }();
   if (x_stats != nullptr && nstats_out != nullptr && fuse && (reinterpret_cast<uintptr_t>(x_stats) & 15) == 0) {
     int64_t work = n / 4;                                  // same grid rule as ava_bn_stats (C = 1)
     int nstats = (int)((work + 256 * 8 - 1) / (256 * 8));
@@ -460,8 +475,11 @@ static int finalize_fwd(ava_model* m, int l, int nparts, int64_t n, hipStream_t 
 }
 static int finalize_bwd(ava_model* m, int l, int nparts, int64_t n, hipStream_t st) {
   const ConvLayer& L = kLayers[l];
-  const int rc = ava_bn_finalize_bwd(m->bn_part, nparts, n, L.cin, PP(m, L.pg), bn_mean(m, l), bn_invstd(m, l),
-                                     GG(m, L.pg), GG(m, L.pbeta), bn_A(m, l), bn_B(m, l), bn_C(m, l), st);
+  // a forward in eval mode normalised with the running statistics: they are constants, so dx = gamma*invstd*g
+  // (no batch-statistic terms); dgamma / dbeta keep their forms with xhat built from the running statistics
+  const int rc = ava_bn_finalize_bwd_ex(m->bn_part, nparts, n, L.cin, PP(m, L.pg), bn_mean(m, l), bn_invstd(m, l),
+                                        GG(m, L.pg), GG(m, L.pbeta), bn_A(m, l), bn_B(m, l), bn_C(m, l),
+                                        m->last_train ? 0 : 1, st);
   mark(m, CAT_BN, st);
   return rc;
 }
@@ -496,7 +514,7 @@ enum { FC1 = 28, FC2 = 30, FC31 = 32, FC32 = 34, FC33 = 36, FC41 = 38, FC42 = 40
 
 // the version-0 (VALU) conv kernels have no NCHW second output: keep the transpose launch for them
 static bool conv7_writes_nchw() {
-  static const bool on = [] { const char* e = getenv("AVA_CONV_IMPL"); return !(e != nullptr && strcmp(e, "valu") == 0); }();
+  static const bool on = [] { const char* e = ava_env("AVA_CONV_IMPL"); return !(e != nullptr && strcmp(e, "valu") == 0); }();
   return on;
 }
 
@@ -586,6 +604,9 @@ static int forward_impl(ava_model* m, const float* x, int B, const float* eps_w,
                                 loss_out != nullptr ? loss_out : m->loss_dev, loss_accum, st));
   mark(m, CAT_LATENT_LOSS, st);
   m->lastB = B;
+  m->last_train = bn_train ? 1 : 0;
+  m->status_last = status_out;
+  m->bwd_scale = nullptr;
   return AVA_OK;
 }
 
@@ -608,6 +629,7 @@ extern "C" int ava_encode(ava_model* m, const float* x, int B, int bn_train, flo
   if (m == nullptr || x == nullptr || mu == nullptr || u == nullptr || d == nullptr || B < 1 || B > m->maxB)
     return AVA_EINVAL;
   hipStream_t st = to_stream(s);
+  m->lastB = 0;                       // the saved activations of the last ava_forward are overwritten
   TRY(pack_weights(m, false, st));
   return encoder_forward(m, x, B, bn_train, mu, u, d, ACT_EXP, st);
 }
@@ -615,6 +637,7 @@ extern "C" int ava_encode(ava_model* m, const float* x, int B, int bn_train, flo
 extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, float* x_rec, ava_stream_t s) {
   if (m == nullptr || z == nullptr || x_rec == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
   hipStream_t st = to_stream(s);
+  m->lastB = 0;
   TRY(pack_weights(m, false, st));
   if (!bn_train) TRY(bn_eval_all(m, st));
   return decoder_forward(m, z, nullptr, B, bn_train, x_rec, st);
@@ -623,7 +646,7 @@ extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, flo
 // ---- all 14 weight-gradient reductions are issued per layer (partials buffer is shared) --------------
 // workgroups (= partial rows) of layer l's fused backward kernel; 0: the layer runs the separate kernels
 static int fused_grid(int l, int B) {
-  static const bool on = [] { const char* e = getenv("AVA_CONV_FUSED"); return e == nullptr || atoi(e) != 0; }();
+  static const bool on = [] { const char* e = ava_env("AVA_CONV_FUSED"); return e == nullptr || atoi(e) != 0; }();
   if (!on) return 0;
   const ConvLayer& L = kLayers[l];
   return ava_conv_fused_grid_for(B, L.hi, L.hi, L.cin, L.cout, L.mode);
@@ -706,6 +729,12 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
 static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st);
 static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, bool whole);
 
+extern "C" int ava_set_backward_scale(ava_model* m, const float* loss_scale) {
+  if (m == nullptr) return AVA_EINVAL;
+  m->bwd_scale = loss_scale;
+  return AVA_OK;
+}
+
 extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s) {
   if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr) return AVA_EINVAL;
   TRY(backward_part0(m, x, B, to_stream(s), true));
@@ -726,6 +755,10 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
   float* gcur = m->gA;
   float* gnext = m->gB;
   mark(m, -1, st);
+  if (m->bwd_scale != nullptr) {       // d(result)/d(loss) != 1: scale the two roots of the backward (here and latent_bwd)
+    TRY(ava_scale_inplace(m->seed, (int64_t)B * 16384, m->bwd_scale, st));
+    mark(m, CAT_LAYOUT, st);
+  }
   TRY(conv_layer_backward(m, 13, x, m->seed, nullptr, nullptr, nullptr, nullptr, PRO_ID, gcur, B, st));
   for (int l = 12; l >= 7; --l) {
     // dU_l = (X_{l+1} > 0) ? A*g + Bc*X_{l+1} + Cc : 0 with the coefficients of BatchNorm l+1
@@ -752,7 +785,8 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   TRY(gemm(m, m->dh6, 0, PP(m, FC6), 0, nullptr, m->dh5, 0, m->h5, nullptr, B, 64, 256, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh5, 0, PP(m, FC5), 0, nullptr, m->dz, 0, nullptr, nullptr, B, z, 64, 1, 0, ACT_NONE, st));
   // ---- latent block ----
-  TRY(ava_latent_bwd(m->zs, m->dz, m->u, m->d, m->eps_w_last, m->eps_d_last, m->dmu, m->du, m->dlogd, B, z, st));
+  TRY(ava_latent_bwd_scaled(m->zs, m->dz, m->u, m->d, m->eps_w_last, m->eps_d_last, m->dmu, m->du, m->dlogd, B, z,
+                            m->bwd_scale, st));
   mark(m, CAT_LATENT_LOSS, st);
   // ---- heads: dX of fc41/42/43 into the three 64-wide slices of dh3 (masked by h3's ReLU), one launch ----
   const AvaGemmProblem hdx[3] = {
@@ -791,6 +825,7 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, b
                             l == 0 ? nullptr : gnext, B, st));
     float* t = gcur; gcur = gnext; gnext = t;
   }
+  m->bwd_scale = nullptr;              // consumed
   return reduce_wgrads(m, whole ? 0 : 0, whole ? NCONV : 7, B, st);      // encoder (whole: all 14) weight/bias gradients
 }
 
@@ -798,7 +833,10 @@ extern "C" int ava_adam_step(ava_model* m, double lr, double beta1, double beta2
                              ava_stream_t s) {
   if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr) return AVA_EINVAL;
   mark(m, -1, to_stream(s));
-  const int rc = ava_adam_flat(m->P, m->G, m->M, m->V, m->arena, lr, beta1, beta2, eps, step, s);
+  // the reference raises inside forward() when d is not positive (vae.py:312) and never reaches optimizer.step():
+  // the update is skipped on the device when the last forward set its status word
+  const int rc = ava_adam_flat_guarded(m->P, m->G, m->M, m->V, m->arena, lr, beta1, beta2, eps, step, m->status_last,
+                                       to_stream(s));
   mark(m, CAT_ADAM, to_stream(s));
   return rc;
 }

@@ -51,6 +51,13 @@ def wait_all(handles):
             h.wait()
 
 
+def allreduce_max_(t):
+    """In-place MAX over ranks (status words)."""
+    if active():
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    return t
+
+
 def broadcast_parameters(model, src=0):
     """Identical weights / BatchNorm buffers / Adam state on every rank."""
     if active():

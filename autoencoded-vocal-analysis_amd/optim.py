@@ -42,8 +42,15 @@ class FlatAdam(torch.optim.Adam):
                              'exp_avg': m, 'exp_avg_sq': v}
 
     def zero_grad(self, set_to_none=True):
-        """The HIP backward overwrites the whole gradient arena every step (the reference
-        resets grads to None before each step, vae.py:348), so there is nothing to clear."""
+        """torch semantics without a pass over the 70 MB arena: the call only records that the gradients are gone
+        (``vae.py:348``); the next backward then OVERWRITES the arena, whereas a backward that follows another
+        backward with no ``zero_grad()`` in between accumulates into it (``VAE._backward_device``), and ``step()``
+        with no gradient since the last ``zero_grad()`` does nothing -- exactly what ``torch.optim.Adam`` does with
+        ``p.grad is None`` parameters.  ``p.grad`` itself keeps pointing at its arena view (stale values until the
+        next backward) instead of becoming ``None``; with ``set_to_none=False`` the arena is zeroed."""
+        self._model._grad_state = "none"
+        if not set_to_none:
+            self._model._grads.zero_()
         return None
 
     @torch.no_grad()
@@ -52,6 +59,8 @@ class FlatAdam(torch.optim.Adam):
         if g['weight_decay'] != 0 or g['amsgrad'] or g['maximize']:
             raise NotImplementedError("FlatAdam implements the reference's plain Adam only")
         m = self._model
+        if getattr(m, "_grad_state", "filled") == "none":
+            return None                         # every p.grad is "None": torch's Adam skips such parameters
         self._step_count_flat += 1
         b1, b2 = g['betas']
         lib = _lib.load()

@@ -40,20 +40,39 @@ _BN_CH = [1, 8, 8, 16, 16, 24, 24, 32, 24, 24, 16, 16, 8, 8]
 
 class _ElboFn(torch.autograd.Function):
     """Makes ``loss = model(x); loss.backward()`` work: forward ran the HIP forward,
-    backward runs the HIP backward into the gradient arena (vae.py:350-352)."""
+    backward runs the HIP backward into the gradient arena (vae.py:350-352).
+
+    The activations a backward needs live in the model's ONE workspace (not in per-call autograd
+    storage), so a backward is only valid while no later ``forward`` / ``encode`` / ``decode`` /
+    ``get_latent`` / ``visualize`` has overwritten them, and only once; both are checked (the
+    reference's autograd would handle e.g. ``(model(x1) + model(x2)).backward()``; here it raises)."""
 
     @staticmethod
     def forward(ctx, anchor, model, x):
         ctx.model = model
         ctx.x = x
-        return model._forward_device(x, need_grad=True).clone()
+        loss = model._forward_device(x, need_grad=True).clone()
+        ctx.generation = model._generation
+        ctx.done = False
+        return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.model._backward_device(ctx.x)
-        # the reference's loss is the root of the graph (grad_out == 1); honour other scalings
-        ctx.model._grads.mul_(grad_out)
-        ctx.model._attach_grads()
+        model = ctx.model
+        if ctx.done:
+            raise RuntimeError("backward was already run for this forward (the HIP path keeps no per-call graph)")
+        if ctx.generation != model._generation:
+            raise RuntimeError("the saved activations of this forward were overwritten by a later forward / encode / "
+                               "decode / get_latent / visualize call on the same model; run backward right after "
+                               "the forward it belongs to")
+        ctx.done = True
+        # grad_out is 1 when the loss is the root of the graph (the reference's use); any other value scales the two
+        # roots of the hand-written backward on the device (no host sync, no pass over the 70 MB gradient arena)
+        scale = grad_out.detach().to(device=model.device, dtype=torch.float32).reshape(1).contiguous()
+        _lib.check(_lib.load().ava_set_backward_scale(model._handle, scale.data_ptr()), "ava_set_backward_scale")
+        model._scale_keepalive = scale
+        model._backward_device(ctx.x)
+        model._attach_grads()
         return None, None, None
 
 
@@ -87,6 +106,8 @@ class VAE(nn.Module):
         self._max_batch = 0
         self._workspace = None
         self._last_x = None
+        self._generation = 0          # bumped by every call that overwrites the workspace (see _ElboFn)
+        self._grad_state = "none"     # "none" (zero_grad) | "filled": what the next backward / step must do (optim.py)
 
     # ------------------------------------------------------------------ network definition
     def _build_network(self):
@@ -280,6 +301,7 @@ class VAE(nn.Module):
         loss to ``self._loss_acc`` on the device (the epoch loops' running sum)."""
         B = x.shape[0]
         self._ensure(B)
+        self._generation += 1
         if self.noise_source is None:
             # device counter RNG: the noise is drawn inside the forward's first launch (same stream as ava_fill_normal)
             n = B * (self.z_dim + 1)
@@ -301,7 +323,17 @@ class VAE(nn.Module):
         return self._loss_buf[0]
 
     def _backward_device(self, x):
+        """ava_backward into the gradient arena with torch's accumulation rule: after ``zero_grad()`` the arena is
+        overwritten; a second backward without ``zero_grad()`` in between ADDS to it (gradient accumulation over
+        micro-batches), at the price of one extra pass over the arena for that call only."""
         lib = _lib.load()
+        held = self._grads.clone() if self._grad_state == "filled" else None
+        self._backward_kernels(lib, x)
+        if held is not None:
+            self._grads.add_(held)
+        self._grad_state = "filled"
+
+    def _backward_kernels(self, lib, x):
         if not _dist.active():
             _lib.check(lib.ava_backward(self._handle, x.data_ptr(), x.shape[0], _lib.stream()), "ava_backward")
             return
@@ -314,13 +346,51 @@ class VAE(nn.Module):
             off, cnt = ctypes.c_int64(), ctypes.c_int64()
             _lib.check(lib.ava_grad_bucket(self._handle, part, ctypes.byref(off), ctypes.byref(cnt)), "ava_grad_bucket")
             pending.append(_dist.allreduce_gradients_async(self._grads[off.value:off.value + cnt.value]))
+        # bench.py sets _comm_events to a list: the time the compute stream then spends blocked on the collectives
+        # (end of the last backward kernel -> all buckets reduced) is the exposed communication of the step
+        evs = getattr(self, "_comm_events", None)
+        if evs is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         _dist.wait_all(pending)
+        if evs is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            evs.append((e0, e1))
 
     def _check_status(self):
+        """Blocking check of the device status word (d not positive in some forward so far).  Under data parallelism
+        the word is OR-ed over the ranks first, so that every rank raises together."""
+        if _dist.active():
+            _dist.allreduce_max_(self._status)
         if int(self._status.item()) != 0:
-            self._status.zero_()
-            # LowRankMultivariateNormal's argument validation (vae.py:312) raises the same type
-            raise ValueError("Expected parameter cov_diag to be positive (d = exp(.) under/overflowed)")
+            self._raise_invalid_posterior()
+
+    def _raise_invalid_posterior(self):
+        self._status.zero_()
+        self._status_poll = None
+        # LowRankMultivariateNormal's argument validation (vae.py:312) raises the same type
+        raise ValueError("Expected parameter cov_diag to be positive (d = exp(.) under/overflowed)")
+
+    def _poll_status(self):
+        """Non-blocking form for the epoch loops.  The reference raises inside the offending ``forward``
+        (vae.py:312); the loops here never wait for the device, so after every step the status word is copied to
+        page-locked host memory asynchronously and looked at as soon as the copy has landed (typically one or two
+        steps later, at the latest at the end of the epoch).  Parameters stay those of before the offending step in
+        the meantime: ``ava_adam_step`` skips the update on the device while the word is set."""
+        poll = getattr(self, "_status_poll", None)
+        if poll is not None:
+            host, ev = poll
+            if not ev.query():
+                return                                   # previous copy still in flight: look again next step
+            if int(host[0]) != 0:
+                self._raise_invalid_posterior()
+        if getattr(self, "_status_host", None) is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_host.copy_(self._status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._status_poll = (self._status_host, ev)
 
     def _workspace_tensor(self, name, shape):
         n = ctypes.c_int64()
@@ -337,6 +407,7 @@ class VAE(nn.Module):
         x = self._prep_x(x)
         B = x.shape[0]
         self._ensure(B)
+        self._generation += 1
         mu = torch.empty(B, self.z_dim, device=self.device)
         u = torch.empty(B, self.z_dim, device=self.device)
         d = torch.empty(B, self.z_dim, device=self.device)
@@ -350,6 +421,7 @@ class VAE(nn.Module):
         z = z.to(device=self.device, dtype=torch.float32).contiguous()
         B = z.shape[0]
         self._ensure(B)
+        self._generation += 1
         out = torch.empty(B, X_DIM, device=self.device)
         rc = _lib.load().ava_decode(self._handle, z.data_ptr(), B, 1 if self.training else 0, out.data_ptr(),
                                     _lib.stream())
@@ -387,6 +459,7 @@ class VAE(nn.Module):
             self._forward_device(data, need_grad=True, accumulate=True)
             self._backward_device(data)
             self.optimizer.step()
+            self._poll_status()
         self._check_status()
         train_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, batch_idx + 1)
         train_loss /= _dist.global_dataset_len(len(train_loader.dataset))

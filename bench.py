@@ -7,18 +7,28 @@ A "step" is one full optimisation step (zero_grad, forward, backward, gradient
 all-reduce when N > 1, Adam) of the reference's VAE (``ava/models/vae.py:347-353``)
 on one synthetic batch of 256 spectrograms of 128x128 per GPU, z_dim 32, fp32
 (BASELINE.json ``configs[1]``), with the batches already resident in HBM.
-For N > 1 launch through ``python -m torch.distributed.run`` (one rank per GPU);
-per-GPU work is fixed (weak scaling) and the value is the whole-job rate.
+
+N > 1: one process per GPU over RCCL.  Either the caller starts the ranks
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK /
+LOCAL_RANK / WORLD_SIZE are in the environment) or ``bench.py --gpus N`` is run
+plainly, in which case it starts the N ranks itself (a child ``torch.distributed.run``,
+launched before this process touches the GPU) and relays rank 0's line.  Per-GPU work
+is fixed (``"scaling": "weak"``, ``--per-gpu-batch``, default 256) and ``value`` is the
+whole-job rate; the same run also times the strong-scaling reading of configs[3]
+(``--global-batch``, default 1024, split over the ranks) and reports it under
+``strong_scaling``.
 
 Rank 0 prints ONE JSON line: metric/value/unit as the contract requires plus
 ``roofline`` (conv + convT + BatchNorm kernels forward+backward against the HBM
-roofline) and, at N = 1, ``cpu_baseline`` (the CPU oracle
-timed on the host cores on a bounded sample of the same workload).
+roofline), ``dist`` (backend, ranks seen, exposed all-reduce
+time per step) and, at N = 1, ``cpu_baseline`` (the CPU oracle timed on the host
+cores on a bounded sample of the same workload).
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,26 +36,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
-A_CONV_BYTES = 175.25 * 4 * 128 * 128      # algorithmic HBM bytes / spectrogram, conv fwd+bwd
+A_CONV_PER_PIXEL = 175.25 * 4              # algorithmic HBM bytes / pixel of a spectrogram, conv fwd+bwd, fp32
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 CATS = ["conv_fwd", "conv_bwd_data", "conv_wgrad", "bn", "gemm", "layout", "latent_loss", "adam", "pack"]
 CONV_FAMILY = ("conv_fwd", "conv_bwd_data", "conv_wgrad", "bn", "pack")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--per-gpu-batch", "--batch", dest="batch", type=int, default=256,
+                    help="spectrograms per GPU and step (weak-scaling reading of the metric; this is `value`)")
+    ap.add_argument("--global-batch", type=int, default=1024,
+                    help="global batch of the strong-scaling leg (configs[3]); 0 skips the leg")
     ap.add_argument("--z-dim", type=int, default=32)
     ap.add_argument("--pool", type=int, default=8, help="distinct device-resident batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
-    return ap.parse_args()
+    ap.add_argument("--no-roofline", action="store_true", help="skip the two HIP-event passes")
+    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
+                    help="bounded: 1 warm-up + 4 timed steps (best thread count) and 1 + 2 (all cores), ~40 s; "
+                         "full: BASELINE.md section 3's 3 warm-up + 10 timed steps for both")
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)    # 'gloo': ranks share cuda:0 (tests on a 1-GPU box)
+    ap.add_argument("--master-port", type=int, default=0, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run (this process has
+    not initialised the GPU and never does) and relay rank 0's JSON line."""
+    import socket
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in res.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line)
+    raise SystemExit(res.returncode if res.returncode else (0 if line is not None else 1))
 
 
 def one_step(model, x):
@@ -56,139 +97,228 @@ def one_step(model, x):
     model.optimizer.step()
 
 
-def cpu_baseline(batch, z_dim, steps):
-    """CPU oracle (stock PyTorch-CPU ops, autograd backward, restated Adam) on `steps` batches."""
+def cpu_model_string():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch, z_dim, protocol):
+    """CPU oracle (stock PyTorch-CPU ops = the ATen kernels the reference dispatches to, autograd backward, restated
+    Adam) on the SAME batch shape; median of the timed steps.  Two thread settings: the fastest one found on this host
+    class (tools/cpu_threads.py: 16 of 8/16/32/64/128 on the 2x64-core EPYC 9575F box) and all cores."""
+    import numpy as np
+    import torch
     from ava_amd import synthetic as syn
     from oracle import vae_oracle as O
     cores = os.cpu_count() or 1
-    threads = min(cores, 16)     # fastest of 8/16/32/64/128 on the 2x64-core EPYC 9575F box (tools/cpu_threads.py)
-    torch.set_num_threads(threads)
-    P = O.to_params(syn.fixture_parameters(z_dim), requires_grad=True)
-    running = O.fresh_running_stats()
-    opt = {"step": 0, "m": {}, "v": {}}
     x = torch.from_numpy(syn.spectrograms(batch))
     ew, ed = [torch.from_numpy(a) for a in syn.noise(batch, z_dim)]
-    O.train_step(P, x, ew, ed, running, opt)                   # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        O.train_step(P, x, ew, ed, running, opt)
-    dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "spectrograms/s", "cores": threads, "kind": "port",
-            "sample": "%d train steps of batch %d (z=%d) after 1 warm-up, oracle/vae_oracle.py on torch-CPU, %d host cores visible"
-                      % (steps, batch, z_dim, cores)}
+
+    def run(threads, warm, timed):
+        torch.set_num_threads(threads)
+        P = O.to_params(syn.fixture_parameters(z_dim), requires_grad=True)
+        running = O.fresh_running_stats()
+        opt = {"step": 0, "m": {}, "v": {}}
+        for _ in range(warm):
+            O.train_step(P, x, ew, ed, running, opt)
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            O.train_step(P, x, ew, ed, running, opt)
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        return {"threads": threads, "torch_num_threads": torch.get_num_threads(), "warmup": warm, "timed": timed,
+                "median_ms_per_step": round(1e3 * med, 1), "value": round(batch / med, 2)}
+
+    best_t = min(cores, 16)
+    plan = {"bounded": ((1, 4), (1, 2)), "full": ((3, 10), (3, 10))}[protocol]
+    best = run(best_t, *plan[0])
+    allc = run(cores, *plan[1]) if cores != best_t else best
+    top = best if best["value"] >= allc["value"] else allc
+    return {"value": top["value"], "unit": "spectrograms/s", "cores": top["threads"], "kind": "port",
+            "sample": "median of %d train steps of batch %d (z=%d) after %d warm-up, oracle/vae_oracle.py on torch-CPU"
+                      % (top["timed"], batch, z_dim, top["warmup"]),
+            "cpu_model": cpu_model_string(), "os_cpu_count": cores, "protocol": protocol,
+            "best_thread_count": best, "all_cores": allc}
 
 
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)                                    # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the VAE hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if args.backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as td
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            td.init_process_group(backend=args.backend)
     from ava_amd import _lib, synthetic as syn
     from ava_amd import dist as adist
     from ava_amd.vae import VAE
+    from ava_amd.layout import X_SHAPE
 
     torch.manual_seed(1234)
     model = VAE(z_dim=args.z_dim, device_name="cuda")
     adist.broadcast_parameters(model)
     model.train()
-    B = args.batch
-    # device-resident pool of distinct synthetic batches (hash recipe, salt 1001; each rank its own shard)
-    pool = [torch.from_numpy(syn.spectrograms(B, salt=1001, start_item=(rank * args.pool + i) * B)).cuda()
-            for i in range(args.pool)]
+    H, W = X_SHAPE
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_step(model, pool[i % len(pool)])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(model, pool[i % len(pool)])
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def make_pool(B):
+        # device-resident pool of distinct synthetic batches (hash recipe, salt 1001; each rank its own shard)
+        return [torch.from_numpy(syn.spectrograms(B, salt=1001, start_item=(rank * args.pool + i) * B)).cuda()
+                for i in range(args.pool)]
+
+    def timed(pool, steps, warmup):
+        for i in range(warmup):
+            one_step(model, pool[i % len(pool)])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(model, pool[i % len(pool)])
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    B = args.batch
+    pool = make_pool(B)
+    dt = timed(pool, args.steps, args.warmup)
     model._check_status()
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
+    elbo = float(model._loss_buf[0].item()) / B
 
-    # ---- roofline leg: same K steps with HIP events around every launch group of the driver -----------
-    lib = _lib.load()
-    ms = (ctypes.c_float * 16)()
-    cnt = (ctypes.c_int * 16)()
-    lib.ava_profile_enable(model._handle, 1)                # fine pass: an event after every launch group
-    for i in range(args.steps):
-        one_step(model, pool[i % len(pool)])
-        lib.ava_profile_read(model._handle, ms, cnt)
-    lib.ava_profile_enable(model._handle, 0)
-    torch.cuda.synchronize()
-    ev_sum_ms = sum(ms[i] for i in range(len(CATS))) / args.steps          # all categories, event-bracketed
-    per_step = {c: ms[i] / args.steps for i, c in enumerate(CATS)}
-    launches = {c: cnt[i] // args.steps for i, c in enumerate(CATS)}
-    conv_ms_fine = sum(per_step[c] for c in CONV_FAMILY)
-    # coarse pass: events only where the kernel family changes (~20 records per step instead of ~100, which stretch
-    # the step by 10-15 %): the conv family's kernel time as it is inside the timed step
-    ms2 = (ctypes.c_float * 16)()
-    cnt2 = (ctypes.c_int * 16)()
-    lib.ava_profile_enable(model._handle, 2)
-    for i in range(args.steps):
-        one_step(model, pool[i % len(pool)])
-        lib.ava_profile_read(model._handle, ms2, cnt2)
-    lib.ava_profile_enable(model._handle, 0)
-    torch.cuda.synchronize()
-    conv_ms = sum(ms2[i] for i, c in enumerate(CATS) if c in CONV_FAMILY) / args.steps
-    coarse_sum_ms = sum(ms2[i] for i in range(len(CATS))) / args.steps
-    coarse_events = sum(cnt2[i] for i in range(len(CATS))) // args.steps
-    achieved = B * A_CONV_BYTES / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
-    # HBM bytes of the same kernels from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of
-    # this command; tools/pmc_traffic.py) -- counters cannot be read from inside this process, so the committed summary of
-    # the latest pass is quoted; null when there is none for this batch size
-    traffic, traffic_src = None, None
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[::-1]:
-        try:
-            t = json.load(open(path))
-            if B == 256 and world == 1:
-                traffic, traffic_src = t["conv_family_bytes_per_step"], os.path.relpath(path, ROOT)
-            break
-        except Exception:
-            pass
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "conv+convT+BatchNorm kernels, forward+backward (SURVEY 8d aggregate)",
-                "algorithmic_bytes_per_step": B * A_CONV_BYTES, "conv_family_ms_per_step": round(conv_ms, 4),
-                # `achieved` uses the coarse pass (HIP events only at kernel-family boundaries); the fine pass below
-                # (an event after each of the ~100 launch groups) stretches the step and is informational
-                "coarse_pass": {"events_per_step": coarse_events, "all_kernels_ms_per_step": round(coarse_sum_ms, 4)},
-                "fine_pass": {"all_kernels_ms_per_step": round(ev_sum_ms, 4), "conv_family_ms_per_step": round(conv_ms_fine, 4)},
-                "ms_per_step_by_category": {k: round(v, 4) for k, v in per_step.items()},
-                "launch_groups_per_step": launches}
+    # ---- exposed communication: time the compute stream spends waiting for the gradient all-reduces --------------
+    dist_info = {"backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world,
+                 "ranks_seen": world, "grad_allreduce_bytes_per_step": int(model._grads.numel()) * 4 if world > 1 else 0,
+                 "buckets": _lib.load().ava_backward_num_parts() if world > 1 else 0}
+    if world > 1:
+        t = torch.ones(1, device="cuda")
+        torch.distributed.all_reduce(t)
+        dist_info["ranks_seen"] = int(round(float(t.item())))
+        model._comm_events = []
+        n_comm = min(args.steps, 50)
+        for i in range(n_comm):
+            one_step(model, pool[i % len(pool)])
+        sync()
+        ev = model._comm_events
+        model._comm_events = None
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        te = torch.tensor([exposed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+        dist_info["exposed_comm_ms_per_step"] = round(float(te.item()), 4)
 
-    out = {"metric": "spectrograms/sec, VAE train step (fwd+bwd+Adam), 128x128, batch %d per GPU" % B,
+    # ---- roofline leg: same K steps with HIP events on the launch stream -----------------------------------------
+    roofline = None
+    if not args.no_roofline:
+        lib = _lib.load()
+        ms = (ctypes.c_float * 16)()
+        cnt = (ctypes.c_int * 16)()
+        lib.ava_profile_enable(model._handle, 1)                # fine pass: an event after every launch group
+        for i in range(args.steps):
+            one_step(model, pool[i % len(pool)])
+            lib.ava_profile_read(model._handle, ms, cnt)
+        lib.ava_profile_enable(model._handle, 0)
+        torch.cuda.synchronize()
+        ev_sum_ms = sum(ms[i] for i in range(len(CATS))) / args.steps
+        per_step = {c: ms[i] / args.steps for i, c in enumerate(CATS)}
+        launches = {c: cnt[i] // args.steps for i, c in enumerate(CATS)}
+        conv_ms_fine = sum(per_step[c] for c in CONV_FAMILY)
+        # coarse pass: events only where the kernel family changes (~10 records per step instead of ~100, which
+        # stretch the step by 10-15 %): the conv family's kernel time as it is inside the timed step
+        ms2 = (ctypes.c_float * 16)()
+        cnt2 = (ctypes.c_int * 16)()
+        lib.ava_profile_enable(model._handle, 2)
+        for i in range(args.steps):
+            one_step(model, pool[i % len(pool)])
+            lib.ava_profile_read(model._handle, ms2, cnt2)
+        lib.ava_profile_enable(model._handle, 0)
+        torch.cuda.synchronize()
+        conv_ms = sum(ms2[i] for i, c in enumerate(CATS) if c in CONV_FAMILY) / args.steps
+        coarse_sum_ms = sum(ms2[i] for i in range(len(CATS))) / args.steps
+        coarse_events = sum(cnt2[i] for i in range(len(CATS))) // args.steps
+        a_conv = A_CONV_PER_PIXEL * H * W
+        achieved = B * a_conv / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+        # HBM bytes of the same kernels from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+        # passes of this command; tools/pmc_traffic.py) -- counters cannot be read from inside this process, so the
+        # committed summary of the latest pass is quoted; null when there is none for this configuration
+        traffic, traffic_src = None, None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[::-1]:
+            try:
+                tj = json.load(open(path))
+                if B == 256 and world == 1 and args.z_dim == 32:
+                    traffic, traffic_src = tj["conv_family_bytes_per_step"], os.path.relpath(path, ROOT)
+                break
+            except Exception:
+                pass
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "conv+convT+BatchNorm kernels, forward+backward (SURVEY 8d aggregate)",
+                    "algorithmic_bytes_per_step": B * a_conv, "conv_family_ms_per_step": round(conv_ms, 4),
+                    # `achieved` uses the coarse pass (HIP events only at kernel-family boundaries); the fine pass
+                    # (an event after each of the ~100 launch groups) stretches the step and is informational
+                    "coarse_pass": {"events_per_step": coarse_events, "all_kernels_ms_per_step": round(coarse_sum_ms, 4)},
+                    "fine_pass": {"all_kernels_ms_per_step": round(ev_sum_ms, 4), "conv_family_ms_per_step": round(conv_ms_fine, 4)},
+                    "ms_per_step_by_category": {k: round(v, 4) for k, v in per_step.items()},
+                    "launch_groups_per_step": launches}
+
+    # ---- strong-scaling reading of configs[3]: a fixed global batch split over the ranks --------------------------
+    strong = None
+    if args.global_batch and args.global_batch % world == 0 and args.global_batch // world != B:
+        Bs = args.global_batch // world
+        del pool
+        spool = make_pool(Bs)
+        ssteps, swarm = max(10, args.steps // 2), max(5, args.warmup // 2)
+        sdt = timed(spool, ssteps, swarm)
+        strong = {"global_batch": args.global_batch, "per_gpu_batch": Bs, "steps": ssteps, "warmup": swarm,
+                  "ms_per_step": round(1e3 * sdt / ssteps, 4), "value": round(args.global_batch * ssteps / sdt, 1),
+                  "unit": "spectrograms/s", "scaling": "strong"}
+        del spool
+
+    out = {"metric": "spectrograms/sec, VAE train step (fwd+bwd+Adam), %dx%d, batch %d per GPU" % (H, W, B),
            "value": round(value, 1), "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "configs[1]: mouse_sylls VAE, batch 256 synthetic 128x128 fp32 spectrograms per GPU, z=%d, "
-                                  "train step = zero_grad+forward+backward+Adam, device-resident batches" % args.z_dim,
-                      "global_batch": world * B, "z_dim": args.z_dim, "parallelism": "dp%d" % world},
-           "elbo_last_batch_mean": round(float(model._loss_buf[0].item()) / B, 3),
-           "roofline": roofline}
+           "config": {"workload": "configs[%d]: mouse_sylls VAE, batch %d synthetic %dx%d fp32 spectrograms per GPU, z=%d, "
+                                  "train step = zero_grad+forward+backward%s+Adam, device-resident batches"
+                                  % (3 if world > 1 else (2 if args.z_dim == 64 else 1), B, H, W, args.z_dim,
+                                     "+RCCL grad all-reduce" if world > 1 else ""),
+                      "global_batch": world * B, "per_gpu_batch": B, "z_dim": args.z_dim, "parallelism": "dp%d" % world},
+           "elbo_last_batch_mean": round(elbo, 3), "dist": dist_info}
+    if roofline is not None:
+        out["roofline"] = roofline
+    if strong is not None:
+        out["strong_scaling"] = strong
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, args.z_dim, args.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(B, args.z_dim, args.cpu_protocol)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -62,7 +62,10 @@ void ava_model_destroy(ava_model* m);
  *   status_out (device int, may be NULL): OR-ed with 1 when some d is not > 0 (reference raises ValueError);
  *     sticky -- the caller clears it after reading.
  * x, eps_w, eps_d must stay valid until ava_backward has run.
- * Leaves every intermediate needed by ava_backward in the workspace. */
+ * Leaves every intermediate needed by ava_backward in the workspace, together with the BatchNorm mode: the backward of
+ * a bn_train = 0 forward differentiates the running-statistics form (dx = gamma*invstd*g), as autograd does for
+ * model.eval(); loss = model(x); loss.backward().  ava_encode / ava_decode overwrite those intermediates: an
+ * ava_backward after them returns AVA_EINVAL until the next ava_forward. */
 int ava_forward(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d,
                 int bn_train, float* loss_out, double* loss_accum, int* status_out, ava_stream_t s);
 /* The same with the noise of rsample() (vae.py:313) drawn by the device inside the forward's first launch instead of
@@ -74,6 +77,11 @@ int ava_forward_noise(ava_model* m, const float* x, int B, float* eps, uint64_t 
 /* loss.backward() (vae.py:352) for the forward that just ran: fills the gradient arena
  * (overwrites: the reference zero_grad()s before every step, vae.py:348). */
 int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);
+/* autograd hands loss.backward() a grad_output; when the caller backpropagates c*loss (or a sum the loss is part of)
+ * it is not 1.  loss_scale: device pointer to that scalar, read by the NEXT ava_backward / ava_backward_part sequence
+ * (the seed gradient and the prior/entropy terms are multiplied by it: the gradient is linear in it), then forgotten.
+ * NULL (the default after every ava_forward) means 1.  Replaces a 70 MB pass over the gradient arena. */
+int ava_set_backward_scale(ava_model* m, const float* loss_scale);
 /* The same backward in ava_backward_num_parts() (= 3) consecutive parts, so that a data-parallel caller can
  * all-reduce each part's gradients while the next part runs.  Part p completes gradient bucket p, a contiguous
  * range of the arena returned by ava_grad_bucket (floats): bucket 0 = fc8, convt1..7, bn8..14 (tail of the arena),
@@ -82,7 +90,9 @@ int ava_backward_num_parts(void);
 int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s);
 int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count);
 /* torch.optim.Adam.step (torch/optim/adam.py:414-547), one fused pass over the four arenas.
- * `step` is the 1-based count after increment. */
+ * `step` is the 1-based count after increment.  When the last ava_forward raised its status word (some d not > 0: the
+ * reference raises ValueError inside forward and never reaches optimizer.step(), vae.py:312,353) the kernel leaves
+ * parameters and moments untouched. */
 int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step, ava_stream_t s);
 /* VAE.encode (vae.py:216-233): mu,u,d [B,z] (d = exp(.)); bn_train as above. */
 int ava_encode(ava_model* m, const float* x, int B, int bn_train, float* mu, float* u, float* d, ava_stream_t s);

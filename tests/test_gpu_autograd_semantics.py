@@ -1,0 +1,179 @@
+"""torch-autograd / torch.optim semantics of the public API that the hand-written backward has to reproduce
+explicitly: eval-mode gradients, grad_output scaling, accumulation without zero_grad, stale-workspace
+and double-backward guards, the Adam update itself, and the d <= 0 error path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, sample_idx
+from gpu_util import build_model, rel
+from ava_amd import synthetic as syn
+from ava_amd.layout import param_specs
+from oracle import vae_oracle as O
+
+
+def _fixed(model, B, z, sw=2002, sd=3003):
+    ew, ed = syn.noise(B, z, sw, sd)
+    model.noise_source = lambda b, zz: (ew, ed)
+    return torch.from_numpy(ew), torch.from_numpy(ed)
+
+
+def _grad_errors(model, P, z):
+    named = dict(model.named_parameters())
+    out = {}
+    for s in param_specs(z):
+        g = named[s.name].grad.detach().cpu().double().numpy().ravel()
+        w = P[s.name].grad.double().numpy().ravel()
+        out[s.name] = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-30)
+    return out
+
+
+def test_eval_mode_backward_matches_oracle():
+    """model.eval(); loss = model(x); loss.backward(): BatchNorm ran on its running statistics, so its backward is
+    dx = gamma*invstd*g with no batch-statistic terms (autograd does this in the reference)."""
+    B, z = 8, 32
+    model = build_model(z)
+    x = torch.from_numpy(syn.spectrograms(B))
+    ew, ed = _fixed(model, B, z)
+    running = O.fresh_running_stats()
+    P = O.to_params(syn.fixture_parameters(z), requires_grad=True)
+    # one train-mode forward on both sides so that the running statistics are not the trivial (0, 1)
+    with torch.no_grad():
+        model.forward(x)
+        O.forward({k: v.detach() for k, v in P.items()}, x, ew, ed, running, True)
+    model.eval()
+    model.optimizer.zero_grad()
+    loss = model.forward(x)
+    loss.backward()
+    out = O.forward(P, x, ew, ed, running, False)
+    out["loss"].backward()
+    assert rel(float(loss.item()), float(out["loss"])) < 1e-5
+    errs = _grad_errors(model, P, z)
+    bad = {k: v for k, v in errs.items() if v > 2e-3}
+    assert not bad, bad
+    # and it really is a different derivative from the train-mode one
+    model.train()
+    model.optimizer.zero_grad()
+    model.forward(x).backward()
+    assert _grad_errors(model, P, z)["conv3.weight"] > 1e-2
+
+
+def test_grad_output_scale_is_applied_on_the_device():
+    B, z = 6, 32
+    model = build_model(z)
+    x = torch.from_numpy(syn.spectrograms(B))
+    _fixed(model, B, z)
+    model.optimizer.zero_grad()
+    model.forward(x).backward()
+    g1 = model._grads.clone()
+    model.optimizer.zero_grad()
+    (model.forward(x) * 2.5).backward()
+    g2 = model._grads.clone()
+    model.optimizer.zero_grad()
+    model.forward(x).backward()                               # the scale does not stick
+    assert torch.equal(model._grads, g1)
+    err = float((g2 - 2.5 * g1).double().norm() / (2.5 * g1).double().norm())
+    assert err < 1e-6, err
+
+
+def test_backward_accumulates_until_zero_grad():
+    B, z = 4, 32
+    model = build_model(z)
+    xa = torch.from_numpy(syn.spectrograms(B, salt=5))
+    xb = torch.from_numpy(syn.spectrograms(B, salt=6))
+    _fixed(model, B, z)
+    model.optimizer.zero_grad()
+    model.forward(xa).backward()
+    ga = model._grads.clone()
+    model.optimizer.zero_grad()
+    model.forward(xb).backward()
+    gb = model._grads.clone()
+    model.optimizer.zero_grad()
+    model.forward(xa).backward()
+    model.forward(xb).backward()                              # no zero_grad in between: torch accumulates
+    assert torch.equal(model._grads, gb + ga) or float((model._grads - (ga + gb)).abs().max()) == 0.0
+    assert model.fc8.weight.grad.data_ptr() == model._grad_view("fc8.weight").data_ptr()
+    # step() with no gradient since zero_grad() is a no-op, like torch.optim.Adam with p.grad None
+    model.optimizer.zero_grad()
+    before = model._params.clone()
+    model.optimizer.step()
+    assert torch.equal(model._params, before) and model.optimizer._step_count_flat == 0
+
+
+def test_stale_or_repeated_backward_raises():
+    B, z = 4, 32
+    model = build_model(z)
+    x = torch.from_numpy(syn.spectrograms(B))
+    _fixed(model, B, z)
+    loss = model.forward(x)
+    model.encode(x)                                           # overwrites the saved activations
+    with pytest.raises(RuntimeError, match="overwritten"):
+        loss.backward()
+    l1 = model.forward(x)
+    l2 = model.forward(x)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        (l1 + l2).backward()
+    l3 = model.forward(x)
+    l3.backward()
+    with pytest.raises(RuntimeError, match="already run"):
+        l3.backward()
+    # the C ABI refuses as well
+    from ava_amd import _lib
+    lib = _lib.load()
+    xd = x.cuda()
+    model._forward_device(xd, need_grad=True)
+    model.decode(torch.zeros(B, z))
+    assert lib.ava_backward(model._handle, xd.data_ptr(), B, _lib.stream()) == -1
+
+
+def test_adam_delta_matches_reference_golden():
+    """The parameter UPDATE of the first Adam step (value after minus value before) against the reference's, entry by
+    entry: the first step moves every weight by -lr*sign(g) (bias-corrected m / sqrt(v) = +-1) wherever |g| >> eps, so
+    a step that did nothing, or went the wrong way, is off by lr resp. 2*lr = 1000x the tolerance."""
+    B, z = 8, 32
+    G = load_golden("step_B8_z32.npz")
+    model = build_model(z)
+    _fixed(model, B, z)
+    x = torch.from_numpy(syn.spectrograms(B))
+    fp = syn.fixture_parameters(z)
+    model.optimizer.zero_grad()
+    model.forward(x).backward()
+    grads = {n: p.grad.detach().cpu().numpy().ravel().copy() for n, p in model.named_parameters()}
+    model.optimizer.step()
+    named = dict(model.named_parameters())
+    checked = 0
+    for s in param_specs(z):
+        idx = sample_idx(s.numel, s.index)
+        init = fp[s.name].ravel()[idx].astype(np.float64)
+        got = named[s.name].detach().cpu().numpy().ravel()[idx].astype(np.float64) - init
+        want = G["s1.val." + s.name].astype(np.float64) - init
+        gref = G["s1.grad." + s.name]
+        gscale = float(G["s1.gradnorm." + s.name]) / np.sqrt(s.numel)
+        # entries whose gradient is well above Adam's eps and above the ReLU-flip noise of its tensor
+        solid = (np.abs(gref) > 1e-5) & (np.abs(gref) > 0.05 * gscale) & (np.abs(grads[s.name][idx]) > 1e-5)
+        if s.layer in ("conv1", "bn1"):
+            continue                                          # flip-sensitive tensors of this fixture
+        assert np.abs(got[solid] - want[solid]).max(initial=0.0) < 2e-6, s.name     # lr = 1e-3; fp32 ulp of a weight ~ 6e-8
+        assert np.all(np.sign(got[solid]) == -np.sign(gref[solid])), s.name
+        checked += int(solid.sum())
+    assert checked > 600
+
+
+def test_invalid_posterior_in_train_epoch_raises_and_keeps_parameters():
+    """d = exp(.) not positive: the reference raises ValueError inside forward and never updates.  Here the epoch loop
+    does not wait for the device; the Adam kernel skips the update on the device, and the loop raises as soon as the
+    status word has reached the host."""
+    z, B = 32, 4
+    model = build_model(z)
+    with torch.no_grad():
+        model.fc43.bias.fill_(float("nan"))
+    before = model._params.clone()
+    loader = syn.get_synthetic_data_loaders(B * 6, batch_size=B, shuffle=(False, False))["train"]
+    with pytest.raises(ValueError):
+        model.train_epoch(loader)
+    torch.cuda.synchronize()
+    same = (model._params == before) | (torch.isnan(model._params) & torch.isnan(before))
+    assert bool(same.all())
+    assert int(model._status.item()) == 0                     # cleared by the raise

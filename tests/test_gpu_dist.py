@@ -77,3 +77,24 @@ def test_two_rank_step_on_gpu():
             assert abs(v - ref) < (2e-2 if sens else 2e-3) * scale, name     # ReLU-flip noise floor: test_gpu_step.GTOL
         assert 0.0 < moved < 2e-3                          # Adam's first step moves every weight by ~lr
     assert res[0][2] == res[1][2] and res[0][5] == res[1][5]   # identical reduced gradients and updated parameters
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks (a child torch.distributed.run) and
+    rank 0 prints ONE line with n_gpus = 2.  The box has one GPU, so the hidden `--backend gloo` lets both ranks share
+    cuda:0; on a multi-GPU node the same command without that flag runs over RCCL."""
+    import json
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4",
+                          "--warmup", "2", "--per-gpu-batch", "16", "--global-batch", "64", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dist"]["world_size"] == 2 and out["dist"]["ranks_seen"] == 2
+    assert out["dist"]["backend"] == "gloo" and out["dist"]["buckets"] == 3
+    assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["dist"]["exposed_comm_ms_per_step"] >= 0
+    assert out["strong_scaling"]["per_gpu_batch"] == 32 and out["strong_scaling"]["value"] > 0
+    assert out["roofline"]["frac"] > 0

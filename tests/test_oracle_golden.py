@@ -159,3 +159,63 @@ def test_latent_backward_closed_form_matches_autograd():
     L.backward()
     dmu, du, da = O.latent_backward(zs.detach() + gdec, u.detach(), d.detach(), ew, ed)
     assert rel(dmu, mu.grad) < 1e-12 and rel(du, u.grad) < 1e-12 and rel(da, a.grad) < 1e-12
+
+
+def test_oracle_callers_sequence_matches_reference():
+    """The callers' own sequences (SURVEY 8c last bullet; golden ``callers.npz`` made by running the reference's
+    ``VAE(save_dir)`` -> ``train_loop(loaders, epochs=2, test_freq=None)`` with the default ``vis_freq=1`` ->
+    ``save_state`` -> ``torch.load(fn)['z_dim']`` -> ``VAE(z_dim)`` -> ``load_state`` -> ``get_latent``,
+    ``examples/mouse_sylls_mwe.py:132-138`` and ``ava/data/data_container.py:458-475``), restated with the oracle:
+    ``visualize`` runs a TRAIN-mode forward of 5 spectrograms after every epoch (it moves the running statistics),
+    ``get_latent`` runs the freshly loaded model in TRAIN mode."""
+    G = load_golden("callers.npz")
+    z, B, nb = 32, 8, 2
+    P = O.to_params(syn.fixture_parameters(z), requires_grad=True)
+    running = O.fresh_running_stats()
+    opt = {"step": 0, "m": {}, "v": {}}
+    ds = syn.SyntheticSpecDataset(B * nb)
+    np.random.seed(1234)
+    losses = []
+
+    def visualize(salt_w, salt_d):
+        idx = np.random.choice(np.arange(len(ds)), size=5, replace=False)           # vae.py:504-505
+        specs = torch.stack(ds[idx])
+        ew, ed = [torch.from_numpy(a) for a in syn.noise(5, z, salt_w, salt_d)]
+        with torch.no_grad():
+            out = O.forward({k: v.detach() for k, v in P.items()}, specs, ew, ed, running, True)
+        return specs.numpy(), out["x_rec"].numpy().reshape(5, 128, 128)
+
+    for ep in range(2):
+        tot = 0.0
+        for k in range(nb):
+            x = torch.from_numpy(syn.spectrograms(B, start_item=B * k))
+            ew, ed = [torch.from_numpy(a) for a in syn.noise(B, z, 2002 + 10 * k + ep, 3003 + 10 * k + ep)]
+            loss, _, _ = O.train_step(P, x, ew, ed, running, opt)
+            tot += loss
+        losses.append(tot / len(ds))                                                  # vae.py:354
+        visualize(2500 + ep, 3500 + ep)
+    # tolerances behind the first Adam step = 4 x the difference between two runs of the REFERENCE ITSELF (8 vs 1 CPU
+    # threads, stored in the golden as selfnoise.*): Adam's first steps are sign-like and amplify rounding noise
+    assert rel(losses[0], G["train_loss"][0]) < 1e-5
+    assert abs(losses[1] - G["train_loss"][1]) < 4 * float(G["selfnoise.train_loss"])
+    bn_noise = max(float(G["selfnoise.trained.bn%d.running_mean" % i]) for i in range(1, 15))   # one pair of runs: use the largest
+    for i in range(1, 15):
+        k = "trained.bn%d.running_mean" % i
+        assert np.abs(running["bn%d.running_mean" % i].numpy() - G[k]).max() < 4 * bn_noise
+        assert int(running["bn%d.num_batches_tracked" % i]) == int(G["trained.bn%d.num_batches_tracked" % i]) == 6
+    np.random.seed(77)
+    specs, rec = visualize(2600, 3600)
+    assert rel(specs.astype(np.float64).sum(axis=(1, 2)), G["vis_specs_sum"]) < 1e-6        # same 5 items picked
+    assert np.abs(rec.ravel()[G["vis_rec_idx"]] - G["vis_rec"]).max() < 4 * float(G["selfnoise.vis_rec"])
+    # DataContainer._make_latent_means: fresh module (train mode) with the trained weights
+    lat = []
+    with torch.no_grad():
+        Pd = {k: v.detach() for k, v in P.items()}
+        for k in range(nb):
+            mu, _, _ = O.encode(Pd, torch.from_numpy(syn.spectrograms(B, start_item=B * k)), running, True)
+            lat.append(mu.numpy())
+    lat = np.concatenate(lat)
+    assert lat.shape == G["latent"].shape == (16, 32)
+    assert np.abs(lat - G["latent"]).max() < 4 * float(G["selfnoise.latent"])
+    assert int(G["epoch"]) == int(G["loaded_epoch"]) == 2 and list(G["files_after_train_loop"]) == ["reconstruction.pdf"]
+    assert len(G["test_loss_keys"]) == 0

@@ -79,6 +79,18 @@ def fixture_parameters(z_dim):
     return out
 
 
+def latent_conditions(n_per=(70, 53, 91), z=32, salt=9100):
+    """Synthetic latent means of several "conditions" for the MMD^2 estimators (``ava/plotting/mmd_plots.py``):
+    Gaussians with different means / scales from the hash recipe.  Returns ``(latent [N,z] float64, condition [N])``."""
+    lat, cond = [], []
+    for c, n in enumerate(n_per):
+        g = gauss(n * z, salt + c).reshape(n, z)
+        shift = 0.6 * c * np.cos(np.arange(z) * (c + 1.0))
+        lat.append(g * (1.0 + 0.25 * c) + shift)
+        cond += [c] * n
+    return np.concatenate(lat).astype(np.float64), np.array(cond)
+
+
 class SyntheticSpecDataset(Dataset):
     """Synthetic stand-in for ``SyllableDataset`` (``vae_dataset.py:102-145``)."""
 

@@ -214,6 +214,24 @@ int ava_elbo_finalize(const float* latent_sums, int B, const float* sse_partials
 int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, int step, ava_stream_t s);
 
+/* ---- MMD^2 between sets of latent means (downstream consumer of get_latent) ------------ */
+/* _estimate_mmd2 (ava/plotting/mmd_plots.py:255-296, Gretton et al. 2012, unbiased quadratic-time estimator with a
+ * Gaussian kernel of bandwidth sigma).  latent: [N][z] float64 row-major on the device (what VAE.get_latent returns,
+ * vae.py:538); i1 / i2: device int64 index lists of the two conditions (already subsampled if the caller wants max_n).
+ * out4 (device, 4 doubles) = {term_1, term_2, term_3, term_1 + term_2 - term_3}.  n1, n2 >= 2 (the reference divides
+ * by n*(n-1)); z <= 128.  ws: ava_mmd2_workspace_bytes(n1, n2) bytes of device scratch. */
+size_t ava_mmd2_workspace_bytes(int n1, int n2);
+int ava_mmd2(const double* latent, int z, const int64_t* i1, int n1, const int64_t* i2, int n2, double sigma,
+             double* out4, void* ws, size_t ws_bytes, ava_stream_t s);
+/* _estimate_mmd2_linear_time (mmd_plots.py:299-312): m = min(len(i1), len(i2)) / 2 quadruples (i1[2i], i2[2i],
+ * i1[2i+1], i2[2i+1]); out (device double) = sum h / m.  ws: (min(ceil(m/256), 1024) + 8) doubles. */
+int ava_mmd2_linear(const double* latent, int z, const int64_t* i1, const int64_t* i2, int m, double sigma,
+                    double* out, void* ws, size_t ws_bytes, ava_stream_t s);
+/* squared distances of n index pairs, out[p] = |latent[a[p]] - latent[b[p]]|^2: the sampled pairs of
+ * estimate_median_sigma (mmd_plots.py:450-474; the median itself is taken by the caller). */
+int ava_pair_sqdist(const double* latent, int z, const int64_t* a, const int64_t* b, int n, double* out,
+                    ava_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

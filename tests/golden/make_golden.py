@@ -29,8 +29,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+class _Stub(types.ModuleType):
+    """stand-in for a third-party module the reference imports at module level but never uses on these paths"""
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return object
+
+
 for _m in ("h5py", "affinewarp", "affinewarp.crossval"):
     sys.modules[_m] = types.ModuleType(_m)
+for _m in ("umap", "numba", "bokeh", "bokeh.plotting", "bokeh.models", "bokeh.models.glyphs"):   # ava.plotting.* imports
+    sys.modules.setdefault(_m, _Stub(_m))
 sys.modules["affinewarp"].PiecewiseWarping = object
 sys.modules["affinewarp.crossval"].paramsearch = None
 sys.path.insert(0, "/root/reference")
@@ -326,6 +336,27 @@ def callers_with_selfnoise():
     return out
 
 
+def mmd_case():
+    """The reference's own estimator functions (ava/plotting/mmd_plots.py:255-312,450-474) on a synthetic latent set."""
+    import ava.plotting.mmd_plots as mp
+    latent, cond = syn.latent_conditions()
+    out = {}
+    out["sigma_default_seed"] = mp.estimate_median_sigma(latent, n=2000)
+    out["sigma_seed7"] = mp.estimate_median_sigma(latent, n=500, seed=7)
+    sigma = float(out["sigma_default_seed"])
+    idx = [np.argwhere(cond == c).flatten() for c in range(3)]
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        out["quad_%d%d" % (a, b)] = mp._estimate_mmd2(latent, idx[a].copy(), idx[b].copy(), sigma=sigma)
+        out["lin_%d%d" % (a, b)] = mp._estimate_mmd2_linear_time(latent, idx[a].copy(), idx[b].copy(), sigma=sigma)
+    i1, i2 = idx[0].copy(), idx[2].copy()
+    out["quad_02_max40_seed3"] = mp._estimate_mmd2(latent, i1, i2, sigma=sigma, max_n=40, seed=3)
+    out["i1_after_shuffle"] = i1                            # the reference shuffles the caller's arrays in place
+    out["i2_after_shuffle"] = i2
+    out["quad_same"] = mp._estimate_mmd2(latent, idx[1][:26].copy(), idx[1][26:].copy(), sigma=0.5 * sigma)
+    out["quad_sigma_none"] = mp._estimate_mmd2(latent, idx[0].copy(), idx[1].copy())
+    return out
+
+
 def main():
     for B, z, steps in ((8, 32, 3), (8, 64, 1), (64, 32, 1)):
         out, _ = forward_backward_case(B, z, steps)
@@ -337,6 +368,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ddp2.npz"), **ddp_case())
     np.savez_compressed(os.path.join(HERE, "harness.npz"), **harness_case())
     np.savez_compressed(os.path.join(HERE, "callers.npz"), **callers_with_selfnoise())
+    np.savez_compressed(os.path.join(HERE, "mmd.npz"), **mmd_case())
     assert not _QUEUE
     print("golden vectors written to", HERE)
 

@@ -26,8 +26,51 @@ from oracle import vae_oracle as O
 # away from an fp64 evaluation on conv1/bn1 at this fixture, tools/flip_hunt.py).  Everything
 # that does not pass through a mask decision is held to 1e-5 (loss terms, BatchNorm statistics) and the kernels are
 # held to 2e-5 with the masks given as inputs (test_gpu_kernels.py).
+# Measured against an fp64 evaluation (test_gradients_against_fp64_noise_floor, profiles/r02/grad_fp64.json): the HIP
+# path is 4e-7 (B=8) / 1.6e-4 (B=64) / 5e-5 (B=256) away globally, the reference-equivalent fp32 CPU oracle 4e-6 / 8e-5 /
+# 5e-5: against the fp32 goldens the bound is therefore the goldens' own distance from fp64 -- 1e-4 at B=8 outside
+# conv1/bn1 (whose B=8 golden carries one ReLU flip: 9e-3), 1e-2 at B=64 (same values as tests/test_oracle_golden.py).
 FLIP_TOL = 2e-2
-GTOL = {8: 2e-3, 64: 1e-2}
+GTOL = {8: 1e-4, 64: 1e-2}
+
+
+def _oracle_grads(fp, x, ew, ed, dtype):
+    """gradients (float64 numpy, by name) and loss of the CPU oracle evaluated in `dtype`"""
+    P = O.to_params(fp, dtype=dtype, requires_grad=True)
+    out = O.forward(P, torch.as_tensor(x, dtype=dtype), torch.as_tensor(ew, dtype=dtype), torch.as_tensor(ed, dtype=dtype),
+                    None, True)
+    out["loss"].backward()
+    return {k: v.grad.double().numpy().ravel() for k, v in P.items()}, float(out["loss"].detach())
+
+
+def _errors_vs_fp64(g, g64, z):
+    """per-tensor relative L2 error against the fp64 evaluation, and the global one.  conv1 / bn1 gradients are sums
+    of terms that cancel to ~1e-6 of their magnitude, so "relative" there is taken against the conv1.bias gradient norm
+    (same summands) when that is larger -- as in tests/test_oracle_golden.py."""
+    cb = np.linalg.norm(g64["conv1.bias"])
+    per, num, den = {}, 0.0, 0.0
+    for s in param_specs(z):
+        r = g64[s.name]
+        scale = max(np.linalg.norm(r), cb if s.layer in ("conv1", "bn1") else 0.0, 1e-300)
+        d = np.linalg.norm(g[s.name] - r)
+        per[s.name] = d / scale
+        num += d * d
+        den += np.linalg.norm(r) ** 2
+    return per, (num / den) ** 0.5
+
+
+def _assert_within_noise_floor(got, g32, g64, z, report=None):
+    """The tolerance is DERIVED, not asserted: two correct fp32 evaluations differ from an fp64 one by rounding plus
+    ReLU-mask flips (a pre-activation within one rounding of zero), so the HIP path is held to the distance the fp32
+    CPU oracle (= the reference's own arithmetic) keeps from fp64 on the same inputs: per tensor within 4x (flip counts
+    are small integers: 1 vs 3 flips upstream of a tensor is a factor 2 in norm) with a 1e-5 floor, globally within 3x."""
+    eh, gh = _errors_vs_fp64(got, g64, z)
+    eo, go = _errors_vs_fp64(g32, g64, z)
+    if report is not None:
+        report.update({"hip_global": gh, "o32_global": go, "hip_max": max(eh.values()), "o32_max": max(eo.values())})
+    bad = {k: (eh[k], eo[k]) for k in eh if eh[k] > max(4 * eo[k], 1e-5)}
+    assert not bad, bad
+    assert gh <= 3 * go + 1e-6, (gh, go)
 
 
 def fixed_noise(model, B, z, sw=2002, sd=3003):
@@ -151,22 +194,12 @@ def test_forward_backward_matches_oracle_odd_batches(B, z):
     x = torch.from_numpy(syn.spectrograms(B, salt=77))
     loss = model.forward(x)
     loss.backward()
-    P = O.to_params(syn.fixture_parameters(z), requires_grad=True)
-    out = O.forward(P, x, torch.from_numpy(ew), torch.from_numpy(ed), None, True)
-    out["loss"].backward()
-    assert rel(float(loss.item()), float(out["loss"])) < 1e-5
     named = dict(model.named_parameters())
-    bad = []
-    for s in param_specs(z):
-        g = named[s.name].grad.cpu().double().numpy().ravel()
-        w = P[s.name].grad.double().numpy().ravel()
-        e = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-30)
-        # loose on purpose: a single ReLU pre-activation within an ulp of zero flips its mask between two
-        # fp32 evaluations and moves every gradient upstream of it by O(1e-3); the kernels themselves are
-        # pinned at 2e-5 with the masks as inputs in test_gpu_kernels.py, the whole path at B=8 by the goldens
-        if e > 5e-2:
-            bad.append((s.name, e))
-    assert not bad, bad
+    got = {s.name: named[s.name].grad.cpu().double().numpy().ravel() for s in param_specs(z)}
+    g32, l32 = _oracle_grads(syn.fixture_parameters(z), x.numpy(), ew, ed, torch.float32)
+    g64, _ = _oracle_grads(syn.fixture_parameters(z), x.numpy(), ew, ed, torch.float64)
+    assert rel(float(loss.item()), l32) < 1e-5
+    _assert_within_noise_floor(got, g32, g64, z)
 
 
 def test_encode_decode_and_get_latent_golden():
@@ -481,3 +514,56 @@ def test_full_batch_properties(B, z):
         model.optimizer.step()
         losses.append(float(l.item()))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("B", [8, 64, 256])
+def test_gradients_against_fp64_noise_floor(B):
+    """the gradient tolerance is derived from an fp64 evaluation of the oracle instead of being
+    asserted -- err(HIP, fp64) must stay within the distance err(fp32 oracle, fp64) on the same fixture
+    (_assert_within_noise_floor).  Measured (tools/grad_fp64.py, profiles/r02/grad_fp64.log): global relative L2 error
+    HIP / fp32 oracle = 4.2e-7 / 4.1e-6 at B=8, 1.6e-4 / 8.0e-5 at B=64, 5.0e-5 / 5.0e-5 at B=256."""
+    z = 32
+    x = syn.spectrograms(B)
+    ew, ed = syn.noise(B, z)
+    model = build_model(z)
+    model.noise_source = lambda b, zz: (ew, ed)
+    loss = model.forward(torch.from_numpy(x))
+    loss.backward()
+    named = dict(model.named_parameters())
+    got = {s.name: named[s.name].grad.cpu().double().numpy().ravel() for s in param_specs(z)}
+    fp = syn.fixture_parameters(z)
+    g64, l64 = _oracle_grads(fp, x, ew, ed, torch.float64)
+    g32, _ = _oracle_grads(fp, x, ew, ed, torch.float32)
+    assert rel(float(loss.item()), l64) < 1e-6           # fp32 ELBO vs fp64: measured 2e-8
+    rep = {}
+    _assert_within_noise_floor(got, g32, g64, z, rep)
+    print("B=%d  HIP vs fp64: global %.2e max %.2e ; fp32 oracle vs fp64: global %.2e max %.2e"
+          % (B, rep["hip_global"], rep["hip_max"], rep["o32_global"], rep["o32_max"]))
+
+
+def test_flip_free_fixture_meets_appendix_b():
+    """A fixture with NO ReLU pre-activation within 2e-5 (relative to its channel's rms) of zero (tests/flipfree.py:
+    biases nudged by <= 2 % of the rms): no mask can flip, so whole-path gradients must meet SURVEY Appendix B's 1e-4
+    against an fp64 evaluation on EVERY tensor (measured <= 2.2e-6) -- a real 1e-3 bug anywhere in the hand-derived
+    backward (e.g. the BatchNorm-backward coefficient hand-off between layers) cannot hide behind flip noise here."""
+    from flipfree import flipfree_parameters
+    B, z = 8, 32
+    x = syn.spectrograms(B)
+    ew, ed = syn.noise(B, z)
+    fp, min_rel = flipfree_parameters(syn.fixture_parameters(z), x, ew, ed)
+    assert min_rel >= 1.9e-5
+    model = build_model(z, fixture=False)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            prm.copy_(torch.from_numpy(fp[name]))
+    model.noise_source = lambda b, zz: (ew, ed)
+    loss = model.forward(torch.from_numpy(x))
+    loss.backward()
+    named = dict(model.named_parameters())
+    got = {s.name: named[s.name].grad.cpu().double().numpy().ravel() for s in param_specs(z)}
+    g64, l64 = _oracle_grads(fp, x, ew, ed, torch.float64)
+    assert rel(float(loss.item()), l64) < 1e-6
+    eh, gh = _errors_vs_fp64(got, g64, z)
+    bad = {k: v for k, v in eh.items() if v > 1e-4}
+    assert not bad, bad
+    assert gh < 1e-5, gh

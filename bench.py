@@ -55,6 +55,7 @@ def parse(argv=None):
     ap.add_argument("--pool", type=int, default=8, help="distinct device-resident batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two HIP-event passes")
+    ap.add_argument("--no-loader-path", action="store_true", help="skip the PCIe-inclusive loader-path leg (N = 1 only)")
     ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
                     help="bounded: 1 warm-up + 4 timed steps (best thread count) and 1 + 2 (all cores), ~40 s; "
                          "full: BASELINE.md section 3's 3 warm-up + 10 timed steps for both")
@@ -95,6 +96,44 @@ def one_step(model, x):
     model._forward_device(x, need_grad=True, accumulate=True)
     model._backward_device(x)
     model.optimizer.step()
+
+
+def loader_path(model, B, z_dim):
+    """PCIe-inclusive rate of VAE.train_epoch fed from HOST memory (never `value`): items collated into the build's
+    page-locked ring in their stored dtype (PinnedBatchLoader), raw DMA on a copy stream and device-side cast
+    (DeviceFeeder + ava_cast_to_f32), against the reference's hand-over (CPU float32 batches, synchronous
+    data.to(device) per step, vae.py:349)."""
+    import contextlib
+    import numpy as np
+    import torch
+    from ava_amd import synthetic as syn
+    from ava_amd.feed import PinnedBatchLoader
+    nb, epochs = 8, 4
+    base = syn.spectrograms(B * nb, salt=1001)
+    out = {"unit": "spectrograms/s", "batches_per_epoch": nb, "epochs_timed": epochs, "note": "host-resident data, H2D inside the timed region"}
+
+    def run(loader, prefetch):
+        model.prefetch = prefetch
+        with contextlib.redirect_stdout(sys.stderr):
+            model.train_epoch(loader)                          # warm-up epoch (ring allocation, slots)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(epochs):
+                model.train_epoch(loader)                      # ends with a host sync (loss read-back)
+            torch.cuda.synchronize()
+        return round(B * nb * epochs / (time.perf_counter() - t0), 1)
+
+    class Ref:                                                 # the reference's loader contract: CPU float32 batches
+        dataset = range(B * nb)
+        def __init__(self): self.b = [torch.from_numpy(base[i * B:(i + 1) * B]) for i in range(nb)]
+        def __iter__(self): return iter(self.b)
+        def __len__(self): return nb
+    out["reference_handover_sync_to_device"] = run(Ref(), False)
+    out["pinned_ring_float32"] = run(PinnedBatchLoader(base, batch_size=B, shuffle=True), True)
+    out["pinned_ring_float64_device_cast"] = run(PinnedBatchLoader(base.astype(np.float64), batch_size=B, shuffle=True), True)
+    out["pinned_ring_uint8_device_cast"] = run(PinnedBatchLoader((base * 255).astype(np.uint8), batch_size=B, shuffle=True), True)
+    model.prefetch = True
+    return out
 
 
 def cpu_model_string():
@@ -313,6 +352,9 @@ def main():
         out["roofline"] = roofline
     if strong is not None:
         out["strong_scaling"] = strong
+    if world == 1 and not args.no_loader_path:
+        model._ensure(B)
+        out["loader_path"] = loader_path(model, B, args.z_dim)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, args.z_dim, args.cpu_protocol)
     if rank == 0:

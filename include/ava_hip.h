@@ -214,6 +214,14 @@ int ava_elbo_finalize(const float* latent_sums, int B, const float* sse_partials
 int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, int step, ava_stream_t s);
 
+/* ---- input feeding ------------------------------------------------------------------- */
+/* Loader bytes -> fp32 spectrograms on the device: replaces the per-item CPU conversion numpy_to_tensor
+ * (ava/models/utils.py:444-446, applied by SyllableDataset.__getitem__, ava/models/vae_dataset.py:125-145) with a
+ * device-side cast of the raw batch, same rounding as torch's .type(torch.FloatTensor).
+ * src_dtype: 0 float32 (copy), 1 float64, 2 uint8, 3 float16, 4 bfloat16.  src and dst 16-byte aligned device
+ * pointers, n elements. */
+int ava_cast_to_f32(const void* src, int src_dtype, int64_t n, float* dst, ava_stream_t s);
+
 /* ---- MMD^2 between sets of latent means (downstream consumer of get_latent) ------------ */
 /* _estimate_mmd2 (ava/plotting/mmd_plots.py:255-296, Gretton et al. 2012, unbiased quadratic-time estimator with a
  * Gaussian kernel of bandwidth sigma).  latent: [N][z] float64 row-major on the device (what VAE.get_latent returns,

@@ -116,3 +116,57 @@ def test_get_latent_bn_mode():
     assert not torch.equal(model._bn_running, before) and not np.allclose(a, c, rtol=1e-3, atol=1e-4)
     with pytest.raises(ValueError):
         model.get_latent(_Loader(data), bn_mode='nope')
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.uint8, torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n", [1, 5, 16, 1000, 3 * 128 * 128 + 7])
+def test_device_cast_matches_numpy_to_tensor(dtype, n):
+    """ava_cast_to_f32 == the reference's per-item conversion torch.from_numpy(x).type(torch.FloatTensor)
+    (ava/models/utils.py:444-446), bit for bit, including lengths that are not a multiple of the vector width."""
+    from ava_amd.feed import cast_to_f32
+    g = torch.Generator().manual_seed(n)
+    if dtype == torch.uint8:
+        src = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8)
+    else:
+        src = (torch.rand(n, generator=g, dtype=torch.float64) * 2.5 - 0.7).to(dtype)
+        if dtype == torch.float64 and n >= 5:
+            src[:5] = torch.tensor([0.1, 1e-310, 3e38 * 10, -0.0, 16777217.0], dtype=torch.float64)   # rounding, subnormal, overflow
+    want = src.type(torch.FloatTensor)
+    got = cast_to_f32(src.cuda()).cpu()
+    assert got.dtype == torch.float32 and torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.uint8])
+def test_ring_loader_plus_feeder_equals_reference_loader_path(dtype):
+    """PinnedBatchLoader (items collated in their own dtype into the page-locked ring) + DeviceFeeder (raw DMA + device
+    cast) hands the model exactly the tensors the reference's path produces: per-item numpy_to_tensor, default
+    collation, .to(device)."""
+    from ava_amd.feed import PinnedBatchLoader
+    n, bs = 37, 8
+    base = syn.spectrograms(n)
+    items = [(base[i] * 255).astype(np.uint8) if dtype == torch.uint8 else base[i].astype(np.float64) * (1 + 1e-9 * i)
+             for i in range(n)]
+    ref_items = [torch.from_numpy(x).type(torch.FloatTensor) for x in items]          # numpy_to_tensor
+    ref_batches = [torch.stack(ref_items[s:s + bs]) for s in range(0, n, bs)]
+    loader = PinnedBatchLoader(items, batch_size=bs, depth=3)
+    got = [d.clone() for d in DeviceFeeder(loader, "cuda", depth=2)]
+    assert len(got) == len(ref_batches) == 5
+    for g_, w in zip(got, ref_batches):
+        assert g_.dtype == torch.float32 and torch.equal(g_.cpu(), w)
+    first = next(iter(loader))
+    assert first.is_pinned() and first.dtype == dtype
+
+
+def test_train_epoch_over_float64_ring_is_bit_identical_to_reference_loader():
+    from ava_amd.feed import PinnedBatchLoader
+    B, nb, z = 8, 4, 32
+    base = syn.spectrograms(B * nb)
+    items64 = [base[i].astype(np.float64) for i in range(B * nb)]
+    ref_loader = _Loader([torch.from_numpy(base[s:s + B]) for s in range(0, B * nb, B)])
+    res = []
+    for loader in (ref_loader, PinnedBatchLoader(items64, batch_size=B)):
+        model = build_model(z)
+        noise = [syn.noise(B, z, 2002 + k, 3003 + k) for k in range(nb)]
+        model.noise_source = lambda b, zz: noise.pop(0)
+        res.append((model.train_epoch(loader), model._params.detach().cpu().clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])

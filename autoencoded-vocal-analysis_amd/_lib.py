@@ -84,6 +84,7 @@ SIGNATURES = {
     "ava_elbo_finalize": (_i, [_p, _i, _p, _i, _i, _f, _p, _p]),
     "ava_adam_flat": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _i, _p]),
     "ava_cast_to_f32": (_i, [_p, _i, _i64, _p, _p]),
+    "ava_host_gather_rows": (_i, [_p, _p, _p, _i64, _i64, _sz, _i]),
     "ava_mmd2_workspace_bytes": (_sz, [_i, _i]),
     "ava_mmd2": (_i, [_p, _i, _p, _i, _p, _i, _d, _p, _p, _sz, _p]),
     "ava_mmd2_linear": (_i, [_p, _i, _p, _p, _i, _d, _p, _p, _sz, _p]),

@@ -172,8 +172,8 @@ class PinnedBatchLoader:
     CPU -- and the batch is handed out as a view of the slot, which ``DeviceFeeder`` DMAs asynchronously and casts on
     the device.
 
-    ``dataset``: an ``[N,H,W]`` numpy array / memmap (fast path: every batch is ONE gather ``np.take(..., out=slot)``,
-    split over ``workers`` threads -- numpy releases the GIL while copying) or any indexable whose ``dataset[i]`` is an
+    ``dataset``: a C-contiguous ``[N,H,W]`` numpy array / memmap (fast path: every batch is ONE native gather into the
+    slot, ``ava_host_gather_rows`` on ``workers`` host threads with the GIL released) or any indexable whose ``dataset[i]`` is an
     ``[H,W]`` numpy array or tensor (per-item copies).  With ``prefetch=True`` a producer thread fills the ring one or
     two batches ahead of the consumer, so collation overlaps the consumer's kernel launches.
 
@@ -190,7 +190,7 @@ class PinnedBatchLoader:
         self.workers = max(1, int(workers))
         self.prefetch = bool(prefetch)
         self._slots = None
-        self._pool = None
+        self._idx = None
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -207,8 +207,6 @@ class PinnedBatchLoader:
     def __del__(self):
         for s in (self._slots or []):
             _RING_SLOTS.pop(s.host.data_ptr(), None)
-        if self._pool is not None:
-            self._pool.shutdown(wait=False)
 
     def _fill(self, slot, idx):
         """write items ``idx`` of the dataset into the slot (its own dtype); returns the batch view"""
@@ -216,29 +214,18 @@ class PinnedBatchLoader:
             slot.copied.synchronize()                        # the DMA that read this slot `depth` batches ago is done
         host = slot.host
         n = len(idx)
-        if isinstance(self.dataset, np.ndarray):
-            dst = host.numpy() if host.dtype != torch.bfloat16 else None
+        if isinstance(self.dataset, np.ndarray) and self.dataset.flags["C_CONTIGUOUS"]:
+            # one native call per batch (csrc/feed.hip: ava_host_gather_rows, std::threads; the GIL is released)
             data = self.dataset
+            row_bytes = data[0].nbytes
             contiguous = n > 0 and idx[-1] - idx[0] == n - 1 and all(b - a == 1 for a, b in zip(idx, idx[1:]))
-            nbytes = n * data[0].nbytes
-            parts = self.workers if nbytes >= (4 << 20) else 1
-
-            def part(lo, hi):
-                if contiguous:
-                    dst[lo:hi] = data[idx[0] + lo:idx[0] + hi]
-                else:
-                    np.take(data, idx[lo:hi], axis=0, out=dst[lo:hi])
-
-            if parts == 1:
-                part(0, n)
+            if contiguous:
+                ip, first = None, int(idx[0])
             else:
-                if self._pool is None:
-                    from concurrent.futures import ThreadPoolExecutor
-                    self._pool = ThreadPoolExecutor(self.workers)
-                step = (n + parts - 1) // parts
-                futs = [self._pool.submit(part, lo, min(lo + step, n)) for lo in range(0, n, step)]
-                for f in futs:
-                    f.result()
+                self._idx = np.ascontiguousarray(idx, dtype=np.int64)
+                ip, first = self._idx.ctypes.data, 0
+            _lib.check(_lib.load().ava_host_gather_rows(host.data_ptr(), data.ctypes.data, ip, first, n, row_bytes,
+                                                        self.workers), "ava_host_gather_rows")
         else:
             for j, i in enumerate(idx):
                 host[j].copy_(torch.as_tensor(self.dataset[i]))

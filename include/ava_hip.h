@@ -221,6 +221,11 @@ int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, doubl
  * src_dtype: 0 float32 (copy), 1 float64, 2 uint8, 3 float16, 4 bfloat16.  src and dst 16-byte aligned device
  * pointers, n elements. */
 int ava_cast_to_f32(const void* src, int src_dtype, int64_t n, float* dst, ava_stream_t s);
+/* HOST function (no GPU involved): collate a batch into a page-locked ring slot -- dst[i] = src[idx[i]] for n rows of
+ * row_bytes each on `threads` host threads (idx == NULL: the contiguous rows first .. first+n-1).  Replaces the
+ * per-item collation of the reference's DataLoader (ava/models/vae_dataset.py:89-96) for array-backed datasets. */
+int ava_host_gather_rows(void* dst, const void* src, const int64_t* idx, int64_t first, int64_t n, size_t row_bytes,
+                         int threads);
 
 /* ---- MMD^2 between sets of latent means (downstream consumer of get_latent) ------------ */
 /* _estimate_mmd2 (ava/plotting/mmd_plots.py:255-296, Gretton et al. 2012, unbiased quadratic-time estimator with a

@@ -43,6 +43,8 @@ def layer_tensors(name, cin, cout, hi, transposed, B, seed):
 def test_conv_forward(layer, B):
     """BN-apply prologue (zero padding AFTER BatchNorm) + conv/convT + bias + ReLU + statistics epilogue."""
     name, cin, cout, mode, hi, tr = layer
+    if name == "convt7":
+        pytest.skip("convt7 has no ReLU / statistics epilogue in the network (vae.py:269); its forward is the SSE-epilogue test below")
     x, w, b, scale, shift = layer_tensors(name, cin, cout, hi, tr, B, 11)
     xhat = x * scale[None, :, None, None] + shift[None, :, None, None]
     want = torch.relu(ref_conv(xhat, w, b, mode, tr))

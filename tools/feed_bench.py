@@ -56,3 +56,28 @@ loader = Loader([pinned[i % 8] for i in range(NB)])       # what DataLoader(pin_
 for name, pf in (("synchronous, pinned batches", False), ("prefetching feeder, pinned", True)):
     r, ms = epoch(pf)
     print("%-29s: %9.0f spectrograms/s  %.3f ms/step" % (name, r, ms))
+
+# ---- build-owned page-locked ring (PinnedBatchLoader): collation alone, then the whole fed epoch ----
+import numpy as np
+from ava_amd.feed import PinnedBatchLoader
+base = np.concatenate([p.numpy() for p in pool])                     # [8*B,128,128] float32 in host memory
+for dt_name, data in (("float32", base), ("float64", base.astype(np.float64)), ("uint8", (base * 255).astype(np.uint8))):
+    for workers in (1, 4, 8):
+        L = PinnedBatchLoader(data, batch_size=B, shuffle=True, workers=workers, prefetch=False)
+        list(L)
+        t0 = time.perf_counter(); n = 0
+        for _ in range(5):
+            for b in L:
+                n += 1
+        print("collate only  %-8s workers=%d : %.3f ms/batch" % (dt_name, workers, 1e3 * (time.perf_counter() - t0) / n))
+    for workers, pf in ((4, True), (8, True), (4, False)):
+        class Rep:                                                     # NB batches per epoch out of the 8-batch array
+            def __init__(self): self.l = PinnedBatchLoader(data, batch_size=B, shuffle=True, workers=workers, prefetch=pf)
+            dataset = range(B * NB)
+            def __len__(self): return NB
+            def __iter__(self):
+                for _ in range(NB // 8):
+                    yield from self.l
+        loader = Rep()
+        r, ms = epoch(True)
+        print("ring %-8s workers=%d producer-thread=%-5s: %9.0f spectrograms/s  %.3f ms/step" % (dt_name, workers, pf, r, ms))

@@ -96,7 +96,11 @@ extern "C" int ava_host_gather_rows(void* dst, const void* src, const int64_t* i
   if (n == 0) return AVA_OK;
   if (threads < 1) threads = 1;
   if (threads > 16) threads = 16;
-  if ((size_t)n * row_bytes < ((size_t)1 << 20)) threads = 1;
+  {  // at least 2 MiB per thread: starting a thread costs more than copying less (uint8 batches: 8 threads 2.1 ms, 4 threads 0.14 ms)
+    const size_t per = (size_t)2 << 20, total = (size_t)n * row_bytes;
+    const int cap = (int)(total / per);
+    if (threads > cap) threads = cap < 1 ? 1 : cap;
+  }
   if ((int64_t)threads > n) threads = (int)n;
   auto work = [=](int64_t lo, int64_t hi) {
     char* d = static_cast<char*>(dst);

@@ -107,33 +107,42 @@ def batchnorm(x, name, P, running, train, record):
     return y
 
 
-def encode(P, x, running=None, train=True, record=None):
+def _relu(u, name, masks):
+    """ReLU (vae.py:217-231,258-268).  ``masks`` (tests only): a dict name -> 0/1 tensor that REPLACES the sign
+    decision, ``relu(u) -> u * mask``: with the masks of another evaluation imposed, the network is a smooth function
+    of its parameters and two correct evaluations agree to rounding -- no ReLU-flip noise (tests/test_gpu_step.py)."""
+    if masks is not None and name in masks:
+        return u * masks[name].to(u.dtype)
+    return F.relu(u)
+
+
+def encode(P, x, running=None, train=True, record=None, masks=None):
     """vae.py:216-233.  ``x`` is ``[B,128,128]``; returns mu [B,z], u [B,z], d [B,z]."""
     h = x.unsqueeze(1)
     for conv, bn, stride in ENC:
         h = batchnorm(h, bn, P, running, train, record)
-        h = F.relu(F.conv2d(h, P[conv + ".weight"], P[conv + ".bias"], stride=stride, padding=1))
+        h = _relu(F.conv2d(h, P[conv + ".weight"], P[conv + ".bias"], stride=stride, padding=1), conv, masks)
         if record is not None:
             record[conv + ".out"] = h
     h = h.reshape(-1, 8192)                                     # vae.py:224 (NCHW flatten)
-    h = F.relu(F.linear(h, P["fc1.weight"], P["fc1.bias"]))
-    h = F.relu(F.linear(h, P["fc2.weight"], P["fc2.bias"]))
+    h = _relu(F.linear(h, P["fc1.weight"], P["fc1.bias"]), "fc1", masks)
+    h = _relu(F.linear(h, P["fc2.weight"], P["fc2.bias"]), "fc2", masks)
     if record is not None:
         record["fc2.out"] = h
-    mu = F.linear(F.relu(F.linear(h, P["fc31.weight"], P["fc31.bias"])), P["fc41.weight"], P["fc41.bias"])
-    u = F.linear(F.relu(F.linear(h, P["fc32.weight"], P["fc32.bias"])), P["fc42.weight"], P["fc42.bias"])
-    a = F.linear(F.relu(F.linear(h, P["fc33.weight"], P["fc33.bias"])), P["fc43.weight"], P["fc43.bias"])
+    mu = F.linear(_relu(F.linear(h, P["fc31.weight"], P["fc31.bias"]), "fc31", masks), P["fc41.weight"], P["fc41.bias"])
+    u = F.linear(_relu(F.linear(h, P["fc32.weight"], P["fc32.bias"]), "fc32", masks), P["fc42.weight"], P["fc42.bias"])
+    a = F.linear(_relu(F.linear(h, P["fc33.weight"], P["fc33.bias"]), "fc33", masks), P["fc43.weight"], P["fc43.bias"])
     if record is not None:
         record["logd"] = a
     return mu, u, torch.exp(a)                                   # vae.py:232
 
 
-def decode(P, z, running=None, train=True, record=None):
+def decode(P, z, running=None, train=True, record=None, masks=None):
     """vae.py:258-270.  Returns x_rec ``[B,16384]``."""
-    h = F.relu(F.linear(z, P["fc5.weight"], P["fc5.bias"]))
-    h = F.relu(F.linear(h, P["fc6.weight"], P["fc6.bias"]))
-    h = F.relu(F.linear(h, P["fc7.weight"], P["fc7.bias"]))
-    h = F.relu(F.linear(h, P["fc8.weight"], P["fc8.bias"]))
+    h = _relu(F.linear(z, P["fc5.weight"], P["fc5.bias"]), "fc5", masks)
+    h = _relu(F.linear(h, P["fc6.weight"], P["fc6.bias"]), "fc6", masks)
+    h = _relu(F.linear(h, P["fc7.weight"], P["fc7.bias"]), "fc7", masks)
+    h = _relu(F.linear(h, P["fc8.weight"], P["fc8.bias"]), "fc8", masks)
     if record is not None:
         record["fc8.out"] = h
     h = h.reshape(-1, 32, 16, 16)                                # vae.py:262
@@ -142,7 +151,7 @@ def decode(P, z, running=None, train=True, record=None):
         h = F.conv_transpose2d(h, P[convt + ".weight"], P[convt + ".bias"], stride=stride,
                                padding=1, output_padding=stride - 1)
         if i < 6:
-            h = F.relu(h)                                        # no ReLU after convt7 (vae.py:269)
+            h = _relu(h, convt, masks)                           # no ReLU after convt7 (vae.py:269)
         if record is not None:
             record[convt + ".out"] = h
     return h.reshape(-1, X_DIM)
@@ -180,14 +189,14 @@ def loss_terms(x, x_rec, z, u, d, model_precision=10.0):
     return loss, sum_z2, sse, sum_h
 
 
-def forward(P, x, eps_w, eps_d, running=None, train=True, model_precision=10.0, record=None):
+def forward(P, x, eps_w, eps_d, running=None, train=True, model_precision=10.0, record=None, masks=None):
     """vae.py:311-327 with the two normal draws injected.  Raises ValueError
     like the reference's argument validation when ``d`` is not positive."""
-    mu, u, d = encode(P, x, running, train, record)
+    mu, u, d = encode(P, x, running, train, record, masks)
     if not bool((d > 0).all()):
         raise ValueError("cov_diag must be positive")
     z = rsample(mu, u, d, eps_w, eps_d)
-    x_rec = decode(P, z, running, train, record)
+    x_rec = decode(P, z, running, train, record, masks)
     loss, sum_z2, sse, sum_h = loss_terms(x, x_rec, z, u, d, model_precision)
     out = dict(loss=loss, sum_z2=sum_z2, sse=sse, sum_h=sum_h, mu=mu, u=u, d=d, z=z, x_rec=x_rec)
     return out

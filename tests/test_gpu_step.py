@@ -60,23 +60,53 @@ def _errors_vs_fp64(g, g64, z):
 
 
 def _assert_within_noise_floor(got, g32, g64, z, report=None):
-    """The tolerance is DERIVED, not asserted: two correct fp32 evaluations differ from an fp64 one by rounding plus
-    ReLU-mask flips (a pre-activation within one rounding of zero), so the HIP path is held to the distance the fp32
-    CPU oracle (= the reference's own arithmetic) keeps from fp64 on the same inputs:
-      * globally (relative L2 over all 80 tensors) within 3x,
-      * no tensor further away than 3x the oracle's WORST tensor (1e-5 floor).
-    A tensor-by-tensor ratio is not a usable bound: which units flip is a different random draw in each implementation,
-    a tensor's error is set by the one to three flips upstream of it, and the observed per-tensor ratios HIP / oracle
-    range from 0.4 to 6 (profiles/r02/grad_fp64.log) with the global ratio between 0.1 and 1.9.  The bound that has no
-    such noise is the flip-free fixture's (test_flip_free_fixture_meets_appendix_b: 1e-4 on every tensor)."""
+    """Distance from an fp64 evaluation, HIP next to the fp32 CPU oracle (= the reference's own arithmetic) on the same
+    inputs.  Both carry rounding plus ReLU-mask flips (a pre-activation within one rounding of zero); which units flip
+    is a different random draw in each implementation and a tensor's error is set by the one to three flips upstream of
+    it, so tensor-by-tensor ratios scatter (0.4 ... 6 observed, profiles/r02/grad_fp64.log) and only the GLOBAL relative
+    L2 error is asserted here (HIP within 4x the oracle's; observed 0.1x ... 1.9x).  The per-tensor bound without flip
+    noise is _masked_fp64_grad_errors below (1e-4 on every tensor at every batch size)."""
     eh, gh = _errors_vs_fp64(got, g64, z)
     eo, go = _errors_vs_fp64(g32, g64, z)
     if report is not None:
         report.update({"hip_global": gh, "o32_global": go, "hip_max": max(eh.values()), "o32_max": max(eo.values())})
-    cap = max(3 * max(eo.values()), 1e-5)
-    bad = {k: (eh[k], eo[k]) for k in eh if eh[k] > cap}
-    assert not bad, (bad, cap)
-    assert gh <= 3 * go + 1e-6, (gh, go)
+    assert gh <= 4 * go + 1e-6, (gh, go)
+
+
+def _hip_masks(model, B):
+    """0/1 ReLU masks of the forward that just ran on the device, by oracle layer name (NCHW for conv layers)."""
+    m = {}
+    ch = {"conv1": (8, 128), "conv2": (8, 64), "conv3": (16, 64), "conv4": (16, 32), "conv5": (24, 32), "conv6": (24, 16),
+          "convt1": (24, 16), "convt2": (24, 32), "convt3": (16, 32), "convt4": (16, 64), "convt5": (8, 64), "convt6": (8, 128)}
+    for i in range(1, 7):
+        c, hw = ch["conv%d" % i]
+        m["conv%d" % i] = (model._workspace_tensor("y%d" % i, (B, hw, hw, c)) > 0).permute(0, 3, 1, 2).cpu()
+        c, hw = ch["convt%d" % i]
+        m["convt%d" % i] = (model._workspace_tensor("d%d" % i, (B, hw, hw, c)) > 0).permute(0, 3, 1, 2).cpu()
+    m["conv7"] = (model._workspace_tensor("y7", (B, 16, 16, 32)) > 0).permute(0, 3, 1, 2).cpu()
+    for name, n in (("h1", 1024), ("h2", 256), ("h5", 64), ("h6", 256), ("h7", 1024), ("f8", 8192)):
+        key = {"h1": "fc1", "h2": "fc2", "h5": "fc5", "h6": "fc6", "h7": "fc7", "f8": "fc8"}[name]
+        m[key] = (model._workspace_tensor(name, (B, n)) > 0).cpu()
+    h3 = (model._workspace_tensor("h3", (B, 192)) > 0).cpu()
+    m["fc31"], m["fc32"], m["fc33"] = h3[:, :64], h3[:, 64:128], h3[:, 128:]
+    return m
+
+
+def _masked_fp64_grad_errors(model, fp, x, ew, ed, z):
+    """Whole-path gradient error WITHOUT ReLU-flip noise: the fp64 oracle is evaluated with the HIP forward's own
+    ReLU masks imposed (relu(u) -> u * mask), which makes it the exact derivative of the function the device
+    evaluated; what remains is fp32 rounding.  Returns (per-tensor relative L2 errors, relative loss difference)."""
+    B = x.shape[0]
+    named = dict(model.named_parameters())
+    got = {s.name: named[s.name].grad.detach().cpu().double().numpy().ravel() for s in param_specs(z)}
+    masks = _hip_masks(model, B)
+    P = O.to_params(fp, dtype=torch.float64, requires_grad=True)
+    out = O.forward(P, torch.as_tensor(x, dtype=torch.float64), torch.as_tensor(ew, dtype=torch.float64),
+                    torch.as_tensor(ed, dtype=torch.float64), None, True, masks=masks)
+    out["loss"].backward()
+    g64 = {k: v.grad.numpy().ravel() for k, v in P.items()}
+    per, _ = _errors_vs_fp64(got, g64, z)
+    return per, float(out["loss"].detach())
 
 
 def fixed_noise(model, B, z, sw=2002, sd=3003):
@@ -200,12 +230,10 @@ def test_forward_backward_matches_oracle_odd_batches(B, z):
     x = torch.from_numpy(syn.spectrograms(B, salt=77))
     loss = model.forward(x)
     loss.backward()
-    named = dict(model.named_parameters())
-    got = {s.name: named[s.name].grad.cpu().double().numpy().ravel() for s in param_specs(z)}
-    g32, l32 = _oracle_grads(syn.fixture_parameters(z), x.numpy(), ew, ed, torch.float32)
-    g64, _ = _oracle_grads(syn.fixture_parameters(z), x.numpy(), ew, ed, torch.float64)
-    assert rel(float(loss.item()), l32) < 1e-5
-    _assert_within_noise_floor(got, g32, g64, z)
+    per, l64 = _masked_fp64_grad_errors(model, syn.fixture_parameters(z), x.numpy(), ew, ed, z)
+    assert rel(float(loss.item()), l64) < 1e-6
+    bad = {k: v for k, v in per.items() if v > 1e-4}       # SURVEY Appendix B's bound, on every tensor
+    assert not bad, bad
 
 
 def test_encode_decode_and_get_latent_golden():
@@ -543,8 +571,12 @@ def test_gradients_against_fp64_noise_floor(B):
     assert rel(float(loss.item()), l64) < 1e-6           # fp32 ELBO vs fp64: measured 2e-8
     rep = {}
     _assert_within_noise_floor(got, g32, g64, z, rep)
-    print("B=%d  HIP vs fp64: global %.2e max %.2e ; fp32 oracle vs fp64: global %.2e max %.2e"
-          % (B, rep["hip_global"], rep["hip_max"], rep["o32_global"], rep["o32_max"]))
+    per, _ = _masked_fp64_grad_errors(model, fp, x, ew, ed, z)
+    print("B=%d  HIP vs fp64: global %.2e max %.2e ; fp32 oracle vs fp64: global %.2e max %.2e ; HIP vs fp64 with the "
+          "device's ReLU masks imposed: max %.2e" % (B, rep["hip_global"], rep["hip_max"], rep["o32_global"],
+                                                      rep["o32_max"], max(per.values())))
+    bad = {k: v for k, v in per.items() if v > 1e-4}
+    assert not bad, bad
 
 
 def test_flip_free_fixture_meets_appendix_b():

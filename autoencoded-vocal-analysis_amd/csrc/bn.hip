@@ -164,40 +164,41 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
   }
 }
 
-// ---- NCHW-flatten <-> NHWC hand-offs (per sample: 32 channels x 256 pixels) --------------------------
-// One workgroup handles a quarter sample: 32 channels x 64 pixels (2048 floats) through a padded LDS tile,
-// so 4*B workgroups keep every CU busy (one workgroup per sample left 3/4 of the waves idle: 20 us -> ~5 us).
-// NCHW element (c, p) of sample b: b*8192 + c*256 + p ; NHWC element: b*8192 + p*32 + c.
+// ---- NCHW-flatten <-> NHWC hand-offs (per sample: 32 channels x P pixels, P = (H/8)*(W/8) = 256 at 128x128) ------
+// One workgroup handles a slab of 32 channels x 64 pixels (2048 floats) through a padded LDS tile, so (P/64)*B
+// workgroups keep every CU busy (one workgroup per sample left 3/4 of the waves idle: 20 us -> ~5 us).
+// NCHW element (c, p) of sample b: b*32*P + c*P + p ; NHWC element: b*32*P + p*32 + c.  `nq` = P / 64 slabs per sample.
 #define QPIX 64
-__device__ __forceinline__ void load_nchw_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q) {
+__device__ __forceinline__ void load_nchw_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q, int P) {
   for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
     const int c = i / QPIX, p = i % QPIX;                    // 64 consecutive pixels of one channel: coalesced
-    tile[c][p] = src[(size_t)b * 8192 + c * 256 + q * QPIX + p];
+    tile[c][p] = src[(size_t)b * 32 * P + (size_t)c * P + q * QPIX + p];
   }
 }
-__device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q) {
+__device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q, int P) {
   for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
-    const int p = i >> 5, c = i & 31;                        // the quarter is one contiguous 8 KB range
-    tile[c][p] = src[(size_t)b * 8192 + (q * QPIX) * 32 + i];
+    const int p = i >> 5, c = i & 31;                        // the slab is one contiguous 8 KB range
+    tile[c][p] = src[(size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i];
   }
 }
 
 // f8 [B][32*256] (c*256+p) -> out [B][256][32], plus per-channel {sum, sum^2} partials for bn8
 __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                 float* __restrict__ partials, int B) {
+                                                                 float* __restrict__ partials, int B, int P) {
   __shared__ float tile[32][QPIX + 1];
   __shared__ float red[8][64];
   const int t = threadIdx.x;
   float s1 = 0.f, s2 = 0.f;                 // thread -> channel t&31, 8 threads per channel
-  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
-    const int b = w >> 2, q = w & 3;
+  const int nq = P / QPIX;
+  for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
+    const int b = w / nq, q = w - b * nq;
     __syncthreads();
-    load_nchw_quarter(tile, in, b, q);
+    load_nchw_quarter(tile, in, b, q, P);
     __syncthreads();
     for (int i = t; i < 32 * QPIX; i += 256) {
       const int p = i >> 5, c = i & 31;     // c == t & 31 for every i of this thread
       const float v = tile[c][p];
-      out[(size_t)b * 8192 + (q * QPIX) * 32 + i] = v;
+      out[(size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i] = v;
       s1 += v;
       s2 = fmaf(v, v, s2);
     }
@@ -214,16 +215,17 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
 }
 
 // y7 [B][256][32] -> out [B][32*256]
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int P) {
   __shared__ float tile[32][QPIX + 1];
-  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
-    const int b = w >> 2, q = w & 3;
+  const int nq = P / QPIX;
+  for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
+    const int b = w / nq, q = w - b * nq;
     __syncthreads();
-    load_nhwc_quarter(tile, in, b, q);
+    load_nhwc_quarter(tile, in, b, q, P);
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
       const int c = i / QPIX, p = i % QPIX;
-      out[(size_t)b * 8192 + c * 256 + q * QPIX + p] = tile[c][p];
+      out[(size_t)b * 32 * P + (size_t)c * P + q * QPIX + p] = tile[c][p];
     }
   }
 }
@@ -231,15 +233,16 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 // dU7 (NHWC) = (y7 > 0) ? dy7 (NCHW-flatten, from fc1's backward) : 0       (ReLU of vae.py:223)
 __global__ __launch_bounds__(256) void relu_mask_to_nhwc_kernel(const float* __restrict__ dy_nchw,
                                                                 const float* __restrict__ y_nhwc,
-                                                                float* __restrict__ du_nhwc, int B) {
+                                                                float* __restrict__ du_nhwc, int B, int P) {
   __shared__ float tile[32][QPIX + 1];
-  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
-    const int b = w >> 2, q = w & 3;
+  const int nq = P / QPIX;
+  for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
+    const int b = w / nq, q = w - b * nq;
     __syncthreads();
-    load_nchw_quarter(tile, dy_nchw, b, q);
+    load_nchw_quarter(tile, dy_nchw, b, q, P);
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
-      const size_t o = (size_t)b * 8192 + (q * QPIX) * 32 + i;
+      const size_t o = (size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i;
       du_nhwc[o] = y_nhwc[o] > 0.f ? tile[i & 31][i >> 5] : 0.f;
     }
   }
@@ -251,16 +254,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* 
                                                                    const float* __restrict__ A,
                                                                    const float* __restrict__ Bc,
                                                                    const float* __restrict__ Cc,
-                                                                   float* __restrict__ out_nchw, int B) {
+                                                                   float* __restrict__ out_nchw, int B, int P) {
   __shared__ float tile[32][QPIX + 1];
-  for (int w = blockIdx.x; w < 4 * B; w += gridDim.x) {
-    const int b = w >> 2, q = w & 3;
+  const int nq = P / QPIX;
+  for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
+    const int b = w / nq, q = w - b * nq;
     __syncthreads();
-    load_nhwc_quarter(tile, g_nhwc, b, q);
+    load_nhwc_quarter(tile, g_nhwc, b, q, P);
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
       const int c = i / QPIX, p = i % QPIX;
-      const size_t o = (size_t)b * 8192 + c * 256 + q * QPIX + p;
+      const size_t o = (size_t)b * 32 * P + (size_t)c * P + q * QPIX + p;
       const float f = f8_nchw[o];
       out_nchw[o] = f > 0.f ? fmaf(A[c], tile[c][p], fmaf(Bc[c], f, Cc[c])) : 0.f;
     }
@@ -338,26 +342,29 @@ int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, 
 }
 
 // internal (model.hip)
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts, hipStream_t st) {
-  const int grid = 4 * B < 1024 ? 4 * B : 1024;
-  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B);
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int* nparts, hipStream_t st) {
+  if (P < QPIX || P % QPIX != 0) return AVA_EINVAL;
+  const int nw = (P / QPIX) * B;
+  const int grid = nw < 1024 ? nw : 1024;
+  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B, P);
   AVA_CHECK_LAUNCH();
   *nparts = grid;
   return AVA_OK;
 }
-int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st) {
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(4 * B < 2048 ? 4 * B : 2048), dim3(256), 0, st, in, out, B);
+static inline int layout_grid(int B, int P) { const int nw = (P / QPIX) * B; return nw < 2048 ? nw : 2048; }
+int ava_nhwc_to_nchw(const float* in, float* out, int B, int P, hipStream_t st) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(layout_grid(B, P)), dim3(256), 0, st, in, out, B, P);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
-int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st) {
-  hipLaunchKernelGGL(relu_mask_to_nhwc_kernel, dim3(4 * B < 2048 ? 4 * B : 2048), dim3(256), 0, st, dy_nchw, y_nhwc, du, B);
+int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, int P, hipStream_t st) {
+  hipLaunchKernelGGL(relu_mask_to_nhwc_kernel, dim3(layout_grid(B, P)), dim3(256), 0, st, dy_nchw, y_nhwc, du, B, P);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
-                             float* out, int B, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel, dim3(4 * B < 2048 ? 4 * B : 2048), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B);
+                             float* out, int B, int P, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -181,9 +181,9 @@ struct TileStager {
 // larger than that runs in rounds whose last one is partly empty, and pays the per-workgroup set-up (weights into
 // registers, pipeline fill) once per round.
 template <typename K>
-static inline int ava_resident_grid(K kernel, size_t lds_bytes) {
+static inline int ava_resident_grid(K kernel, size_t lds_bytes, int block_threads = 256) {
   int per_cu = 0, dev = 0, cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, lds_bytes) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), block_threads, lds_bytes) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
   hipDeviceProp_t prop;

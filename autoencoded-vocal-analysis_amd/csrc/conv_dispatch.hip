@@ -99,6 +99,7 @@ int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, i
 int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);
 int ava_conv3x3_thin(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st);
 int ava_conv3x3_wgrad_thin(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);
+int ava_conv3x3_wgrad_thin_rows(const WgradArgs& a, int grid, int Cin, int Cout, int mode);
 
 #ifdef AVA_LAB
 // lab build: AVA_CONV_IMPL=valu forces the version-0 VALU kernels (lab/conv_valu.hip) everywhere
@@ -236,6 +237,8 @@ extern "C" int ava_conv_wgrad_rows(int B, int Hi, int Wi, int Cin, int Cout, int
   if (use_mfma()) {
     const int rows = ava_conv3x3_wgrad_mfma(a, grid, Cin, Cout, mode, dy_pro, nullptr);   // partials == NULL: query
     if (rows > 0) return rows;
+    const int trows = ava_conv3x3_wgrad_thin_rows(a, grid, Cin, Cout, mode);
+    if (trows > 0) return trows;
   }
   return grid;
 }

@@ -289,7 +289,6 @@ int ava_conv3x3_mfma_ws(const ConvArgs& a, int grid, int Cin, int Cout, int mode
 int ava_conv3x3_up88_direct(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st);
 
 int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
-  const int tw = a.Wo >= 32 ? 32 : 16;
   if (epi == EPI_FWD && !a.relu) return AVA_EINVAL;        // the fused epilogue always applies the ReLU
   {                                                        // convt6 forward: direct packed-FMA kernel (conv_thin.hip)
     const int rc = ava_conv3x3_up88_direct(a, grid, Cin, Cout, mode, pro, epi, st);
@@ -305,12 +304,12 @@ int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, i
 #ifndef AVA_LAB
   // Everything else runs the wave-specialised kernel above.  The plain 256-thread kernel is compiled for the one
   // launch that needs its second output: conv7's forward, which also writes the NCHW-flatten copy fc1 reads.
-  if (a.out2 != nullptr && Cin == 24 && Cout == 32 && mode == MODE_S1 && tw == 16 && pro == PRO_BN && epi == EPI_FWD)
+  if (a.out2 != nullptr && Cin == 24 && Cout == 32 && mode == MODE_S1 && a.Wo % 16 == 0 && a.Ho % 8 == 0 && pro == PRO_BN && epi == EPI_FWD)
     return launch_mfma<24, 32, MODE_S1, PRO_BN, EPI_FWD, 16, 8>(a, grid, st);
   return AVA_EINVAL;
 #else
 #define AVA_MFMA_CASE(ci, co, md, tww, thh) \
-  if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_mfma_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
+  if (Cin == ci && Cout == co && mode == md && a.Wo % tww == 0 && a.Ho % thh == 0) return launch_mfma_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
   AVA_MFMA_CASE(8, 8, MODE_DOWN, 32, 4)
   AVA_MFMA_CASE(8, 16, MODE_S1, 32, 8)
   AVA_MFMA_CASE(16, 16, MODE_DOWN, 32, 4)
@@ -629,9 +628,8 @@ static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
 }
 
 int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
-  const int tw = a.Wo >= 32 ? 32 : 16;
 #define AVA_WGM_CASE(ci, co, md, tww, thh)                                                     \
-  if (Cin == ci && Cout == co && mode == md && tw == tww) {                                    \
+  if (Cin == ci && Cout == co && mode == md && a.Wo % tww == 0 && a.Ho % thh == 0) {                                    \
     if (dy_pro == PRO_BWD) return launch_wgrad_mfma<ci, co, md, PRO_BWD, tww, thh>(a, grid, st); \
     if (dy_pro == PRO_ID) return launch_wgrad_mfma<ci, co, md, PRO_ID, tww, thh>(a, grid, st);   \
     return AVA_EINVAL;                                                                         \

@@ -19,17 +19,29 @@
 #include "conv_common.h"
 #include "conv_fused.h"
 
-#define THIN_W 128          // image width handled (Wo == Wi == 128)
-#define THIN_TH 8           // tile: 8 rows x 128 columns
+// Every kernel is a template on the image width W (128 or 256: BASELINE configs 1-4 resp. 5): a workgroup of 2*W
+// threads owns a tile of 8 full-width rows -- lane pair (2x, 2x+1) shares pixel column x -- so no kernel needs a
+// horizontal halo from another workgroup.
+#define THIN_TH 8           // tile: 8 rows x W columns
 #define THIN_IR (THIN_TH + 2)
-#define THIN_IC (THIN_W + 2)
+#define THIN_IC (W + 2)
+#define THIN_NT (2 * W)      // threads per workgroup
+#define THIN_NW (2 * W / 64) // waves per workgroup
+
+// sum over the workgroup's waves in a fixed order: f(w) = wave w's value.  ((0+1)+(2+3)) for 4 waves (W = 128, the
+// order the 128-wide kernels have always used), the same tree one level deeper for 8 (W = 256).
+template <int NW, typename F>
+__device__ __forceinline__ float thin_sum_waves(F f) {
+  if constexpr (NW == 4) return (f(0) + f(1)) + (f(2) + f(3));
+  else return ((f(0) + f(1)) + (f(2) + f(3))) + ((f(4) + f(5)) + (f(6) + f(7)));
+}
 #ifndef THIN_PLANES
 #define THIN_PLANES 0     // 1: two [10][130][4] channel planes instead of [10][130][8]
 #endif
 
-// sum N per-thread values over the workgroup: wave shuffles, then one LDS exchange (lds: [4][N] floats);
+// sum N per-thread values over the workgroup: wave shuffles, then one LDS exchange (lds: [NW][N] floats);
 // result i is written to out[i] by thread i.  Fixed order -> deterministic.
-template <int N>
+template <int N, int NW>
 __device__ __forceinline__ void thin_block_reduce(const float (&v)[N], float* lds, float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
@@ -40,7 +52,7 @@ __device__ __forceinline__ void thin_block_reduce(const float (&v)[N], float* ld
   }
   __syncthreads();
   if (threadIdx.x < N && out != nullptr)
-    out[threadIdx.x] = (lds[threadIdx.x] + lds[N + threadIdx.x]) + (lds[2 * N + threadIdx.x] + lds[3 * N + threadIdx.x]);
+    out[threadIdx.x] = thin_sum_waves<NW>([&](int w) { return lds[w * N + threadIdx.x]; });
 }
 
 // partial rows of workgroups that were not launched (grid < part_rows) are zero-filled, N floats per row
@@ -84,16 +96,16 @@ struct ThinPairWeights {
 };
 
 // stage a 1-channel [10 x 130] window (origin row gy0, column -1) with the prologue applied
-template <int PRO>
+template <int W, int PRO>
 __device__ __forceinline__ void thin_stage1(float* __restrict__ lds, const float* __restrict__ in,
                                             const float* __restrict__ in2, float ca, float cb, float cc, int b,
                                             int H, int gy0) {
-  for (int v = threadIdx.x; v < THIN_IR * THIN_IC; v += 256) {
+  for (int v = threadIdx.x; v < THIN_IR * THIN_IC; v += THIN_NT) {
     const int r = v / THIN_IC, c = v - r * THIN_IC;
     const int gy = gy0 + r, gx = c - 1;
     float o = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < THIN_W) {
-      const size_t off = ((size_t)b * H + gy) * THIN_W + gx;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const size_t off = ((size_t)b * H + gy) * W + gx;
       o = prologue<PRO>(in[off], PRO == PRO_BWD ? in2[off] : 0.f, ca, cb, cc);
     }
     lds[v] = o;
@@ -108,10 +120,10 @@ __device__ __forceinline__ void thin_stage1(float* __restrict__ lds, const float
 // lines); with one thread per pixel and two 16-byte stores per pixel each instruction wrote every other 16-byte
 // slot and the layer ran at 3.8 TB/s of a possible ~5.  Weights depend on h, so they live in vector registers
 // (36 per thread) as channel pairs for v_pk_fma_f32.
-template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
+template <int W, int PRO, int EPI>
+__global__ __launch_bounds__(2 * W) void thin_1to8_kernel(const ConvArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];
-  __shared__ float red[4][2][8];
+  __shared__ float red[THIN_NW][2][8];
   const int t = threadIdx.x, h = t & 1, x = t >> 1, lane = t & 63, wave = t >> 6;
   const float ca = a.pa ? a.pa[0] : 0.f, cb = a.pb ? a.pb[0] : 0.f, cc = a.pc ? a.pc[0] : 0.f;
   avaf2 w2[9][2];                                    // [tap][channel pair of this half]
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
-    thin_stage1<PRO>(tile, a.in, a.in2, ca, cb, cc, b, a.Hi, oy0 - 1);
+    thin_stage1<W, PRO>(tile, a.in, a.in2, ca, cb, cc, b, a.Hi, oy0 - 1);
     __syncthreads();
     avaf2 acc[THIN_TH][2];
 #pragma unroll
@@ -162,10 +174,10 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
           for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_elementwise_fma(iv, w2[ky * 3 + kx][q], acc[p][q]);
         }
     }
-    const size_t o0 = (((size_t)b * a.Ho + oy0) * THIN_W + x) * 8 + 4 * h;
+    const size_t o0 = (((size_t)b * a.Ho + oy0) * W + x) * 8 + 4 * h;
 #pragma unroll
     for (int p = 0; p < THIN_TH; ++p) {
-      const size_t off = o0 + (size_t)p * THIN_W * 8;
+      const size_t off = o0 + (size_t)p * W * 8;
       avaf2 v0 = acc[p][0], v1 = acc[p][1];
       if (EPI == EPI_FWD) {
         v0 += bias2[0]; v1 += bias2[1];
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
   __syncthreads();
   if (t < 16 && a.partials != nullptr) {
     const int which = t >> 3, co = t & 7, hh = co >> 2, i = which * 4 + (co & 3);
-    a.partials[(size_t)blockIdx.x * 16 + t] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);
+    a.partials[(size_t)blockIdx.x * 16 + t] = thin_sum_waves<THIN_NW>([&](int w) { return red[w][hh][i]; });
   }
   thin_zero_rows<16>(a.partials, a.part_rows);
 }
@@ -206,23 +218,23 @@ __global__ __launch_bounds__(256) void thin_1to8_kernel(const ConvArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // 8 -> 1 channels: convt7 forward (PRO_BN, EPI_SSE), conv1 backward-data (PRO_BWD / PRO_ID, EPI_BWD)
 // ---------------------------------------------------------------------------------------------------------
-template <int PRO, int EPI>
-__global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
+template <int W, int PRO, int EPI>
+__global__ __launch_bounds__(2 * W, W == 128 ? 2 : 1) void thin_8to1_kernel(const ConvArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* tile = smem;                                   // [10][130][8]
   float* coef = smem + THIN_IR * THIN_IC * 8;           // [3][32]
   float* red = coef + 96;                               // [4][2]
-  const int t = threadIdx.x, ty0 = (t >> 7) * 4, x = t & 127;
+  const int t = threadIdx.x, ty0 = (t / W) * 4, x = t % W;
   if (t < 96) {
     const int which = t >> 5, c = t & 31;
     const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
     coef[t] = (src != nullptr && c < 8) ? src[c] : 0.f;
   }
-  const ThinWeights W(a.G);                             // [9][8][1]
+  const ThinWeights Wt(a.G);                            // [9][8][1]
   const float bias0 = EPI == EPI_SSE ? ava_uniform(a.bias[0]) : 0.f;
   const float em0 = EPI == EPI_BWD ? ava_uniform(a.epi_mean[0]) : 0.f, ei0 = EPI == EPI_BWD ? ava_uniform(a.epi_invstd[0]) : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  TileStager<8, PRO, THIN_IR, THIN_IC, (THIN_PLANES != 0)> stg;
+  TileStager<8, PRO, THIN_IR, THIN_IC, (THIN_PLANES != 0), THIN_NT> stg;
   stg.init();
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
@@ -248,17 +260,17 @@ __global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
           const int p = j - ky;                         // output row fed by input row j through tap ky
           if (p >= 0 && p < 4) {
 #pragma unroll
-            for (int ci = 0; ci < 8; ++ci) acc[p] = fmaf(in[ci], W.w[(ky * 3 + kx) * 8 + ci], acc[p]);
+            for (int ci = 0; ci < 8; ++ci) acc[p] = fmaf(in[ci], Wt.w[(ky * 3 + kx) * 8 + ci], acc[p]);
           }
         }
       }
     }
-    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * W + x;
     if (EPI == EPI_SSE) {
       const float bias = bias0;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const size_t opix = opix0 + (size_t)p * THIN_W;
+        const size_t opix = opix0 + (size_t)p * W;
         const float v = acc[p] + bias;
         if (a.epi_x != nullptr) {
           const float r = v - a.epi_x[opix];
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
       const float m = em0, is = ei0;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const size_t opix = opix0 + (size_t)p * THIN_W;
+        const size_t opix = opix0 + (size_t)p * W;
         s1 += acc[p];
         s2 = fmaf(acc[p], (a.epi_x[opix] - m) * is, s2);
         if (a.out != nullptr) a.out[opix] = acc[p];
@@ -279,11 +291,12 @@ __global__ __launch_bounds__(256, 2) void thin_8to1_kernel(const ConvArgs a) {
     }
   }
   const float sv[2] = {s1, s2};
-  thin_block_reduce<2>(sv, red, a.partials != nullptr ? a.partials + (size_t)blockIdx.x * 2 : nullptr);
+  thin_block_reduce<2, THIN_NW>(sv, red, a.partials != nullptr ? a.partials + (size_t)blockIdx.x * 2 : nullptr);
   thin_zero_rows<2>(a.partials, a.part_rows);
 }
 
 #ifdef AVA_LAB
+#define W 128   /* lab-only kernels: 128-wide images only */
 // Wave-specialised variant (512 threads, one workgroup per CU): waves 0-3 stage tile k+1 (global -> registers ->
 // prologue -> LDS buffer (k+1)&1) while waves 4-7 multiply tile k out of buffer k&1; one barrier per tile.  At the
 // barrier of tile k the staging waves have filled buffer k&1 and the compute waves have left buffer (k-1)&1, which
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
   } else {
     // ---- compute waves ----
     const int tc = t - NS, ty0 = (tc >> 7) * 4, x = tc & 127;
-    const ThinPairWeights W(a.G);                       // [9][8][1] as channel pairs
+    const ThinPairWeights Wp(a.G);                       // [9][8][1] as channel pairs
     const float bias0 = EPI == EPI_SSE ? ava_uniform(a.bias[0]) : 0.f;
     const float em0 = EPI == EPI_BWD ? ava_uniform(a.epi_mean[0]) : 0.f, ei0 = EPI == EPI_BWD ? ava_uniform(a.epi_invstd[0]) : 0.f;
     __syncthreads();
@@ -333,11 +346,11 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
     for (TileWalk walk(a.ntiles); walk.valid(); walk.advance(), k ^= 1) {
       const int tl = walk.cur;
       const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
-      const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+      const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * W + x;
       float ex[4] = {0.f, 0.f, 0.f, 0.f};               // epilogue operand, requested before the wait for the tile
       if (a.epi_x != nullptr) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ex[p] = a.epi_x[opix0 + (size_t)p * THIN_W];
+        for (int p = 0; p < 4; ++p) ex[p] = a.epi_x[opix0 + (size_t)p * W];
       }
       __syncthreads();                                  // buffer k full
       const float* tile = smem + k * TILE_F;
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
             const int p = j - ky;                       // output row fed by input row j through tap ky
             if (p >= 0 && p < 4) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) acc2[p] = __builtin_elementwise_fma(in2[q], W.w[ky * 3 + kx][q], acc2[p]);
+              for (int q = 0; q < 4; ++q) acc2[p] = __builtin_elementwise_fma(in2[q], Wp.w[ky * 3 + kx][q], acc2[p]);
             }
           }
         }
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
       if (EPI == EPI_SSE) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          const size_t opix = opix0 + (size_t)p * THIN_W;
+          const size_t opix = opix0 + (size_t)p * W;
           const float v = acc[p] + bias0;
           if (a.epi_x != nullptr) {
             const float r = v - ex[p];
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
       } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          const size_t opix = opix0 + (size_t)p * THIN_W;
+          const size_t opix = opix0 + (size_t)p * W;
           s1 += acc[p];
           s2 = fmaf(acc[p], (ex[p] - em0) * ei0, s2);
           if (a.out != nullptr) a.out[opix] = acc[p];
@@ -401,6 +414,7 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
   thin_zero_rows<2>(a.partials, a.part_rows);
 }
 
+#undef W
 #endif  // AVA_LAB
 
 // "Direct" form of the 8 -> 1 forward (convt7 + SSE epilogue): the 8-channel input needs no LDS window.  Thread (x, h)
@@ -411,11 +425,11 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
 //   y[r][x] = bias + sum_h sum_kx u_h[r][kx] at column x + kx - 1.
 // No staging role, three workgroups per CU resident, ten independent 16-byte loads per thread in flight; the
 // LDS-staged wave-specialised form kept one 41.6 KB window per workgroup in flight.
-template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void thin_8to1_direct_kernel(const ConvArgs a) {
+template <int W, int PRO, int EPI>
+__global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs a) {
   static_assert(PRO == PRO_BN && EPI == EPI_SSE, "only convt7's forward uses this form");
   __shared__ float U[2][3][THIN_TH][THIN_IC];           // [half][kx][row][column + 1]; columns 0 and 129 stay zero
-  __shared__ float red[4][2];
+  __shared__ float red[THIN_NW][2];
   const int t = threadIdx.x, h = t & 1, x = t >> 1, lane = t & 63, wave = t >> 6;
   if (t < 2 * 3 * THIN_TH) {                            // zero borders, once
     float* row = &U[0][0][0][0] + t * THIN_IC;
@@ -435,28 +449,28 @@ __global__ __launch_bounds__(256) void thin_8to1_direct_kernel(const ConvArgs a)
       w2[tap][q] = v;
     }
   const float bias0 = a.bias[0];
-  const int xo = t & 127, r0 = (t >> 7) * 4;            // phase 2: output pixels (r0 + p, xo)
+  const int xo = t % W, r0 = (t / W) * 4;            // phase 2: output pixels (r0 + p, xo)
   float s1 = 0.f;
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     // ---- phase 1: own pixel column, 10 rows ----
-    const float* __restrict__ xin = a.in + ((size_t)b * a.Hi * THIN_W + x) * 8 + 4 * h;
+    const float* __restrict__ xin = a.in + ((size_t)b * a.Hi * W + x) * 8 + 4 * h;
     avaf2 xn[THIN_IR][2];
 #pragma unroll
     for (int j = 0; j < THIN_IR; ++j) {
       const int gy = oy0 - 1 + j;
       const bool ok = gy >= 0 && gy < a.Hi;             // wave-uniform
-      const avaf4 v = *reinterpret_cast<const avaf4*>(xin + (size_t)min(max(gy, 0), a.Hi - 1) * THIN_W * 8);
+      const avaf4 v = *reinterpret_cast<const avaf4*>(xin + (size_t)min(max(gy, 0), a.Hi - 1) * W * 8);
       xn[j][0] = ok ? avaf2{fmaf(ca[0], v[0], cb[0]), fmaf(ca[1], v[1], cb[1])} : avaf2{0.f, 0.f};
       xn[j][1] = ok ? avaf2{fmaf(ca[2], v[2], cb[2]), fmaf(ca[3], v[3], cb[3])} : avaf2{0.f, 0.f};
     }
-    const size_t opix0 = ((size_t)b * a.Ho + oy0 + r0) * THIN_W + xo;
+    const size_t opix0 = ((size_t)b * a.Ho + oy0 + r0) * W + xo;
     float ex[4] = {0.f, 0.f, 0.f, 0.f};                 // epilogue operand of this thread's output pixels
     if (a.epi_x != nullptr) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) ex[p] = a.epi_x[opix0 + (size_t)p * THIN_W];
+      for (int p = 0; p < 4; ++p) ex[p] = a.epi_x[opix0 + (size_t)p * W];
     }
     float u[THIN_TH][3];
 #pragma unroll
@@ -482,7 +496,7 @@ __global__ __launch_bounds__(256) void thin_8to1_direct_kernel(const ConvArgs a)
       float v = bias0;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) v += U[0][kx][r0 + p][xo + kx] + U[1][kx][r0 + p][xo + kx];
-      const size_t opix = opix0 + (size_t)p * THIN_W;
+      const size_t opix = opix0 + (size_t)p * W;
       if (a.epi_x != nullptr) {
         const float r = v - ex[p];
         a.out2[opix] = a.prec * r;
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(256) void thin_8to1_direct_kernel(const ConvArgs a)
   if (lane == 0) { red[wave][0] = r1; red[wave][1] = 0.f; }
   __syncthreads();
   if (t < 2 && a.partials != nullptr)
-    a.partials[(size_t)blockIdx.x * 2 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    a.partials[(size_t)blockIdx.x * 2 + t] = thin_sum_waves<THIN_NW>([&](int w) { return red[w][t]; });
   thin_zero_rows<2>(a.partials, a.part_rows);
 }
 
@@ -503,11 +517,11 @@ __global__ __launch_bounds__(256) void thin_8to1_direct_kernel(const ConvArgs a)
 // weight gradients.  dy-side prologue is applied on the fly to each thread's own 4 pixels (no LDS needed for dy)
 // ---------------------------------------------------------------------------------------------------------
 // conv1: CIN = 1, COUT = 8.  dG[9][8], db[8]
-template <int DYPRO>
-__global__ __launch_bounds__(256) void thin_wgrad_1to8_kernel(const WgradArgs a) {
+template <int W, int DYPRO>
+__global__ __launch_bounds__(2 * W) void thin_wgrad_1to8_kernel(const WgradArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];
-  __shared__ float red[4 * 80];
-  const int t = threadIdx.x, ty0 = (t >> 7) * 4, x = t & 127;
+  __shared__ float red[THIN_NW * 80];
+  const int t = threadIdx.x, ty0 = (t / W) * 4, x = t % W;
   const float xa = a.xa[0], xb = a.xb[0];
   float acc[9][8], bacc[8];
 #pragma unroll
@@ -528,13 +542,13 @@ __global__ __launch_bounds__(256) void thin_wgrad_1to8_kernel(const WgradArgs a)
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
-    thin_stage1<PRO_BN>(tile, a.x, nullptr, xa, xb, 0.f, b, a.Hi, oy0 - 1);
+    thin_stage1<W, PRO_BN>(tile, a.x, nullptr, xa, xb, 0.f, b, a.Hi, oy0 - 1);
     __syncthreads();
-    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * W + x;
     float du[4][8];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const size_t opix = opix0 + (size_t)p * THIN_W - p;
+      const size_t opix = opix0 + (size_t)p * W - p;
       const float4 g0 = *reinterpret_cast<const float4*>(a.dy + (opix + p) * 8);
       const float4 g1 = *reinterpret_cast<const float4*>(a.dy + (opix + p) * 8 + 4);
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -570,16 +584,16 @@ __global__ __launch_bounds__(256) void thin_wgrad_1to8_kernel(const WgradArgs a)
     for (int co = 0; co < 8; ++co) sv[k * 8 + co] = acc[k][co];
 #pragma unroll
   for (int co = 0; co < 8; ++co) sv[72 + co] = bacc[co];
-  thin_block_reduce<80>(sv, red, a.partials + (size_t)blockIdx.x * 80);
+  thin_block_reduce<80, THIN_NW>(sv, red, a.partials + (size_t)blockIdx.x * 80);
 }
 
 // convt7: CIN = 8, COUT = 1.  dG[9][8][1], db[1]
-template <int DYPRO>
-__global__ __launch_bounds__(256, 2) void thin_wgrad_8to1_kernel(const WgradArgs a) {
+template <int W, int DYPRO>
+__global__ __launch_bounds__(2 * W, W == 128 ? 2 : 1) void thin_wgrad_8to1_kernel(const WgradArgs a) {
   extern __shared__ __align__(16) float smem[];
   float* tile = smem;
   float* coef = smem + THIN_IR * THIN_IC * 8;
-  const int t = threadIdx.x, ty0 = (t >> 7) * 4, x = t & 127;
+  const int t = threadIdx.x, ty0 = (t / W) * 4, x = t % W;
   if (t < 96) {
     const int which = t >> 5, c = t & 31;
     const float* src = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_8to1_kernel(const WgradArgs
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) acc[k][ci] = 0.f;
-  TileStager<8, PRO_BN, THIN_IR, THIN_IC, (THIN_PLANES != 0)> stg;
+  TileStager<8, PRO_BN, THIN_IR, THIN_IC, (THIN_PLANES != 0), THIN_NT> stg;
   stg.init();
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
@@ -602,11 +616,11 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_8to1_kernel(const WgradArgs
     stg.load(a.x, nullptr, b, a.Hi, a.Wi, oy0 - 1, -1);
     stg.store(tile, coef);
     __syncthreads();
-    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * W + x;
     float du[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const size_t opix = opix0 + (size_t)p * THIN_W;
+      const size_t opix = opix0 + (size_t)p * W;
       du[p] = prologue<DYPRO>(a.dy[opix], DYPRO == PRO_BWD ? a.dy2[opix] : 0.f, da, db, dc);
     }
     bacc += (du[0] + du[1]) + (du[2] + du[3]);
@@ -634,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_8to1_kernel(const WgradArgs
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) sv[k * 8 + ci] = acc[k][ci];
   sv[72] = bacc;
-  thin_block_reduce<73>(sv, smem, a.partials + (size_t)blockIdx.x * 73);     // tiles are dead: reuse their LDS
+  thin_block_reduce<73, THIN_NW>(sv, smem, a.partials + (size_t)blockIdx.x * 73);     // tiles are dead: reuse their LDS
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -652,10 +666,10 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_8to1_kernel(const WgradArgs
 // ---------------------------------------------------------------------------------------------------------
 // Thread mapping: lane pair (2x, 2x+1) shares pixel column x; thread (x, h) owns channels 4h..4h+3 of the 8 rows
 // of the tile, so every g / y load is one 16-byte slot per lane, contiguous across the wave.
-template <int DYPRO>
-__global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArgs a) {
+template <int W, int DYPRO>
+__global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];             // xhat0 window
-  __shared__ float red[4][2][44];                       // per wave, per channel half: dG' [9][4], T [4], border sums
+  __shared__ float red[THIN_NW][2][44];                       // per wave, per channel half: dG' [9][4], T [4], border sums
   __shared__ float tot[2][44];
   __shared__ float ccol[2][2][4], kcor[2][2][2][4];     // [left/right][h], [left/right][top/bottom][h]
   const int t = threadIdx.x, h = t & 1, x = t >> 1, wave = t >> 6, lane = t & 63;
@@ -675,20 +689,20 @@ __global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArg
     db[c] = DYPRO == PRO_BWD ? a.db[4 * h + c] : 0.f;
     dc[c] = DYPRO == PRO_BWD ? a.dc[4 * h + c] : 0.f;
   }
-  const bool edge_col = x == 0 || x == THIN_W - 1;
+  const bool edge_col = x == 0 || x == W - 1;
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles, a.sweep == 0); walk.valid(); walk.advance()) {
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
-    thin_stage1<PRO_BN>(tile, a.x, nullptr, ha, hb, 0.f, b, a.Hi, oy0 - 1);
-    const size_t o0 = (((size_t)b * a.Ho + oy0) * THIN_W + x) * 8 + 4 * h;
+    thin_stage1<W, PRO_BN>(tile, a.x, nullptr, ha, hb, 0.f, b, a.Hi, oy0 - 1);
+    const size_t o0 = (((size_t)b * a.Ho + oy0) * W + x) * 8 + 4 * h;
     float du[THIN_TH][4];
 #pragma unroll
     for (int p = 0; p < THIN_TH; ++p) {
-      const float4 g = *reinterpret_cast<const float4*>(a.dy + o0 + (size_t)p * THIN_W * 8);
+      const float4 g = *reinterpret_cast<const float4*>(a.dy + o0 + (size_t)p * W * 8);
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (DYPRO == PRO_BWD) y = *reinterpret_cast<const float4*>(a.dy2 + o0 + (size_t)p * THIN_W * 8);
+      if (DYPRO == PRO_BWD) y = *reinterpret_cast<const float4*>(a.dy2 + o0 + (size_t)p * W * 8);
       du[p][0] = prologue<DYPRO>(g.x, y.x, da[0], db[0], dc[0]);
       du[p][1] = prologue<DYPRO>(g.y, y.y, da[1], db[1], dc[1]);
       du[p][2] = prologue<DYPRO>(g.z, y.z, da[2], db[2], dc[2]);
@@ -752,7 +766,7 @@ __global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArg
     for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
     rb[c] = v;
   }
-  __shared__ float rbot[4][2][4];
+  __shared__ float rbot[THIN_NW][2][4];
   if (lane < 2) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) rbot[wave][lane][c] = rb[c];
@@ -765,7 +779,7 @@ __global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArg
   __syncthreads();
   if (t < 88) {
     const int hh = t / 44, i = t - 44 * hh;
-    tot[hh][i] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);
+    tot[hh][i] = thin_sum_waves<THIN_NW>([&](int w) { return red[w][hh][i]; });
   }
   __syncthreads();
   float* scratch = &red[0][0][0];                        // [2][72] products for the two BatchNorm sums (red is dead)
@@ -773,7 +787,7 @@ __global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArg
     const int tap = t >> 3, co = t & 7, hh = co >> 2, c = co & 3, ky = tap / 3, kx = tap - 3 * ky;
     float S = tot[hh][36 + c];
     if (ky == 0) S -= tot[hh][40 + c];
-    if (ky == 2) S -= (rbot[0][hh][c] + rbot[1][hh][c]) + (rbot[2][hh][c] + rbot[3][hh][c]);
+    if (ky == 2) S -= thin_sum_waves<THIN_NW>([&](int w) { return rbot[w][hh][c]; });
     if (kx == 0) S -= ccol[0][hh][c];
     if (kx == 2) S -= ccol[1][hh][c];
     if (ky == 0 && kx == 0) S += kcor[0][0][hh][c];
@@ -806,7 +820,8 @@ __global__ __launch_bounds__(256) void thin_bwd_fused_1to8_kernel(const FusedArg
 // (S[tap] = sum of dU over the pixels whose tap lands inside the image), so the data-gradient kernel
 // (thin_1to8_kernel<.., EPI_NONE>) only has to write dx and never reads x; this kernel reads x once.
 // ---------------------------------------------------------------------------------------------------------
-#ifdef AVA_LAB   // the LDS-staged form of this kernel (AVA_THIN_STATS_DIRECT=0); the library runs the direct form below
+#ifdef AVA_LAB
+#define W 128   /* lab-only kernels: 128-wide images only */   // the LDS-staged form of this kernel (AVA_THIN_STATS_DIRECT=0); the library runs the direct form below
 template <int DYPRO>
 __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const FusedArgs a) {
   extern __shared__ __align__(16) float smem[];
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc2[k][q] = avaf2{0.f, 0.f};
-  const bool edge_col = x == 0 || x == THIN_W - 1;
+  const bool edge_col = x == 0 || x == W - 1;
   TileStager<8, PRO_BN, THIN_IR, THIN_IC, (THIN_PLANES != 0)> stg;
   stg.init();
   const int tiles_y = a.Ho / THIN_TH;
@@ -839,11 +854,11 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
     stg.load(a.x, nullptr, b, a.Hi, a.Wi, oy0 - 1, -1);
     stg.store(tile, coef);
     __syncthreads();
-    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * THIN_W + x;
+    const size_t opix0 = ((size_t)b * a.Ho + oy0 + ty0) * W + x;
     float du[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const size_t opix = opix0 + (size_t)p * THIN_W;
+      const size_t opix = opix0 + (size_t)p * W;
       du[p] = prologue<DYPRO>(a.dy[opix], DYPRO == PRO_BWD ? a.dy2[opix] : 0.f, da, db, dc);
     }
     const float strip = (du[0] + du[1]) + (du[2] + du[3]);
@@ -885,7 +900,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
     for (int ci = 0; ci < 8; ++ci) sv[k * 8 + ci] = acc2[k][ci >> 1][ci & 1];
   sv[72] = T;
   float* tot = smem + 4 * 73;                           // [73] behind the reduction scratch (tiles are dead)
-  thin_block_reduce<73>(sv, smem, tot);
+  thin_block_reduce<73, 4>(sv, smem, tot);
   const float rw = wave_sum(R);
   if (lane == 0) aux[wave] = rw;                        // waves 0,1: image row 0;  waves 2,3: image row H-1
   if (edge_col) {
@@ -925,6 +940,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
   }
 }
 
+#undef W
 #endif  // AVA_LAB
 
 // "Direct" form of thin_wgrad_stats_8to1_kernel: the same correlation, indexed by the INPUT pixel q instead of the
@@ -934,11 +950,11 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
 // the tile, exactly like thin_bwd_fused_1to8_kernel), and only the 1-channel dU window goes through LDS (5 KB).
 // The LDS-staged form keeps one 41.6 KB window per workgroup in flight and runs at 2.7 TB/s; this one has no staging
 // role at all, more resident workgroups and eight independent 16-byte loads per thread in flight.
-template <int DYPRO>
-__global__ __launch_bounds__(256) void thin_wgrad_stats_8to1_direct_kernel(const FusedArgs a) {
+template <int W, int DYPRO>
+__global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(const FusedArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];             // dU window (prologue applied, zero outside the image)
-  __shared__ float red[4][2][36];                       // per wave, per channel half: dG' [9][4]
-  __shared__ float sc[4][9];                            // per wave: T, Rt, Rb, Cl, Cr, Ktl, Ktr, Kbl, Kbr
+  __shared__ float red[THIN_NW][2][36];                       // per wave, per channel half: dG' [9][4]
+  __shared__ float sc[THIN_NW][9];                            // per wave: T, Rt, Rb, Cl, Cr, Ktl, Ktr, Kbl, Kbr
   __shared__ float tot[2][36];
   __shared__ float stot[9];
   __shared__ float scratch[2][72];
@@ -962,12 +978,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_stats_8to1_direct_kernel(const
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
-    thin_stage1<DYPRO>(tile, a.dy, a.dy2, da, db, dc, b, a.Ho, oy0 - 1);
-    const size_t o0 = (((size_t)b * a.Hi + oy0) * THIN_W + x) * 8 + 4 * h;
+    thin_stage1<W, DYPRO>(tile, a.dy, a.dy2, da, db, dc, b, a.Ho, oy0 - 1);
+    const size_t o0 = (((size_t)b * a.Hi + oy0) * W + x) * 8 + 4 * h;
     avaf2 xh[THIN_TH][2];
 #pragma unroll
     for (int r = 0; r < THIN_TH; ++r) {
-      const avaf4 v = *reinterpret_cast<const avaf4*>(a.x + o0 + (size_t)r * THIN_W * 8);
+      const avaf4 v = *reinterpret_cast<const avaf4*>(a.x + o0 + (size_t)r * W * 8);
       xh[r][0] = avaf2{fmaf(ha[0], v[0], hb[0]), fmaf(ha[1], v[1], hb[1])};
       xh[r][1] = avaf2{fmaf(ha[2], v[2], hb[2]), fmaf(ha[3], v[3], hb[3])};
     }
@@ -983,7 +999,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_stats_8to1_direct_kernel(const
       Rt += own * top;
       Rb += own * bot;
       if (x == 0) { Cl += own * col; Ktl += own * top; Kbl += own * bot; }
-      if (x == THIN_W - 1) { Cr += own * col; Ktr += own * top; Kbr += own * bot; }
+      if (x == W - 1) { Cr += own * col; Ktr += own * top; Kbr += own * bot; }
     }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -1024,10 +1040,10 @@ __global__ __launch_bounds__(256) void thin_wgrad_stats_8to1_direct_kernel(const
   __syncthreads();
   if (t < 72) {
     const int hh = t / 36, i = t - 36 * hh;
-    tot[hh][i] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);
+    tot[hh][i] = thin_sum_waves<THIN_NW>([&](int w) { return red[w][hh][i]; });
   } else if (t < 81) {
     const int i = t - 72;
-    stot[i] = (sc[0][i] + sc[1][i]) + (sc[2][i] + sc[3][i]);
+    stot[i] = thin_sum_waves<THIN_NW>([&](int w) { return sc[w][i]; });
   }
   __syncthreads();
   if (t < 72) {
@@ -1183,41 +1199,67 @@ int ava_conv3x3_up88_direct(const ConvArgs& a0, int grid, int Cin, int Cout, int
   return AVA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// host side.  The kernels exist for W = 128 (BASELINE configs 1-4) and W = 256 (config 5); a workgroup has 2*W threads.
+// ---------------------------------------------------------------------------------------------------------
+static inline bool thin_width_ok(int W) { return W == 128 || W == 256; }
+
+// resident workgroups of a 2*W-thread kernel (occupancy x CUs)
+template <typename K>
+static int thin_resident(K kernel, int W, size_t lds) { return ava_resident_grid(kernel, lds, 2 * W); }
+
+#ifdef AVA_LAB
 static int thin_ws_mode() {
   static const int ws = [] { const char* e = ava_env("AVA_THIN_WS"); return e ? atoi(e) : 1; }();
   return ws;
 }
+#endif
 
-int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
-  if (mode != MODE_S1 || Wi != THIN_W || Hi % THIN_TH != 0) return 0;
-  if (!((Cin == 1 && Cout == 8) || (Cin == 8 && Cout == 1))) return 0;
-  const int nt = B * (Hi / THIN_TH);
-  static const int env1 = [] { const char* e = ava_env("AVA_THIN_GRID1"); return (e && atoi(e) >= 8) ? atoi(e) : 768; }();
-  static const int env8 = [] {
+template <int W>
+static int thin_fused_grid_w(int nt, int Cin) {
+  if (Cin == 1) {
+    // conv1's backward: 768 workgroups of 256 threads (3 per CU) measured best at W = 128; one resident wave at W = 256
+    static const int cap1 = [] {
+      const char* e = ava_env("AVA_THIN_GRID1");
+      if (e && atoi(e) >= 8) return atoi(e);
+      if (W == 128) return 768;
+      return thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD>, W, 0);
+    }();
+    return nt < cap1 ? nt : cap1;
+  }
+  static const int cap8 = [] {
     const char* e = ava_env("AVA_THIN_GRID8");
     if (e && atoi(e) >= 8) return atoi(e);
+#ifdef AVA_LAB
     const char* d = ava_env("AVA_THIN_STATS_DIRECT");
     if (d && atoi(d) == 0) return 512;                    // LDS-staged form: two workgroups per CU
+#endif
     // direct form: one resident wave (3 per CU at 138 VGPRs; in-step A/B 512 / 768 / 1024 -> 48.0 / 42.4 / 55.7 us)
-    return ava_resident_grid(&thin_wgrad_stats_8to1_direct_kernel<PRO_ID>, 0);
+    return thin_resident(&thin_wgrad_stats_8to1_direct_kernel<W, PRO_ID>, W, 0);
   }();
-  const int cap = Cin == 1 ? env1 : env8;                // one resident wave of workgroups (3 per CU each)
-  return nt < cap ? nt : cap;
+  return nt < cap8 ? nt : cap8;
 }
 
-static const size_t kThinStatsLds = (size_t)(THIN_IR * THIN_IC * 8 + 96 + 16) * sizeof(float);
+int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
+  if (mode != MODE_S1 || !thin_width_ok(Wi) || Hi % THIN_TH != 0) return 0;
+  if (!((Cin == 1 && Cout == 8) || (Cin == 8 && Cout == 1))) return 0;
+  const int nt = B * (Hi / THIN_TH);
+  return Wi == 128 ? thin_fused_grid_w<128>(nt, Cin) : thin_fused_grid_w<256>(nt, Cin);
+}
 
-int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro, hipStream_t st) {
+template <int W>
+static int thin_bwd_fused_launch_w(const FusedArgs& a0, int grid, int Cin, int dy_pro, hipStream_t st) {
   FusedArgs a = a0;
   a.ntiles = a.B * (a.Ho / THIN_TH);
   // the 8-channel tensors of these kernels have no halo: sweeping the tile list together beats per-XCD chunks
   // (in-step A/B: conv1 backward 68.0 -> 59.0 us, convt7 weight gradient 44.5 -> 42.9 us)
   { static const int sw = [] { const char* e = ava_env("AVA_THIN_SWEEP"); return e ? atoi(e) : 1; }(); a.sweep = sw; }
   if (dy_pro != PRO_BWD && dy_pro != PRO_ID) return AVA_EINVAL;
+  const dim3 block(2 * W);
   if (Cin == 1) {
     if (a.dx != nullptr) return AVA_EINVAL;              // this layer's data gradient is never formed
-    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
+    else hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);
     AVA_CHECK_LAUNCH();
     return AVA_OK;
   }
@@ -1231,93 +1273,110 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro
   static const int dcap = [] {
     const char* e = ava_env("AVA_THIN_DGRID");
     if (e && atoi(e) >= 8) return atoi(e);
-    return ava_resident_grid(&thin_1to8_kernel<PRO_ID, EPI_NONE>, 0);
+    return thin_resident(&thin_1to8_kernel<W, PRO_ID, EPI_NONE>, W, 0);
   }();
   const int dgrid = a.ntiles < dcap ? a.ntiles : dcap;
-  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BWD, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
-  else hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_NONE>), dim3(dgrid), dim3(256), 0, st, c);
+  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BWD, EPI_NONE>), dim3(dgrid), block, 0, st, c);
+  else hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_ID, EPI_NONE>), dim3(dgrid), block, 0, st, c);
   AVA_CHECK_LAUNCH();
 #ifdef AVA_LAB
-  static const int direct = [] { const char* e = ava_env("AVA_THIN_STATS_DIRECT"); return e ? atoi(e) : 1; }();
-  if (direct == 0) {
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_BWD>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_ID>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThinStatsLds) != hipSuccess)
-        return AVA_ELAUNCH;
-      attr = true;
+  if constexpr (W == 128) {
+    static const int direct = [] { const char* e = ava_env("AVA_THIN_STATS_DIRECT"); return e ? atoi(e) : 1; }();
+    if (direct == 0) {
+      const size_t lds = (size_t)(THIN_IR * 130 * 8 + 96 + 16) * sizeof(float);
+      static bool attr = false;
+      if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_BWD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_stats_8to1_kernel<PRO_ID>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return AVA_ELAUNCH;
+        attr = true;
+      }
+      if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_BWD>), dim3(grid), dim3(256), lds, st, a);
+      else hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_ID>), dim3(grid), dim3(256), lds, st, a);
+      AVA_CHECK_LAUNCH();
+      return AVA_OK;
     }
-    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_BWD>), dim3(grid), dim3(256), kThinStatsLds, st, a);
-    else hipLaunchKernelGGL((thin_wgrad_stats_8to1_kernel<PRO_ID>), dim3(grid), dim3(256), kThinStatsLds, st, a);
-    AVA_CHECK_LAUNCH();
-    return AVA_OK;
   }
 #endif
-  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
+  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
+  else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// dispatch (called from conv.hip before the generic kernels); AVA_EINVAL = shape not handled here
-// ---------------------------------------------------------------------------------------------------------
-static const size_t kThin8Lds = (size_t)(THIN_IR * THIN_IC * 8 + 96 + 8) * sizeof(float);
-static const size_t kThin8WsLds = (size_t)(2 * THIN_IR * THIN_IC * 8 + 96 + 8) * sizeof(float);
-
-template <typename K>
-static int thin_set_lds(K kernel) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)kThin8Lds) == hipSuccess ? AVA_OK : AVA_ELAUNCH;
+int ava_thin_bwd_fused_launch(const FusedArgs& a0, int grid, int Cin, int dy_pro, hipStream_t st) {
+  if (a0.Wi == 128) return thin_bwd_fused_launch_w<128>(a0, grid, Cin, dy_pro, st);
+  if (a0.Wi == 256) return thin_bwd_fused_launch_w<256>(a0, grid, Cin, dy_pro, st);
+  return AVA_EINVAL;
 }
 
-int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
-  if (mode != MODE_S1 || a0.Wo != THIN_W || a0.Ho % THIN_TH != 0) return AVA_EINVAL;
+// ---------------------------------------------------------------------------------------------------------
+// dispatch (called from conv_dispatch.hip); AVA_EINVAL = shape not handled here
+// ---------------------------------------------------------------------------------------------------------
+template <typename K>
+static int thin_set_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes) == hipSuccess ? AVA_OK : AVA_ELAUNCH;
+}
+
+template <int W>
+static int conv3x3_thin_w(const ConvArgs& a0, int grid, int Cin, int Cout, int pro, int epi, hipStream_t st) {
+  const size_t kThin8Lds = (size_t)(THIN_IR * THIN_IC * 8 + 96 + 8) * sizeof(float);
+  const dim3 block(2 * W);
   ConvArgs a = a0;
   a.ntiles = a.B * (a.Ho / THIN_TH);                     // workgroups beyond ntiles still write their (zero) partial row
   a.part_rows = grid;                                    // rows the caller sized; one resident wave is launched
   if (Cin == 8 && grid > 512) grid = 512;                // 8 -> 1: two workgroups per CU are resident (measured -3.5 us)
   { const char* e = ava_env("AVA_THIN_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (Cin == 1 && Cout == 8) {
-    if (pro == PRO_BN && epi == EPI_FWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BN, EPI_FWD>), dim3(grid), dim3(256), 0, st, a);
-    else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_ID, EPI_BWD>), dim3(grid), dim3(256), 0, st, a);
-    else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<PRO_BWD, EPI_BWD>), dim3(grid), dim3(256), 0, st, a);
+    if (W == 256) {                                      // 512-thread workgroups: at most one resident wave
+      static const int res = thin_resident(&thin_1to8_kernel<W, PRO_BN, EPI_FWD>, W, 0);
+      if (grid > res) grid = res;
+    }
+    if (pro == PRO_BN && epi == EPI_FWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BN, EPI_FWD>), dim3(grid), block, 0, st, a);
+    else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_ID, EPI_BWD>), dim3(grid), block, 0, st, a);
+    else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BWD, EPI_BWD>), dim3(grid), block, 0, st, a);
     else return AVA_EINVAL;
   } else if (Cin == 8 && Cout == 1) {
     static bool attr = false;
     if (!attr) {
-      if (thin_set_lds(&thin_8to1_kernel<PRO_BN, EPI_SSE>) != AVA_OK || thin_set_lds(&thin_8to1_kernel<PRO_BWD, EPI_BWD>) != AVA_OK ||
-          thin_set_lds(&thin_8to1_kernel<PRO_ID, EPI_BWD>) != AVA_OK)
+      if (thin_set_lds(&thin_8to1_kernel<W, PRO_BWD, EPI_BWD>, kThin8Lds) != AVA_OK ||
+          thin_set_lds(&thin_8to1_kernel<W, PRO_ID, EPI_BWD>, kThin8Lds) != AVA_OK)
         return AVA_ELAUNCH;
       attr = true;
     }
-    const int ws = thin_ws_mode();
-    (void)ws;
+    if (W == 256 && grid > 256) grid = 256;              // 82 KB of LDS per workgroup: one per CU
+#ifdef AVA_LAB
     static const int direct = [] { const char* e = ava_env("AVA_THIN_FWD_DIRECT"); return e ? atoi(e) : 1; }();
-    if (direct != 0 && pro == PRO_BN && epi == EPI_SSE) {
-      static const int resident = ava_resident_grid(&thin_8to1_direct_kernel<PRO_BN, EPI_SSE>, 0);
+    if (W == 128 && direct == 0 && pro == PRO_BN && epi == EPI_SSE) {
+      if constexpr (W == 128) {
+        if (thin_ws_mode() != 0) {
+          const size_t ws_lds = (size_t)(2 * THIN_IR * 130 * 8 + 96 + 8) * sizeof(float);
+          static bool attr_ws = false;
+          if (!attr_ws) {
+            if (thin_set_lds(&thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>, ws_lds) != AVA_OK) return AVA_ELAUNCH;
+            attr_ws = true;
+          }
+          const int g = grid < 256 ? grid : 256;          // one workgroup per CU
+          hipLaunchKernelGGL((thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>), dim3(g), dim3(512), ws_lds, st, a);
+          AVA_CHECK_LAUNCH();
+          return AVA_OK;
+        }
+      }
+    }
+#endif
+    if (pro == PRO_BN && epi == EPI_SSE) {
+      static const int resident = thin_resident(&thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE>, W, 0);
       int g = a.part_rows < resident ? a.part_rows : resident;   // at most one resident wave; rows beyond the grid are zero-filled
       if (g > 512) g = 512;                               // in-step A/B: 512 / 768 / 1023 workgroups -> 34.1 / 34.7 / 37.0 us
       { const char* e = ava_env("AVA_THIN_FWD_GRID"); if (e && atoi(e) >= 8 && atoi(e) < a.part_rows) g = atoi(e); }
       if (g > a.ntiles) g = a.ntiles;
-      hipLaunchKernelGGL((thin_8to1_direct_kernel<PRO_BN, EPI_SSE>), dim3(g), dim3(256), 0, st, a);
-#ifdef AVA_LAB
-    } else if (ws != 0 && pro == PRO_BN && epi == EPI_SSE) {
-      static bool attr_ws = false;
-      if (!attr_ws) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kThin8WsLds) != hipSuccess)
-          return AVA_ELAUNCH;
-        attr_ws = true;
-      }
-      const int g = grid < 256 ? grid : 256;              // one workgroup per CU
-      hipLaunchKernelGGL((thin_8to1_ws_kernel<PRO_BN, EPI_SSE, 256>), dim3(g), dim3(512), kThin8WsLds, st, a);
-#endif
-    } else if (pro == PRO_BN && epi == EPI_SSE) hipLaunchKernelGGL((thin_8to1_kernel<PRO_BN, EPI_SSE>), dim3(grid), dim3(256), kThin8Lds, st, a);
-    else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<PRO_BWD, EPI_BWD>), dim3(grid), dim3(256), kThin8Lds, st, a);
-    else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<PRO_ID, EPI_BWD>), dim3(grid), dim3(256), kThin8Lds, st, a);
+      hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE>), dim3(g), block, 0, st, a);
+    }
+    else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<W, PRO_BWD, EPI_BWD>), dim3(grid), block, kThin8Lds, st, a);
+    else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<W, PRO_ID, EPI_BWD>), dim3(grid), block, kThin8Lds, st, a);
     else return AVA_EINVAL;
   } else {
     return AVA_EINVAL;
@@ -1326,27 +1385,51 @@ int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, 
   return AVA_OK;
 }
 
-int ava_conv3x3_wgrad_thin(const WgradArgs& a0, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
-  if (mode != MODE_S1 || a0.Wo != THIN_W || a0.Ho % THIN_TH != 0) return AVA_EINVAL;
+int ava_conv3x3_thin(const ConvArgs& a0, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
+  if (mode != MODE_S1 || !thin_width_ok(a0.Wo) || a0.Ho % THIN_TH != 0) return AVA_EINVAL;
+  if (a0.Wo == 128) return conv3x3_thin_w<128>(a0, grid, Cin, Cout, pro, epi, st);
+  return conv3x3_thin_w<256>(a0, grid, Cin, Cout, pro, epi, st);
+}
+
+template <int W>
+static int conv3x3_wgrad_thin_w(const WgradArgs& a0, int grid, int Cin, int Cout, int dy_pro, hipStream_t st) {
+  const size_t kThin8Lds = (size_t)(THIN_IR * THIN_IC * 8 + 96 + 8) * sizeof(float);
+  const dim3 block(2 * W);
   WgradArgs a = a0;
   a.ntiles = a.B * (a.Ho / THIN_TH);
   if (Cin == 1 && Cout == 8) {
-    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_1to8_kernel<PRO_BWD>), dim3(grid), dim3(256), 0, st, a);
-    else if (dy_pro == PRO_ID) hipLaunchKernelGGL((thin_wgrad_1to8_kernel<PRO_ID>), dim3(grid), dim3(256), 0, st, a);
+    if (W == 256 && grid > 256) grid = 256;              // 200-register kernel: one 512-thread workgroup per CU
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_1to8_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
+    else if (dy_pro == PRO_ID) hipLaunchKernelGGL((thin_wgrad_1to8_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);
     else return AVA_EINVAL;
   } else if (Cin == 8 && Cout == 1) {
     static bool attr = false;
     if (!attr) {
-      if (thin_set_lds(&thin_wgrad_8to1_kernel<PRO_BWD>) != AVA_OK || thin_set_lds(&thin_wgrad_8to1_kernel<PRO_ID>) != AVA_OK)
+      if (thin_set_lds(&thin_wgrad_8to1_kernel<W, PRO_BWD>, kThin8Lds) != AVA_OK ||
+          thin_set_lds(&thin_wgrad_8to1_kernel<W, PRO_ID>, kThin8Lds) != AVA_OK)
         return AVA_ELAUNCH;
       attr = true;
     }
-    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_8to1_kernel<PRO_BWD>), dim3(grid), dim3(256), kThin8Lds, st, a);
-    else if (dy_pro == PRO_ID) hipLaunchKernelGGL((thin_wgrad_8to1_kernel<PRO_ID>), dim3(grid), dim3(256), kThin8Lds, st, a);
+    if (W == 256 && grid > 256) grid = 256;
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_8to1_kernel<W, PRO_BWD>), dim3(grid), block, kThin8Lds, st, a);
+    else if (dy_pro == PRO_ID) hipLaunchKernelGGL((thin_wgrad_8to1_kernel<W, PRO_ID>), dim3(grid), block, kThin8Lds, st, a);
     else return AVA_EINVAL;
   } else {
     return AVA_EINVAL;
   }
   AVA_CHECK_LAUNCH();
   return AVA_OK;
+}
+
+// workgroups (= partial rows) ava_conv3x3_wgrad_thin launches for this shape; 0: not a thin shape
+int ava_conv3x3_wgrad_thin_rows(const WgradArgs& a, int grid, int Cin, int Cout, int mode) {
+  if (mode != MODE_S1 || !thin_width_ok(a.Wo) || a.Ho % THIN_TH != 0) return 0;
+  if (!((Cin == 1 && Cout == 8) || (Cin == 8 && Cout == 1))) return 0;
+  return (a.Wo == 256 && grid > 256) ? 256 : grid;
+}
+
+int ava_conv3x3_wgrad_thin(const WgradArgs& a0, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
+  if (mode != MODE_S1 || !thin_width_ok(a0.Wo) || a0.Ho % THIN_TH != 0) return AVA_EINVAL;
+  if (a0.Wo == 128) return conv3x3_wgrad_thin_w<128>(a0, grid, Cin, Cout, dy_pro, st);
+  return conv3x3_wgrad_thin_w<256>(a0, grid, Cin, Cout, dy_pro, st);
 }

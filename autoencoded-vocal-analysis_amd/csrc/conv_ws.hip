@@ -276,9 +276,8 @@ static int launch_ws_pe(const ConvArgs& a, int grid, int pro, int epi, hipStream
 
 // the same shape table as ava_conv3x3_mfma
 int ava_conv3x3_mfma_ws(const ConvArgs& a, int grid, int Cin, int Cout, int mode, int pro, int epi, hipStream_t st) {
-  const int tw = a.Wo >= 32 ? 32 : 16;
 #define AVA_WS_CASE(ci, co, md, tww, thh) \
-  if (Cin == ci && Cout == co && mode == md && tw == tww) return launch_ws_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
+  if (Cin == ci && Cout == co && mode == md && a.Wo % tww == 0 && a.Ho % thh == 0) return launch_ws_pe<ci, co, md, tww, thh>(a, grid, pro, epi, st);
   AVA_WS_CASE(8, 8, MODE_DOWN, 32, 4)
   AVA_WS_CASE(8, 16, MODE_S1, 32, 8)
   AVA_WS_CASE(16, 16, MODE_DOWN, 32, 4)

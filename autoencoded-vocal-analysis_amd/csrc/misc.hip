@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* __restrict__ latent_sums, int B,
                                                             const float* __restrict__ sse_partials, int nparts,
-                                                            int stride, int zdim, float prec,
+                                                            int stride, int zdim, float prec, double xdim,
                                                             float* __restrict__ loss_out,
                                                             double* __restrict__ loss_accum) {
   __shared__ double red[3][4];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(const float* __restr
     sse = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     // -elbo = 0.5*(sum z^2 + zdim ln 2pi) + 0.5*X_DIM*ln(2pi/prec) + 0.5*prec*SSE - sum H   (vae.py:316-323)
     const double c1 = 0.5 * zdim * LOG_2PI;
-    const double c2 = 0.5 * 16384.0 * (LOG_2PI - log((double)prec));
+    const double c2 = 0.5 * xdim * (LOG_2PI - log((double)prec));      // X_DIM = H*W (16384 for the reference's 128 x 128)
     const float loss = (float)(0.5 * sz2 + c1 + c2 + 0.5 * (double)prec * sse - sh);
     loss_out[0] = loss;
     if (loss_accum != nullptr) *loss_accum += (double)loss;      // running epoch sum (train_epoch's `train_loss += loss.item()`)
@@ -183,16 +183,16 @@ int ava_scale_inplace(float* v, int64_t n, const float* scale, hipStream_t st) {
   return AVA_OK;
 }
 int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
-                              int zdim, float prec, float* loss_out, double* loss_accum, hipStream_t st) {
+                              int zdim, float prec, int xdim, float* loss_out, double* loss_accum, hipStream_t st) {
   hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, latent_sums, B, sse_partials, nparts, stride, zdim,
-                     prec, loss_out, loss_accum);
+                     prec, (double)xdim, loss_out, loss_accum);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 extern "C" int ava_elbo_finalize(const float* latent_sums, int B, const float* sse_partials, int nparts, int zdim,
                                  float prec, float* loss_out, ava_stream_t s) {
   if (latent_sums == nullptr || sse_partials == nullptr || loss_out == nullptr) return AVA_EINVAL;
-  return ava_elbo_finalize_strided(latent_sums, B, sse_partials, nparts, 2, zdim, prec, loss_out, nullptr, to_stream(s));
+  return ava_elbo_finalize_strided(latent_sums, B, sse_partials, nparts, 2, zdim, prec, 16384, loss_out, nullptr, to_stream(s));
 }
 extern "C" int ava_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                              double beta2, double eps, int step, ava_stream_t s) {

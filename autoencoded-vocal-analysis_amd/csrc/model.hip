@@ -9,7 +9,7 @@
 #include "conv_fused.h"
 
 // internal entry points of the other translation units
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int* nparts,
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int* nparts,
                            hipStream_t st);
 int ava_bn_eval_all(const float* const* gamma, const float* const* beta, const int* C, const float* running, float* save,
                     hipStream_t st);
@@ -17,10 +17,10 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
                    int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s);
-int ava_nhwc_to_nchw(const float* in, float* out, int B, hipStream_t st);
-int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, hipStream_t st);
+int ava_nhwc_to_nchw(const float* in, float* out, int B, int P, hipStream_t st);
+int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, int P, hipStream_t st);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
-                             float* out, int B, hipStream_t st);
+                             float* out, int B, int P, hipStream_t st);
 int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, float* A, float* Bc, float* Cc, int eval,
                            hipStream_t st);
@@ -31,7 +31,7 @@ int ava_scale_inplace(float* v, int64_t n, const float* scale, hipStream_t st);
 int ava_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                           double eps, int step, const int* skip_if_set, hipStream_t st);
 int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
-                              int zdim, float prec, float* loss_out, double* loss_accum, hipStream_t st);
+                              int zdim, float prec, int xdim, float* loss_out, double* loss_accum, hipStream_t st);
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_EXP = 2 };
 
@@ -61,11 +61,13 @@ static inline int prof_family(int cat) {
 }
 
 struct ConvLayer {
-  int cin, cout, mode, hi;        // forward gather mode, input height (= width)
-  int ho;
+  int cin, cout, mode;            // forward gather mode
+  int hi, ho;                     // input / output height at the reference's 128 x 128 (kLayers); the model's own
+                                  // per-layer sizes are these scaled by H/128 and W/128 (ava_model::lay)
   int transposed;                 // 0: Conv2d, 1: ConvTranspose2d
   int pw, pb, pg, pbeta;          // parameter indices: weight, bias, bn gamma, bn beta
 };
+struct LayerDims { int hi, wi, ho, wo; };
 
 // named_parameters() order (vae.py:125-168): conv1..7 (w,b) 0..13 ; bn1..7 (w,b) 14..27 ; fc1,fc2,fc31,fc32,fc33,
 // fc41,fc42,fc43,fc5..fc8 (w,b) 28..51 ; convt1..7 (w,b) 52..65 ; bn8..14 (w,b) 66..79
@@ -85,15 +87,16 @@ struct ParamInfo { int64_t off, numel; };
 // fc31.w fc32.w fc33.w | fc31.b fc32.b fc33.b so that they form one [192,256] matrix and one [192] bias
 // (a single GEMM forward, a single pair of GEMMs backward).  Checkpoints are unaffected: the Python
 // parameters are views into the arena keyed by name.
-static void build_param_table(int z, ParamInfo* tab, int64_t* total) {
+static void build_param_table(int z, int F, ParamInfo* tab, int64_t* total) {
   int64_t numel[NPARAM];
   int p = 0;
   const int enc[7][2] = {{1, 8}, {8, 8}, {8, 16}, {16, 16}, {16, 24}, {24, 24}, {24, 32}};
   for (int i = 0; i < 7; ++i) { numel[p++] = (int64_t)enc[i][0] * enc[i][1] * 9; numel[p++] = enc[i][1]; }
   const int bne[7] = {1, 8, 8, 16, 16, 24, 24};
   for (int i = 0; i < 7; ++i) { numel[p++] = bne[i]; numel[p++] = bne[i]; }
-  const int fc[12][2] = {{8192, 1024}, {1024, 256}, {256, 64}, {256, 64}, {256, 64}, {64, z}, {64, z}, {64, z},
-                         {z, 64}, {64, 256}, {256, 1024}, {1024, 8192}};
+  // fc1.in = fc8.out = F = 32 * (H/8) * (W/8): 8192 at the reference's 128 x 128 (vae.py:142,153,224,262)
+  const int fc[12][2] = {{F, 1024}, {1024, 256}, {256, 64}, {256, 64}, {256, 64}, {64, z}, {64, z}, {64, z},
+                         {z, 64}, {64, 256}, {256, 1024}, {1024, F}};
   for (int i = 0; i < 12; ++i) { numel[p++] = (int64_t)fc[i][0] * fc[i][1]; numel[p++] = fc[i][1]; }
   const int dec[7][2] = {{32, 24}, {24, 24}, {24, 16}, {16, 16}, {16, 8}, {8, 8}, {8, 1}};
   for (int i = 0; i < 7; ++i) { numel[p++] = (int64_t)dec[i][0] * dec[i][1] * 9; numel[p++] = dec[i][1]; }
@@ -116,6 +119,9 @@ static void build_param_table(int z, ParamInfo* tab, int64_t* total) {
 
 struct ava_model {
   int z, maxB;
+  int H, W;                 // spectrogram size (128 x 128 in the reference, vae.py:33); W in {128, 256}, H % 64 == 0
+  int P8, F;                // pixels at the bottleneck (H/8 * W/8) and fc1.in = fc8.out = 32 * P8
+  LayerDims lay[NCONV];
   float prec;
   float *P, *G, *M, *V;
   float* bn_running;
@@ -171,16 +177,16 @@ struct Carver {
   }
 };
 
-static size_t max_gemm_ws(int z, int B) {
+static size_t max_gemm_ws(int z, int B, int F) {
   size_t mx = 0;
-  const int shapes[][3] = {{B, 1024, 8192}, {B, 256, 1024}, {B, 192, 256}, {B, z, 64}, {B, 64, z}, {B, 256, 64},
-                           {B, 1024, 256}, {B, 8192, 1024},
+  const int shapes[][3] = {{B, 1024, F}, {B, 256, 1024}, {B, 192, 256}, {B, z, 64}, {B, 64, z}, {B, 256, 64},
+                           {B, 1024, 256}, {B, F, 1024},
                            // dX products
-                           {B, 8192, 1024}, {B, 1024, 256}, {B, 256, 192}, {B, 64, z}, {B, z, 64}, {B, 64, 256},
-                           {B, 256, 1024}, {B, 1024, 8192},
+                           {B, F, 1024}, {B, 1024, 256}, {B, 256, 192}, {B, 64, z}, {B, z, 64}, {B, 64, 256},
+                           {B, 256, 1024}, {B, 1024, F},
                            // dW products (K = batch)
-                           {8192, 1024, B}, {1024, 256, B}, {256, 64, B}, {64, z, B}, {z, 64, B}, {192, 256, B},
-                           {256, 1024, B}, {1024, 8192, B}};
+                           {F, 1024, B}, {1024, 256, B}, {256, 64, B}, {64, z, B}, {z, 64, B}, {192, 256, B},
+                           {256, 1024, B}, {1024, F, B}};
   for (auto& s : shapes) {
     size_t b = ava_gemm_workspace_bytes(s[0], s[1], s[2]);
     if (b > mx) mx = b;
@@ -188,10 +194,11 @@ static size_t max_gemm_ws(int z, int B) {
   return mx;
 }
 
-static size_t wgrad_part_floats(int B, int l) {
+static size_t wgrad_part_floats(const ava_model* m, int B, int l) {
   const ConvLayer& L = kLayers[l];
-  int grid = ava_conv_wgrad_grid(B, L.ho, L.ho, L.mode);
-  const int fg = ava_conv_fused_grid_for(B, L.hi, L.hi, L.cin, L.cout, L.mode);     // fused backward kernel's rows
+  const LayerDims& D = m->lay[l];
+  int grid = ava_conv_wgrad_grid(B, D.ho, D.wo, L.mode);
+  const int fg = ava_conv_fused_grid_for(B, D.hi, D.wi, L.cin, L.cout, L.mode);     // fused backward kernel's rows
   if (fg > grid) grid = fg;
   return (size_t)grid * (9 * L.cin * L.cout + L.cout);
 }
@@ -200,18 +207,19 @@ static void carve(ava_model* m, void* ws, size_t* total) {
   Carver c{reinterpret_cast<char*>(ws), 0};
   const size_t B = (size_t)m->maxB;
   const int z = m->z;
+  const size_t F = (size_t)m->F, XD = (size_t)m->H * m->W;
   m->X[0] = nullptr;
   for (int l = 1; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
-    if (l == 7) m->X[l] = c.take(B * 8192);
-    else m->X[l] = c.take(B * L.hi * L.hi * L.cin);
+    if (l == 7) m->X[l] = c.take(B * F);
+    else m->X[l] = c.take(B * m->lay[l].hi * m->lay[l].wi * L.cin);
   }
-  m->y7 = c.take(B * 8192); m->y7t = c.take(B * 8192);
+  m->y7 = c.take(B * F); m->y7t = c.take(B * F);
   m->h1 = c.take(B * 1024); m->h2 = c.take(B * 256); m->h3 = c.take(B * 192);
   m->mu = c.take(B * z); m->u = c.take(B * z); m->logd = c.take(B * z); m->d = c.take(B * z); m->zs = c.take(B * z);
   m->lat_sums = c.take(B * 2);
-  m->h5 = c.take(B * 64); m->h6 = c.take(B * 256); m->h7 = c.take(B * 1024); m->f8 = c.take(B * 8192);
-  m->xrec = c.take(B * 16384); m->seed = c.take(B * 16384);
+  m->h5 = c.take(B * 64); m->h6 = c.take(B * 256); m->h7 = c.take(B * 1024); m->f8 = c.take(B * F);
+  m->xrec = c.take(B * XD); m->seed = c.take(B * XD);
   m->bn_part = c.take(1024 * 64);
   m->bn_save = c.take(NCONV * 4 * 32);
   m->bn_bwd = c.take(NCONV * 3 * 32);
@@ -219,12 +227,12 @@ static void carve(ava_model* m, void* ws, size_t* total) {
     m->Gf[l] = c.take(9 * kLayers[l].cin * kLayers[l].cout);
     m->Gb[l] = c.take(9 * kLayers[l].cin * kLayers[l].cout);
   }
-  m->gA = c.take(B * 131072); m->gB = c.take(B * 131072);
-  for (int l = 0; l < NCONV; ++l) m->wg_part[l] = c.take(wgrad_part_floats((int)B, l));
-  m->dF8 = c.take(B * 8192); m->dh7 = c.take(B * 1024); m->dh6 = c.take(B * 256); m->dh5 = c.take(B * 64);
+  m->gA = c.take(B * XD * 8); m->gB = c.take(B * XD * 8);          // largest activation: 8 channels at full resolution
+  for (int l = 0; l < NCONV; ++l) m->wg_part[l] = c.take(wgrad_part_floats(m, (int)B, l));
+  m->dF8 = c.take(B * F); m->dh7 = c.take(B * 1024); m->dh6 = c.take(B * 256); m->dh5 = c.take(B * 64);
   m->dz = c.take(B * z); m->dmu = c.take(B * z); m->du = c.take(B * z); m->dlogd = c.take(B * z);
-  m->dh3 = c.take(B * 192); m->dh2 = c.take(B * 256); m->dh1 = c.take(B * 1024); m->dy7 = c.take(B * 8192);
-  m->gemm_ws_bytes = max_gemm_ws(z, (int)B);
+  m->dh3 = c.take(B * 192); m->dh2 = c.take(B * 256); m->dh1 = c.take(B * 1024); m->dy7 = c.take(B * F);
+  m->gemm_ws_bytes = max_gemm_ws(z, (int)B, m->F);
   m->gemm_ws = c.take(m->gemm_ws_bytes / sizeof(float) + 64);
   m->loss_dev = c.take(64);
   m->status_dev = reinterpret_cast<int*>(c.take(64));
@@ -233,39 +241,62 @@ static void carve(ava_model* m, void* ws, size_t* total) {
 
 extern "C" int ava_version(void) { return 100; }
 
-extern "C" int64_t ava_arena_floats(int z_dim) {
+// spectrogram sizes the kernels cover: W = 128 or 256 (the full-resolution 1- and 8-channel layers run 2*W-thread
+// workgroups that own whole rows), H a multiple of 128 (16-row tiles of the layers at H/8 x W/8)
+static bool size_ok(int H, int W) { return (W == 128 || W == 256) && H >= 128 && H <= 1024 && H % 128 == 0; }
+
+static void set_geometry(ava_model* m, int H, int W) {
+  m->H = H; m->W = W;
+  m->P8 = (H / 8) * (W / 8);
+  m->F = 32 * m->P8;
+  for (int l = 0; l < NCONV; ++l) {
+    const ConvLayer& L = kLayers[l];
+    m->lay[l].hi = L.hi * H / 128; m->lay[l].wi = L.hi * W / 128;
+    m->lay[l].ho = L.ho * H / 128; m->lay[l].wo = L.ho * W / 128;
+  }
+}
+
+extern "C" int64_t ava_arena_floats_hw(int z_dim, int H, int W) {
+  if (!size_ok(H, W)) return -1;
   ParamInfo tab[NPARAM];
   int64_t total;
-  build_param_table(z_dim, tab, &total);
+  build_param_table(z_dim, 32 * (H / 8) * (W / 8), tab, &total);
   return total;
 }
-extern "C" int64_t ava_param_offset(int z_dim, int index, int64_t* numel) {
-  if (index < 0 || index >= NPARAM) return -1;
+extern "C" int64_t ava_param_offset_hw(int z_dim, int H, int W, int index, int64_t* numel) {
+  if (index < 0 || index >= NPARAM || !size_ok(H, W)) return -1;
   ParamInfo tab[NPARAM];
   int64_t total;
-  build_param_table(z_dim, tab, &total);
+  build_param_table(z_dim, 32 * (H / 8) * (W / 8), tab, &total);
   if (numel) *numel = tab[index].numel;
   return tab[index].off;
 }
-extern "C" size_t ava_workspace_bytes(int z_dim, int max_batch) {
+extern "C" size_t ava_workspace_bytes_hw(int z_dim, int H, int W, int max_batch) {
+  if (!size_ok(H, W)) return 0;
   ava_model tmp;
   tmp.z = z_dim;
   tmp.maxB = max_batch;
+  set_geometry(&tmp, H, W);
   size_t total = 0;
   carve(&tmp, nullptr, &total);
   return total;
 }
+extern "C" int64_t ava_arena_floats(int z_dim) { return ava_arena_floats_hw(z_dim, 128, 128); }
+extern "C" int64_t ava_param_offset(int z_dim, int index, int64_t* numel) { return ava_param_offset_hw(z_dim, 128, 128, index, numel); }
+extern "C" size_t ava_workspace_bytes(int z_dim, int max_batch) { return ava_workspace_bytes_hw(z_dim, 128, 128, max_batch); }
 
-extern "C" int ava_model_create(ava_model** out, int z_dim, int max_batch, float model_precision, float* params,
-                                float* grads, float* exp_avg, float* exp_avg_sq, float* bn_running,
-                                int64_t* bn_batches, void* workspace, size_t workspace_bytes) {
-  if (out == nullptr || z_dim < 1 || z_dim > 128 || max_batch < 1 || params == nullptr || workspace == nullptr)
+extern "C" int ava_model_create_hw(ava_model** out, int z_dim, int H, int W, int max_batch, float model_precision,
+                                   float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* bn_running,
+                                   int64_t* bn_batches, void* workspace, size_t workspace_bytes) {
+  if (out == nullptr || z_dim < 1 || z_dim > 128 || max_batch < 1 || params == nullptr || workspace == nullptr ||
+      !size_ok(H, W))
     return AVA_EINVAL;
   ava_model* m = new ava_model();
   m->z = z_dim; m->maxB = max_batch; m->prec = model_precision;
+  set_geometry(m, H, W);
   m->P = params; m->G = grads; m->M = exp_avg; m->V = exp_avg_sq;
   m->bn_running = bn_running; m->bn_batches = bn_batches;
-  build_param_table(z_dim, m->tab, &m->arena);
+  build_param_table(z_dim, m->F, m->tab, &m->arena);
   size_t need = 0;
   carve(m, workspace, &need);
   if (need > workspace_bytes) { delete m; return AVA_EWORKSPACE; }
@@ -274,29 +305,35 @@ extern "C" int ava_model_create(ava_model** out, int z_dim, int max_batch, float
   m->status_last = nullptr;
   m->bwd_scale = nullptr;
   m->sse_parts = 0;
-  // the only device write outside a stream: the ticket counters start at zero (every launch leaves them at zero)
   const size_t B = max_batch;
+  const int64_t F = m->F, XD = (int64_t)H * W;
   for (int l = 1; l < NCONV; ++l) {
     char nm[16];
     if (l < 7) { snprintf(nm, sizeof nm, "y%d", l); }
     else if (l == 7) { snprintf(nm, sizeof nm, "f8t"); }
     else { snprintf(nm, sizeof nm, "d%d", l - 7); }
-    m->dbg[nm] = {m->X[l], (int64_t)(l == 7 ? B * 8192 : B * kLayers[l].hi * kLayers[l].hi * kLayers[l].cin)};
+    m->dbg[nm] = {m->X[l], (int64_t)(l == 7 ? B * F : B * m->lay[l].hi * m->lay[l].wi * kLayers[l].cin)};
   }
-  m->dbg["y7"] = {m->y7, (int64_t)B * 8192}; m->dbg["y7t"] = {m->y7t, (int64_t)B * 8192};
+  m->dbg["y7"] = {m->y7, (int64_t)B * F}; m->dbg["y7t"] = {m->y7t, (int64_t)B * F};
   m->dbg["h1"] = {m->h1, (int64_t)B * 1024}; m->dbg["h2"] = {m->h2, (int64_t)B * 256};
   m->dbg["h3"] = {m->h3, (int64_t)B * 192};
   m->dbg["mu"] = {m->mu, (int64_t)B * z_dim}; m->dbg["u"] = {m->u, (int64_t)B * z_dim};
   m->dbg["logd"] = {m->logd, (int64_t)B * z_dim}; m->dbg["d"] = {m->d, (int64_t)B * z_dim};
   m->dbg["z"] = {m->zs, (int64_t)B * z_dim};
   m->dbg["h5"] = {m->h5, (int64_t)B * 64}; m->dbg["h6"] = {m->h6, (int64_t)B * 256};
-  m->dbg["h7"] = {m->h7, (int64_t)B * 1024}; m->dbg["f8"] = {m->f8, (int64_t)B * 8192};
-  m->dbg["xrec"] = {m->xrec, (int64_t)B * 16384}; m->dbg["seed"] = {m->seed, (int64_t)B * 16384};
+  m->dbg["h7"] = {m->h7, (int64_t)B * 1024}; m->dbg["f8"] = {m->f8, (int64_t)B * F};
+  m->dbg["xrec"] = {m->xrec, (int64_t)B * XD}; m->dbg["seed"] = {m->seed, (int64_t)B * XD};
   m->dbg["bn_save"] = {m->bn_save, NCONV * 4 * 32}; m->dbg["bn_bwd"] = {m->bn_bwd, NCONV * 3 * 32};
-  m->dbg["dz"] = {m->dz, (int64_t)B * z_dim}; m->dbg["dF8"] = {m->dF8, (int64_t)B * 8192};
-  m->dbg["dy7"] = {m->dy7, (int64_t)B * 8192};
+  m->dbg["dz"] = {m->dz, (int64_t)B * z_dim}; m->dbg["dF8"] = {m->dF8, (int64_t)B * F};
+  m->dbg["dy7"] = {m->dy7, (int64_t)B * F};
   *out = m;
   return AVA_OK;
+}
+extern "C" int ava_model_create(ava_model** out, int z_dim, int max_batch, float model_precision, float* params,
+                                float* grads, float* exp_avg, float* exp_avg_sq, float* bn_running,
+                                int64_t* bn_batches, void* workspace, size_t workspace_bytes) {
+  return ava_model_create_hw(out, z_dim, 128, 128, max_batch, model_precision, params, grads, exp_avg, exp_avg_sq,
+                             bn_running, bn_batches, workspace, workspace_bytes);
 }
 extern "C" void ava_model_destroy(ava_model* m) { delete m; }
 extern "C" const float* ava_last_z(ava_model* m) { return m->zs; }
@@ -524,29 +561,30 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
   int nparts = pre_nparts;                 // > 0: pack_stats_kernel already wrote the input statistics' partial rows
   if (train) {
     if (nparts <= 0) {
-      TRY(ava_bn_stats(x, (int64_t)B * 16384, 1, m->bn_part, &nparts, reinterpret_cast<ava_stream_t>(st)));
+      TRY(ava_bn_stats(x, (int64_t)B * m->H * m->W, 1, m->bn_part, &nparts, reinterpret_cast<ava_stream_t>(st)));
       mark(m, CAT_BN, st);
     }
-    TRY(finalize_fwd(m, 0, nparts, (int64_t)B * 16384, st));
+    TRY(finalize_fwd(m, 0, nparts, (int64_t)B * m->H * m->W, st));
   } else {
     TRY(bn_eval_all(m, st));       // all 14 layers from the running statistics (also serves the decoder)
   }
   for (int l = 0; l < 7; ++l) {
     const ConvLayer& L = kLayers[l];
+    const LayerDims& D = m->lay[l];
     const float* in = l == 0 ? x : m->X[l];
     float* out = l == 6 ? m->y7 : m->X[l + 1];
     // conv7's matrix-core kernel also writes the NCHW-flatten copy fc1 reads (saves the transpose launch)
     float* nchw = (l == 6 && conv7_writes_nchw()) ? m->y7t : nullptr;
     TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nchw,
-                       nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
+                       nullptr, nullptr, nullptr, m->bn_part, B, D.hi, D.wi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
                        0.f, reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_CONV_FWD, st);
     if (train && l < 6)
-      TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, L.ho, L.ho, L.mode), (int64_t)B * L.ho * L.ho, st));
+      TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, D.ho, D.wo, L.mode), (int64_t)B * D.ho * D.wo, st));
   }
-  if (!conv7_writes_nchw()) TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, st));
+  if (!conv7_writes_nchw()) TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, m->P8, st));
   mark(m, CAT_LAYOUT, st);
-  TRY(gemm(m, m->y7t, 0, PP(m, FC1), 0, PP(m, FC1 + 1), m->h1, 0, nullptr, nullptr, B, 1024, 8192, 1, 1, ACT_RELU, st));
+  TRY(gemm(m, m->y7t, 0, PP(m, FC1), 0, PP(m, FC1 + 1), m->h1, 0, nullptr, nullptr, B, 1024, m->F, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h1, 0, PP(m, FC2), 0, PP(m, FC2 + 1), m->h2, 0, nullptr, nullptr, B, 256, 1024, 1, 1, ACT_RELU, st));
   // fc31|fc32|fc33 as one [192,256] layer (arena keeps the three weights, then the three biases, contiguous)
   TRY(gemm(m, m->h2, 0, PP(m, FC31), 0, PP(m, FC31 + 1), m->h3, 0, nullptr, nullptr, B, 192, 256, 1, 1, ACT_RELU, st));
@@ -565,23 +603,24 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
   TRY(gemm(m, zin, 0, PP(m, FC5), 0, PP(m, FC5 + 1), m->h5, 0, nullptr, nullptr, B, 64, z, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h5, 0, PP(m, FC6), 0, PP(m, FC6 + 1), m->h6, 0, nullptr, nullptr, B, 256, 64, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h6, 0, PP(m, FC7), 0, PP(m, FC7 + 1), m->h7, 0, nullptr, nullptr, B, 1024, 256, 1, 1, ACT_RELU, st));
-  TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, 8192, 1024, 1, 1, ACT_RELU, st));
+  TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, m->F, 1024, 1, 1, ACT_RELU, st));
   int nparts = 0;
-  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, &nparts, st));
+  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, m->P8, &nparts, st));
   mark(m, CAT_LAYOUT, st);
-  if (train) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * 256, st));
+  if (train) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * m->P8, st));
   for (int l = 7; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
+    const LayerDims& D = m->lay[l];
     const bool last = l == NCONV - 1;
     float* out = last ? xrec : m->X[l + 1];
     TRY(ava_conv3x3_ex(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
-                       last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, L.hi, L.hi,
+                       last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, D.hi, D.wi,
                        L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec,
                        reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_CONV_FWD, st);
     if (train && !last)
-      TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, L.ho, L.ho, L.mode), (int64_t)B * L.ho * L.ho, st));
-    if (last) m->sse_parts = ava_conv_grid(B, L.ho, L.ho, L.mode);
+      TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, D.ho, D.wo, L.mode), (int64_t)B * D.ho * D.wo, st));
+    if (last) m->sse_parts = ava_conv_grid(B, D.ho, D.wo, L.mode);
   }
   return AVA_OK;
 }
@@ -592,7 +631,7 @@ static int forward_impl(ava_model* m, const float* x, int B, const float* eps_w,
   hipStream_t st = to_stream(s);
   const int z = m->z;
   int pre = 0;
-  TRY(pack_weights(m, true, st, bn_train ? x : nullptr, (int64_t)B * 16384, &pre, ng));
+  TRY(pack_weights(m, true, st, bn_train ? x : nullptr, (int64_t)B * m->H * m->W, &pre, ng));
   TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st, pre));
   mark(m, CAT_LAYOUT, st);
   TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
@@ -600,7 +639,7 @@ static int forward_impl(ava_model* m, const float* x, int B, const float* eps_w,
   m->eps_d_last = eps_d;
   mark(m, CAT_LATENT_LOSS, st);
   TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st));
-  TRY(ava_elbo_finalize_strided(m->lat_sums, B, m->bn_part, m->sse_parts, 2, z, m->prec,
+  TRY(ava_elbo_finalize_strided(m->lat_sums, B, m->bn_part, m->sse_parts, 2, z, m->prec, m->H * m->W,
                                 loss_out != nullptr ? loss_out : m->loss_dev, loss_accum, st));
   mark(m, CAT_LATENT_LOSS, st);
   m->lastB = B;
@@ -645,43 +684,44 @@ extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, flo
 
 // ---- all 14 weight-gradient reductions are issued per layer (partials buffer is shared) --------------
 // workgroups (= partial rows) of layer l's fused backward kernel; 0: the layer runs the separate kernels
-static int fused_grid(int l, int B) {
+static int fused_grid(const ava_model* m, int l, int B) {
   static const bool on = [] { const char* e = ava_env("AVA_CONV_FUSED"); return e == nullptr || atoi(e) != 0; }();
   if (!on) return 0;
   const ConvLayer& L = kLayers[l];
-  return ava_conv_fused_grid_for(B, L.hi, L.hi, L.cin, L.cout, L.mode);
+  return ava_conv_fused_grid_for(B, m->lay[l].hi, m->lay[l].wi, L.cin, L.cout, L.mode);
 }
 
 static int conv_layer_backward(ava_model* m, int l, const float* x0, const float* gin, const float* gin2,
                                const float* ca, const float* cb, const float* cc, int pro, float* gout, int B,
                                hipStream_t st) {
   const ConvLayer& L = kLayers[l];
+  const LayerDims& D = m->lay[l];
   const float* X = l == 0 ? x0 : m->X[l];
   // layers with a fused kernel: data gradient, BatchNorm-backward sums and weight/bias partials from one pass
-  const int fgrid = fused_grid(l, B);
+  const int fgrid = fused_grid(m, l, B);
   if (fgrid > 0 && (gout != nullptr || l == 0)) {
     FusedArgs a = {};
     a.x = X; a.xa = bn_scale(m, l); a.xb = bn_shift(m, l);
     a.dy = gin; a.dy2 = gin2; a.da = ca; a.db = cb; a.dc = cc;
     a.Gb = m->Gb[l]; a.dx = gout; a.mean = bn_mean(m, l); a.invstd = bn_invstd(m, l);
     a.bn_partials = m->bn_part; a.wg_partials = m->wg_part[l];
-    a.B = B; a.Hi = L.hi; a.Wi = L.hi; a.Ho = L.ho; a.Wo = L.ho;
+    a.B = B; a.Hi = D.hi; a.Wi = D.wi; a.Ho = D.ho; a.Wo = D.wo;
     a.tiles_y = a.tiles_x = a.ntiles = 0;
     TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
     mark(m, CAT_CONV_BWD_DATA, st);
-    return finalize_bwd(m, l, fgrid, (int64_t)B * L.hi * L.hi, st);
+    return finalize_bwd(m, l, fgrid, (int64_t)B * D.hi * D.wi, st);
   }
   // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
-  TRY(ava_conv3x3_wgrad(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], B, L.hi, L.hi, L.cin,
+  TRY(ava_conv3x3_wgrad(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], B, D.hi, D.wi, L.cin,
                         L.cout, L.mode, pro, st));
   mark(m, CAT_CONV_WGRAD, st);
   // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
   const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
   TRY(ava_conv3x3_ex(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
-                     m->bn_part, B, L.ho, L.ho, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f,
+                     m->bn_part, B, D.ho, D.wo, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f,
                      reinterpret_cast<ava_stream_t>(st)));
   mark(m, CAT_CONV_BWD_DATA, st);
-  TRY(finalize_bwd(m, l, ava_conv_grid(B, L.hi, L.hi, bmode), (int64_t)B * L.hi * L.hi, st));
+  TRY(finalize_bwd(m, l, ava_conv_grid(B, D.hi, D.wi, bmode), (int64_t)B * D.hi * D.wi, st));
   return AVA_OK;
 }
 
@@ -694,8 +734,8 @@ static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
     tab.e[n].partials = m->wg_part[l];
     tab.e[n].dw = GG(m, L.pw);
     tab.e[n].dbias = GG(m, L.pb);
-    const int fg = fused_grid(l, B);
-    tab.e[n].nparts = fg > 0 ? fg : ava_conv_wgrad_rows(B, L.hi, L.hi, L.cin, L.cout, L.mode, l == 13 || l == 6 ? PRO_ID : PRO_BWD);
+    const int fg = fused_grid(m, l, B);
+    tab.e[n].nparts = fg > 0 ? fg : ava_conv_wgrad_rows(B, m->lay[l].hi, m->lay[l].wi, L.cin, L.cout, L.mode, l == 13 || l == 6 ? PRO_ID : PRO_BWD);
     tab.e[n].cin = L.cin; tab.e[n].cout = L.cout;
     tab.e[n].kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);
     tab.e[n].block0 = blocks;
@@ -756,7 +796,7 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
   float* gnext = m->gB;
   mark(m, -1, st);
   if (m->bwd_scale != nullptr) {       // d(result)/d(loss) != 1: scale the two roots of the backward (here and latent_bwd)
-    TRY(ava_scale_inplace(m->seed, (int64_t)B * 16384, m->bwd_scale, st));
+    TRY(ava_scale_inplace(m->seed, (int64_t)B * m->H * m->W, m->bwd_scale, st));
     mark(m, CAT_LAYOUT, st);
   }
   TRY(conv_layer_backward(m, 13, x, m->seed, nullptr, nullptr, nullptr, nullptr, PRO_ID, gcur, B, st));
@@ -767,10 +807,10 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
     float* t = gcur; gcur = gnext; gnext = t;
   }
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
-  TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, st));
+  TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, m->P8, st));
   mark(m, CAT_LAYOUT, st);
   if (!whole) TRY(reduce_wgrads(m, 7, NCONV, B, st));
-  TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), 8192, 1024, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), m->F, 1024, B, 0, 0, ACT_NONE, st));
   return AVA_OK;
 }
 
@@ -780,7 +820,7 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   // ---- fully connected layers.  dX = (dY W) masked by the producer's ReLU runs as a chain; the weight
   // gradients dW = dY^T X (+ db = column sums) only need buffers that stay valid, so the two big ones are
   // issued in place and the eight small ones are collected into ONE grouped launch at the end. ----
-  TRY(gemm(m, m->dF8, 0, PP(m, FC8), 0, nullptr, m->dh7, 0, m->h7, nullptr, B, 1024, 8192, 1, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dF8, 0, PP(m, FC8), 0, nullptr, m->dh7, 0, m->h7, nullptr, B, 1024, m->F, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh7, 0, PP(m, FC7), 0, nullptr, m->dh6, 0, m->h6, nullptr, B, 256, 1024, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh6, 0, PP(m, FC6), 0, nullptr, m->dh5, 0, m->h5, nullptr, B, 64, 256, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh5, 0, PP(m, FC5), 0, nullptr, m->dz, 0, nullptr, nullptr, B, z, 64, 1, 0, ACT_NONE, st));
@@ -796,8 +836,8 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   TRY(gemm_group(m, hdx, 3, 1, 0, st));
   TRY(gemm(m, m->dh3, 0, PP(m, FC31), 0, nullptr, m->dh2, 0, m->h2, nullptr, B, 256, 192, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh2, 0, PP(m, FC2), 0, nullptr, m->dh1, 0, m->h1, nullptr, B, 1024, 256, 1, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh1, 0, m->y7t, 0, nullptr, GG(m, FC1), 0, nullptr, GG(m, FC1 + 1), 1024, 8192, B, 0, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, nullptr, nullptr, B, 8192, 1024, 1, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh1, 0, m->y7t, 0, nullptr, GG(m, FC1), 0, nullptr, GG(m, FC1 + 1), 1024, m->F, B, 0, 0, ACT_NONE, st));
+  TRY(gemm(m, m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, nullptr, nullptr, B, m->F, 1024, 1, 0, ACT_NONE, st));
   // ---- the eight small weight gradients (K = batch): fc7, fc6, fc5, fc41/42/43, fc31|32|33, fc2 ----
   const AvaGemmProblem dws[8] = {
       {m->dh7, 0, m->h6, 0, nullptr, GG(m, FC7), 0, nullptr, GG(m, FC7 + 1), 1024, 256, B, ACT_NONE},
@@ -816,7 +856,7 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, b
   float* gcur = m->gA;
   float* gnext = m->gB;
   mark(m, -1, st);
-  TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, st));             // dU_7 (ReLU of conv7)
+  TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, m->P8, st));             // dU_7 (ReLU of conv7)
   mark(m, CAT_LAYOUT, st);
   TRY(conv_layer_backward(m, 6, x, gcur, nullptr, nullptr, nullptr, nullptr, PRO_ID, gnext, B, st));
   { float* t = gcur; gcur = gnext; gnext = t; }

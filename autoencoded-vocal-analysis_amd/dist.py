@@ -65,12 +65,12 @@ def broadcast_parameters(model, src=0):
             td.broadcast(t, src=src)
 
 
-def per_call_constants(z_dim, model_precision):
+def per_call_constants(z_dim, model_precision, x_dim=X_DIM):
     """The two constants the reference adds once per forward call (vae.py:316,318)."""
-    return 0.5 * z_dim * math.log(2 * math.pi) + 0.5 * X_DIM * math.log(2 * math.pi / model_precision)
+    return 0.5 * z_dim * math.log(2 * math.pi) + 0.5 * x_dim * math.log(2 * math.pi / model_precision)
 
 
-def global_loss(local_sum, z_dim, model_precision, num_batches):
+def global_loss(local_sum, z_dim, model_precision, num_batches, x_dim=X_DIM):
     """Loss of the global batch from per-rank sums: every rank's forward added the per-call
     constants once per batch, a single-process run adds them once per *global* batch:
     ``L = sum_r L_r - (N-1) * num_batches * (c1 + c2)``."""
@@ -79,7 +79,7 @@ def global_loss(local_sum, z_dim, model_precision, num_batches):
     t = local_sum.detach().clone().double().reshape(1)
     td.all_reduce(t, op=td.ReduceOp.SUM)
     n = world_size()
-    return float(t.item()) - (n - 1) * num_batches * per_call_constants(z_dim, model_precision)
+    return float(t.item()) - (n - 1) * num_batches * per_call_constants(z_dim, model_precision, x_dim)
 
 
 def global_dataset_len(local_len):

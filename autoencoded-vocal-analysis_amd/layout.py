@@ -23,13 +23,28 @@ ENC_BN = [("bn%d" % (i + 1), c[1]) for i, c in enumerate(ENC_CONVS)]        # va
 DEC_BN = [("bn%d" % (i + 8), c[1]) for i, c in enumerate(DEC_CONVTS)]       # vae.py:162-168
 
 
-def fc_layers(z_dim):
+def bottleneck_features(x_shape=X_SHAPE):
+    """fc1.in = fc8.out: 32 channels x (H/8) x (W/8) -- the literal 8192 of ava/models/vae.py:142,153,224,262 at the
+    reference's 128 x 128."""
+    return 32 * (x_shape[0] // 8) * (x_shape[1] // 8)
+
+
+def check_x_shape(x_shape):
+    """Spectrogram sizes the kernels cover (csrc/model.hip: size_ok): W in {128, 256}, H a multiple of 128."""
+    h, w = int(x_shape[0]), int(x_shape[1])
+    if w not in (128, 256) or h % 128 != 0 or not 128 <= h <= 1024:
+        raise ValueError("unsupported spectrogram size %dx%d: width must be 128 or 256, height a multiple of 128" % (h, w))
+    return (h, w)
+
+
+def fc_layers(z_dim, x_shape=X_SHAPE):
     """(name, in_features, out_features) ; ava/models/vae.py:142-154"""
+    f = bottleneck_features(x_shape)
     return [
-        ("fc1", 8192, 1024), ("fc2", 1024, 256),
+        ("fc1", f, 1024), ("fc2", 1024, 256),
         ("fc31", 256, 64), ("fc32", 256, 64), ("fc33", 256, 64),
         ("fc41", 64, z_dim), ("fc42", 64, z_dim), ("fc43", 64, z_dim),
-        ("fc5", z_dim, 64), ("fc6", 64, 256), ("fc7", 256, 1024), ("fc8", 1024, 8192),
+        ("fc5", z_dim, 64), ("fc6", 64, 256), ("fc7", 256, 1024), ("fc8", 1024, f),
     ]
 
 
@@ -45,7 +60,7 @@ def checkpoint_layer_order():
 ParamSpec = namedtuple("ParamSpec", "name layer kind shape numel index")
 
 
-def param_specs(z_dim):
+def param_specs(z_dim, x_shape=X_SHAPE):
     """Parameters in the reference's ``named_parameters()`` order (= module
     registration order in ``_build_network``): conv1..7, bn1..7, fc*, convt1..7,
     bn8..14.  ``index`` is the Adam param index in ``optimizer_state``."""
@@ -63,7 +78,7 @@ def param_specs(z_dim):
     for name, c in ENC_BN:
         add(name, "weight", (c,))
         add(name, "bias", (c,))
-    for name, fin, fout in fc_layers(z_dim):
+    for name, fin, fout in fc_layers(z_dim, x_shape):
         add(name, "weight", (fout, fin))
         add(name, "bias", (fout,))
     for name, cin, cout, _ in DEC_CONVTS:
@@ -75,7 +90,7 @@ def param_specs(z_dim):
     return specs
 
 
-def arena_offsets(z_dim, align=64):
+def arena_offsets(z_dim, align=64, x_shape=X_SHAPE):
     """Offsets (in floats) of every parameter inside the flat fp32 arena.
 
     Mirror of ``build_param_table`` in ``csrc/model.hip`` (the native library is the source
@@ -85,7 +100,7 @@ def arena_offsets(z_dim, align=64):
     [192] bias.  Every tensor starts on a 256-byte boundary (``align`` floats); the same
     offsets index the gradient, exp_avg and exp_avg_sq arenas.
     Returns (OrderedDict name -> offset, total_floats)."""
-    specs = param_specs(z_dim)
+    specs = param_specs(z_dim, x_shape)
     order = list(range(32)) + [32, 34, 36, 33, 35, 37] + list(range(38, len(specs)))
     offs = {}
     cur = 0
@@ -96,5 +111,5 @@ def arena_offsets(z_dim, align=64):
     return OrderedDict((s.name, offs[s.name]) for s in specs), cur
 
 
-def num_params(z_dim):
-    return sum(s.numel for s in param_specs(z_dim))
+def num_params(z_dim, x_shape=X_SHAPE):
+    return sum(s.numel for s in param_specs(z_dim, x_shape))

@@ -59,12 +59,12 @@ def noise(batch, z_dim, salt_w=2002, salt_d=3003):
     return eps_w, eps_d
 
 
-def fixture_parameters(z_dim):
+def fixture_parameters(z_dim, x_shape=X_SHAPE):
     """name -> float32 ndarray for all 80 parameters (Appendix E recipe):
     weights ``r/sqrt(fan)``, BN weight ``1+0.1r``, BN bias ``0.1r``, other
     biases ``0.25r`` with ``r = 2*u01(numel, index+1) - 1``."""
     out = {}
-    for s in param_specs(z_dim):
+    for s in param_specs(z_dim, x_shape):
         r = 2.0 * u01(s.numel, s.index + 1) - 1.0
         if len(s.shape) >= 2:
             fan = 1

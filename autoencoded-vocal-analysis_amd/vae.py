@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import dist as _dist
-from .layout import X_SHAPE, X_DIM, param_specs, checkpoint_layer_order
+from .layout import X_SHAPE, X_DIM, param_specs, checkpoint_layer_order, bottleneck_features, check_x_shape
 from .optim import FlatAdam
 from .feed import DeviceFeeder
 
@@ -77,11 +77,17 @@ class _ElboFn(torch.autograd.Function):
 
 
 class VAE(nn.Module):
-    """Variational Autoencoder for 128x128 single-channel spectrograms
+    """Variational Autoencoder for single-channel spectrograms, 128x128 unless ``x_shape`` says otherwise
     (reference: ``ava/models/vae.py:40-122``)."""
 
-    def __init__(self, save_dir='', lr=1e-3, z_dim=32, model_precision=10.0, device_name="auto"):
+    def __init__(self, save_dir='', lr=1e-3, z_dim=32, model_precision=10.0, device_name="auto", *, x_shape=X_SHAPE):
+        """Reference signature (vae.py:80-81) plus one keyword-only extension: ``x_shape`` -- the reference fixes the
+        spectrogram size in the module constant ``X_SHAPE = (128, 128)`` and the literal 8192 (vae.py:33,142,153);
+        here the layers scale with ``(H, W)`` (width 128 or 256, height a multiple of 128; BASELINE config 5 is
+        256 x 256) and ``fc1.in = fc8.out = 32 * H/8 * W/8``."""
         super(VAE, self).__init__()
+        self.x_shape = check_x_shape(x_shape)
+        self.x_dim = self.x_shape[0] * self.x_shape[1]
         self.save_dir = save_dir
         self.lr = lr
         self.z_dim = z_dim
@@ -127,7 +133,7 @@ class VAE(nn.Module):
         self.bn5 = nn.BatchNorm2d(16)
         self.bn6 = nn.BatchNorm2d(24)
         self.bn7 = nn.BatchNorm2d(24)
-        self.fc1 = nn.Linear(8192, 1024)
+        self.fc1 = nn.Linear(bottleneck_features(self.x_shape), 1024)
         self.fc2 = nn.Linear(1024, 256)
         self.fc31 = nn.Linear(256, 64)
         self.fc32 = nn.Linear(256, 64)
@@ -138,7 +144,7 @@ class VAE(nn.Module):
         self.fc5 = nn.Linear(self.z_dim, 64)
         self.fc6 = nn.Linear(64, 256)
         self.fc7 = nn.Linear(256, 1024)
-        self.fc8 = nn.Linear(1024, 8192)
+        self.fc8 = nn.Linear(1024, bottleneck_features(self.x_shape))
         self.convt1 = nn.ConvTranspose2d(32, 24, 3, 1, padding=1)
         self.convt2 = nn.ConvTranspose2d(24, 24, 3, 2, padding=1, output_padding=1)
         self.convt3 = nn.ConvTranspose2d(24, 16, 3, 1, padding=1)
@@ -162,14 +168,15 @@ class VAE(nn.Module):
     def _arena_layout(self):
         """(offsets by parameter name, total floats).  The native library is the source of truth;
         ``layout.arena_offsets`` mirrors it (tests/test_layout.py) for machines without it."""
-        specs = param_specs(self.z_dim)
+        specs = param_specs(self.z_dim, self.x_shape)
+        H, W = self.x_shape
         try:
             lib = _lib.load()
-            offs = {s.name: int(lib.ava_param_offset(self.z_dim, s.index, None)) for s in specs}
-            total = int(lib.ava_arena_floats(self.z_dim))
+            offs = {s.name: int(lib.ava_param_offset_hw(self.z_dim, H, W, s.index, None)) for s in specs}
+            total = int(lib.ava_arena_floats_hw(self.z_dim, H, W))
         except (_lib.AvaHipError, OSError):
             from .layout import arena_offsets
-            offs, total = arena_offsets(self.z_dim)
+            offs, total = arena_offsets(self.z_dim, x_shape=self.x_shape)
         return specs, offs, total
 
     def _flatten_parameters(self):
@@ -257,10 +264,11 @@ class VAE(nn.Module):
         lib = _lib.load()
         self._destroy_handle()
         cap = max(batch, 8)
-        nbytes = lib.ava_workspace_bytes(self.z_dim, cap)
+        H, W = self.x_shape
+        nbytes = lib.ava_workspace_bytes_hw(self.z_dim, H, W, cap)
         self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         h = ctypes.c_void_p()
-        rc = lib.ava_model_create(ctypes.byref(h), self.z_dim, cap, float(self.model_precision),
+        rc = lib.ava_model_create_hw(ctypes.byref(h), self.z_dim, H, W, cap, float(self.model_precision),
                                   self._params.data_ptr(), self._grads.data_ptr(), self._exp_avg.data_ptr(),
                                   self._exp_avg_sq.data_ptr(), self._bn_running.data_ptr(),
                                   self._bn_batches.data_ptr(), self._workspace.data_ptr(), nbytes)
@@ -278,7 +286,7 @@ class VAE(nn.Module):
 
     def _prep_x(self, x):
         x = x.to(device=self.device, dtype=torch.float32)
-        assert x.dim() == 3 and tuple(x.shape[1:]) == X_SHAPE, "expected [batch,128,128] spectrograms"
+        assert x.dim() == 3 and tuple(x.shape[1:]) == self.x_shape, "expected [batch,%d,%d] spectrograms" % self.x_shape
         return x.contiguous()
 
     def _noise(self, B):
@@ -422,7 +430,7 @@ class VAE(nn.Module):
         B = z.shape[0]
         self._ensure(B)
         self._generation += 1
-        out = torch.empty(B, X_DIM, device=self.device)
+        out = torch.empty(B, self.x_dim, device=self.device)
         rc = _lib.load().ava_decode(self._handle, z.data_ptr(), B, 1 if self.training else 0, out.data_ptr(),
                                     _lib.stream())
         _lib.check(rc, "ava_decode")
@@ -440,7 +448,7 @@ class VAE(nn.Module):
         if return_latent_rec:
             B = x.shape[0]
             z = self._workspace_tensor("z", (B, self.z_dim)).detach().cpu().numpy()
-            rec = self._workspace_tensor("xrec", (B, X_SHAPE[0], X_SHAPE[1])).detach().cpu().numpy()
+            rec = self._workspace_tensor("xrec", (B, self.x_shape[0], self.x_shape[1])).detach().cpu().numpy()
             return loss, z, rec
         return loss
 
@@ -461,7 +469,7 @@ class VAE(nn.Module):
             self.optimizer.step()
             self._poll_status()
         self._check_status()
-        train_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, batch_idx + 1)
+        train_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, batch_idx + 1, self.x_dim)
         train_loss /= _dist.global_dataset_len(len(train_loader.dataset))
         print('Epoch: {} Average loss: {:.4f}'.format(self.epoch, train_loss))
         self.epoch += 1

@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--global-batch", type=int, default=1024,
                     help="global batch of the strong-scaling leg (configs[3]); 0 skips the leg")
     ap.add_argument("--z-dim", type=int, default=32)
+    ap.add_argument("--height", type=int, default=128, help="spectrogram height (reference: 128; configs[4]: 256)")
+    ap.add_argument("--width", type=int, default=128, help="spectrogram width (128 or 256)")
     ap.add_argument("--pool", type=int, default=8, help="distinct device-resident batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two HIP-event passes")
@@ -98,7 +100,7 @@ def one_step(model, x):
     model.optimizer.step()
 
 
-def loader_path(model, B, z_dim):
+def loader_path(model, B, z_dim, shape):
     """PCIe-inclusive rate of VAE.train_epoch fed from HOST memory (never `value`): items collated into the build's
     page-locked ring in their stored dtype (PinnedBatchLoader), raw DMA on a copy stream and device-side cast
     (DeviceFeeder + ava_cast_to_f32), against the reference's hand-over (CPU float32 batches, synchronous
@@ -109,7 +111,7 @@ def loader_path(model, B, z_dim):
     from ava_amd import synthetic as syn
     from ava_amd.feed import PinnedBatchLoader
     nb, epochs = 8, 4
-    base = syn.spectrograms(B * nb, salt=1001)
+    base = syn.spectrograms(B * nb, salt=1001, shape=shape)
     out = {"unit": "spectrograms/s", "batches_per_epoch": nb, "epochs_timed": epochs, "note": "host-resident data, H2D inside the timed region"}
 
     def run(loader, prefetch):
@@ -146,7 +148,7 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(batch, z_dim, protocol):
+def cpu_baseline(batch, z_dim, protocol, shape=(128, 128)):
     """CPU oracle (stock PyTorch-CPU ops = the ATen kernels the reference dispatches to, autograd backward, restated
     Adam) on the SAME batch shape; median of the timed steps.  Two thread settings: the fastest one found on this host
     class (tools/cpu_threads.py: 16 of 8/16/32/64/128 on the 2x64-core EPYC 9575F box) and all cores."""
@@ -155,12 +157,12 @@ def cpu_baseline(batch, z_dim, protocol):
     from ava_amd import synthetic as syn
     from oracle import vae_oracle as O
     cores = os.cpu_count() or 1
-    x = torch.from_numpy(syn.spectrograms(batch))
+    x = torch.from_numpy(syn.spectrograms(batch, shape=shape))
     ew, ed = [torch.from_numpy(a) for a in syn.noise(batch, z_dim)]
 
     def run(threads, warm, timed):
         torch.set_num_threads(threads)
-        P = O.to_params(syn.fixture_parameters(z_dim), requires_grad=True)
+        P = O.to_params(syn.fixture_parameters(z_dim, shape), requires_grad=True)
         running = O.fresh_running_stats()
         opt = {"step": 0, "m": {}, "v": {}}
         for _ in range(warm):
@@ -209,13 +211,12 @@ def main():
     from ava_amd import _lib, synthetic as syn
     from ava_amd import dist as adist
     from ava_amd.vae import VAE
-    from ava_amd.layout import X_SHAPE
 
     torch.manual_seed(1234)
-    model = VAE(z_dim=args.z_dim, device_name="cuda")
+    H, W = args.height, args.width
+    model = VAE(z_dim=args.z_dim, device_name="cuda", x_shape=(H, W))
     adist.broadcast_parameters(model)
     model.train()
-    H, W = X_SHAPE
 
     def sync():
         if world > 1:
@@ -224,7 +225,7 @@ def main():
 
     def make_pool(B):
         # device-resident pool of distinct synthetic batches (hash recipe, salt 1001; each rank its own shard)
-        return [torch.from_numpy(syn.spectrograms(B, salt=1001, start_item=(rank * args.pool + i) * B)).cuda()
+        return [torch.from_numpy(syn.spectrograms(B, salt=1001, start_item=(rank * args.pool + i) * B, shape=(H, W))).cuda()
                 for i in range(args.pool)]
 
     def timed(pool, steps, warmup):
@@ -309,7 +310,7 @@ def main():
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[::-1]:
             try:
                 tj = json.load(open(path))
-                if B == 256 and world == 1 and args.z_dim == 32:
+                if B == 256 and world == 1 and args.z_dim == 32 and (H, W) == (128, 128):
                     traffic, traffic_src = tj["conv_family_bytes_per_step"], os.path.relpath(path, ROOT)
                 break
             except Exception:
@@ -344,7 +345,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "configs[%d]: mouse_sylls VAE, batch %d synthetic %dx%d fp32 spectrograms per GPU, z=%d, "
                                   "train step = zero_grad+forward+backward%s+Adam, device-resident batches"
-                                  % (3 if world > 1 else (2 if args.z_dim == 64 else 1), B, H, W, args.z_dim,
+                                  % (4 if (H, W) != (128, 128) else (3 if world > 1 else (2 if args.z_dim == 64 else 1)), B, H, W, args.z_dim,
                                      "+RCCL grad all-reduce" if world > 1 else ""),
                       "global_batch": world * B, "per_gpu_batch": B, "z_dim": args.z_dim, "parallelism": "dp%d" % world},
            "elbo_last_batch_mean": round(elbo, 3), "dist": dist_info}
@@ -354,9 +355,9 @@ def main():
         out["strong_scaling"] = strong
     if world == 1 and not args.no_loader_path:
         model._ensure(B)
-        out["loader_path"] = loader_path(model, B, args.z_dim)
+        out["loader_path"] = loader_path(model, B, args.z_dim, (H, W))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, args.z_dim, args.cpu_protocol)
+        out["cpu_baseline"] = cpu_baseline(B, args.z_dim, args.cpu_protocol, (H, W))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

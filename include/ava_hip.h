@@ -51,6 +51,17 @@ int ava_model_create(ava_model** out, int z_dim, int max_batch, float model_prec
                      float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                      float* bn_running, int64_t* bn_batches, void* workspace, size_t workspace_bytes);
 void ava_model_destroy(ava_model* m);
+/* The same for spectrograms of H x W instead of the reference's module constant X_SHAPE = (128, 128) (vae.py:33-36;
+ * BASELINE config 5 is 256 x 256): every layer keeps its channels, strides and 3x3 kernels, the spatial sizes scale, and
+ * fc1.in = fc8.out = 32 * (H/8) * (W/8) replaces the literal 8192 of vae.py:142,153,224,262.  W must be 128 or 256 and H
+ * a multiple of 128 (128..1024); other sizes return -1 / 0 / AVA_EINVAL.  The functions without the _hw suffix are
+ * these with H = W = 128. */
+int64_t ava_arena_floats_hw(int z_dim, int H, int W);
+int64_t ava_param_offset_hw(int z_dim, int H, int W, int index, int64_t* numel);
+size_t ava_workspace_bytes_hw(int z_dim, int H, int W, int max_batch);
+int ava_model_create_hw(ava_model** out, int z_dim, int H, int W, int max_batch, float model_precision,
+                        float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                        float* bn_running, int64_t* bn_batches, void* workspace, size_t workspace_bytes);
 
 /* ---- whole-path entry points ------------------------------------------------------------------ */
 /* VAE.forward (vae.py:273-327): encode -> rsample -> decode -> -ELBO.

@@ -124,7 +124,7 @@ def encode(P, x, running=None, train=True, record=None, masks=None):
         h = _relu(F.conv2d(h, P[conv + ".weight"], P[conv + ".bias"], stride=stride, padding=1), conv, masks)
         if record is not None:
             record[conv + ".out"] = h
-    h = h.reshape(-1, 8192)                                     # vae.py:224 (NCHW flatten)
+    h = h.reshape(h.shape[0], -1)                               # vae.py:224 (NCHW flatten; 8192 features at 128 x 128)
     h = _relu(F.linear(h, P["fc1.weight"], P["fc1.bias"]), "fc1", masks)
     h = _relu(F.linear(h, P["fc2.weight"], P["fc2.bias"]), "fc2", masks)
     if record is not None:
@@ -137,15 +137,16 @@ def encode(P, x, running=None, train=True, record=None, masks=None):
     return mu, u, torch.exp(a)                                   # vae.py:232
 
 
-def decode(P, z, running=None, train=True, record=None, masks=None):
-    """vae.py:258-270.  Returns x_rec ``[B,16384]``."""
+def decode(P, z, running=None, train=True, record=None, masks=None, x_shape=(128, 128)):
+    """vae.py:258-270.  Returns x_rec ``[B, H*W]`` (``[B,16384]`` at the reference's X_SHAPE; ``x_shape`` other than
+    (128, 128) is this build's size extension: fc8.out = 32 * H/8 * W/8)."""
     h = _relu(F.linear(z, P["fc5.weight"], P["fc5.bias"]), "fc5", masks)
     h = _relu(F.linear(h, P["fc6.weight"], P["fc6.bias"]), "fc6", masks)
     h = _relu(F.linear(h, P["fc7.weight"], P["fc7.bias"]), "fc7", masks)
     h = _relu(F.linear(h, P["fc8.weight"], P["fc8.bias"]), "fc8", masks)
     if record is not None:
         record["fc8.out"] = h
-    h = h.reshape(-1, 32, 16, 16)                                # vae.py:262
+    h = h.reshape(-1, 32, x_shape[0] // 8, x_shape[1] // 8)     # vae.py:262 (32 x 16 x 16 at 128 x 128)
     for i, (convt, bn, stride) in enumerate(DEC):
         h = batchnorm(h, bn, P, running, train, record)
         h = F.conv_transpose2d(h, P[convt + ".weight"], P[convt + ".bias"], stride=stride,
@@ -154,7 +155,7 @@ def decode(P, z, running=None, train=True, record=None, masks=None):
             h = _relu(h, convt, masks)                           # no ReLU after convt7 (vae.py:269)
         if record is not None:
             record[convt + ".out"] = h
-    return h.reshape(-1, X_DIM)
+    return h.reshape(-1, x_shape[0] * x_shape[1])
 
 
 def rsample(mu, u, d, eps_w, eps_d):
@@ -184,7 +185,7 @@ def loss_terms(x, x_rec, z, u, d, model_precision=10.0):
     sse = ((x.reshape(x.shape[0], -1) - x_rec) ** 2).sum(dim=1).sum()
     sum_h = entropy(u, d).sum()
     c1 = 0.5 * zdim * math.log(2 * math.pi)
-    c2 = 0.5 * X_DIM * math.log(2 * math.pi / model_precision)
+    c2 = 0.5 * x[0].numel() * math.log(2 * math.pi / model_precision)      # X_DIM (vae.py:35,318)
     loss = 0.5 * sum_z2 + c1 + c2 + 0.5 * model_precision * sse - sum_h
     return loss, sum_z2, sse, sum_h
 
@@ -196,7 +197,7 @@ def forward(P, x, eps_w, eps_d, running=None, train=True, model_precision=10.0, 
     if not bool((d > 0).all()):
         raise ValueError("cov_diag must be positive")
     z = rsample(mu, u, d, eps_w, eps_d)
-    x_rec = decode(P, z, running, train, record, masks)
+    x_rec = decode(P, z, running, train, record, masks, tuple(x.shape[1:]))
     loss, sum_z2, sse, sum_h = loss_terms(x, x_rec, z, u, d, model_precision)
     out = dict(loss=loss, sum_z2=sum_z2, sse=sse, sum_h=sum_h, mu=mu, u=u, d=d, z=z, x_rec=x_rec)
     return out

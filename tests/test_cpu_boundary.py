@@ -143,3 +143,35 @@ def test_synthetic_loader_contract():
     # the integer-hash recipe is platform independent: pin a few values
     np.testing.assert_allclose(syn.u01(3, 1001), [0.17569250689332405, 0.46630860756399706, 0.06287327795656672], rtol=0, atol=1e-15)
     assert torch.equal(torch.from_numpy(syn.spectrograms(3)[2]), ds[2])
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (128, 256), (256, 128)])
+def test_size_extension_layout_mirror_and_surface(shape):
+    """x_shape other than the reference's (128, 128) (BASELINE config 5: 256 x 256): fc1.in = fc8.out = 32*H/8*W/8, the
+    arena mirror agrees with the library, everything else keeps the reference's shapes."""
+    import ctypes
+    lib = _lib.load()
+    z = 128
+    H, W = shape
+    f = 32 * (H // 8) * (W // 8)
+    assert layout.bottleneck_features(shape) == f
+    offs, total = layout.arena_offsets(z, x_shape=shape)
+    assert total == lib.ava_arena_floats_hw(z, H, W)
+    for s in layout.param_specs(z, shape):
+        n = ctypes.c_int64()
+        assert offs[s.name] == lib.ava_param_offset_hw(z, H, W, s.index, ctypes.byref(n)) and n.value == s.numel
+    assert lib.ava_workspace_bytes_hw(z, H, W, 8) > lib.ava_workspace_bytes(z, 8) > 0
+    m = VAE(z_dim=z, device_name="cpu", x_shape=shape)
+    assert tuple(m.fc1.weight.shape) == (1024, f) and tuple(m.fc8.weight.shape) == (f, 1024)
+    assert m.x_shape == shape and m.x_dim == H * W
+    assert [n for n, _ in m.named_parameters()] == [s.name for s in layout.param_specs(z, shape)]
+    assert tuple(m.conv1.weight.shape) == (8, 1, 3, 3) and tuple(m.convt7.weight.shape) == (8, 1, 3, 3)
+
+
+def test_unsupported_sizes_are_refused():
+    lib = _lib.load()
+    for bad in [(128, 192), (96, 128), (64, 128), (128, 512), (2048, 128)]:
+        with pytest.raises(ValueError):
+            VAE(device_name="cpu", x_shape=bad)
+        assert lib.ava_arena_floats_hw(32, bad[0], bad[1]) == -1 and lib.ava_workspace_bytes_hw(32, bad[0], bad[1], 8) == 0
+    assert lib.ava_arena_floats_hw(32, 128, 128) == lib.ava_arena_floats(32)

@@ -38,12 +38,16 @@ def layer_tensors(name, cin, cout, hi, transposed, B, seed):
     return x, w, b, scale, shift
 
 
-@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+# the same layers at twice the size: the spectrogram-size extension (BASELINE configs[4]: 256 x 256 input)
+LAYERS_2X = [(n + "@2x", ci, co, md, 2 * hi, tr) for (n, ci, co, md, hi, tr) in LAYERS]
+
+
+@pytest.mark.parametrize("layer", LAYERS + LAYERS_2X, ids=[l[0] for l in LAYERS + LAYERS_2X])
 @pytest.mark.parametrize("B", [1, 3])
 def test_conv_forward(layer, B):
     """BN-apply prologue (zero padding AFTER BatchNorm) + conv/convT + bias + ReLU + statistics epilogue."""
     name, cin, cout, mode, hi, tr = layer
-    if name == "convt7":
+    if name.startswith("convt7"):
         pytest.skip("convt7 has no ReLU / statistics epilogue in the network (vae.py:269); its forward is the SSE-epilogue test below")
     x, w, b, scale, shift = layer_tensors(name, cin, cout, hi, tr, B, 11)
     xhat = x * scale[None, :, None, None] + shift[None, :, None, None]
@@ -58,7 +62,7 @@ def test_conv_forward(layer, B):
     assert rel(sums[cout:], (want * want).sum(dim=(0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+@pytest.mark.parametrize("layer", LAYERS + LAYERS_2X, ids=[l[0] for l in LAYERS + LAYERS_2X])
 def test_conv_backward_data_and_wgrad(layer):
     """ReLU-mask + BatchNorm-backward prologue, backward-data with BN-backward sums, weight/bias gradient."""
     name, cin, cout, mode, hi, tr = layer

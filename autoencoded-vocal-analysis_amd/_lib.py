@@ -53,6 +53,7 @@ SIGNATURES = {
     "ava_param_offset_hw": (_i64, [_i, _i, _i, _i, C.POINTER(_i64)]),
     "ava_workspace_bytes_hw": (_sz, [_i, _i, _i, _i]),
     "ava_model_create_hw": (_i, [C.POINTER(_p), _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz]),
+    "ava_model_create_ex": (_i, [C.POINTER(_p), _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _sz]),
     "ava_forward": (_i, [_p, _p, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ava_forward_noise": (_i, [_p, _p, _i, _p, C.c_uint64, C.c_uint64, _i, _p, _p, _p, _p]),
     "ava_backward": (_i, [_p, _p, _i, _p]),

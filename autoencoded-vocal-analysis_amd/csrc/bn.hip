@@ -81,26 +81,17 @@ __device__ void column_sums(const float* __restrict__ partials, int nparts, int 
   }
   scratch[t] = grp < groups ? s : 0.0;
   __syncthreads();
-  // with few columns there are hundreds of groups (bn1: 2 columns, 512 groups): 32 threads per column first sum
-  // every 32nd group, then one thread per column adds the 32 results -- fixed order, 16+32 dependent adds instead of 512
-  if (groups > 64) {
-    double part = 0.0;
-    const int col2 = t % ncols, j = t / ncols;
-    if (j < 32)
-      for (int gI = j; gI < groups; gI += 32) part += scratch[gI * ncols + col2];
+  // Sum the per-group results of every column with a binary tree over the groups (fixed shape -> deterministic):
+  // ceil(log2(groups)) rounds of one fp64 add per thread instead of one thread per column walking all its groups
+  // (64 dependent LDS reads + adds for the 8-channel layers: 1.6 us of a 5 us kernel).
+  int cnt = groups;
+  while (cnt > 1) {
+    const int half = (cnt + 1) >> 1;
+    if (grp < cnt - half) scratch[t] += scratch[t + half * ncols];     // t = grp * ncols + col
     __syncthreads();
-    if (j < 32) scratch[j * ncols + col2] = part;
-    __syncthreads();
-    if (t < ncols) {
-      double tot = 0.0;
-      for (int jj = 0; jj < 32; ++jj) tot += scratch[jj * ncols + t];
-      sums[t] = tot;
-    }
-  } else if (t < ncols) {
-    double tot = 0.0;
-    for (int gI = 0; gI < groups; ++gI) tot += scratch[gI * ncols + t];
-    sums[t] = tot;
+    cnt = half;
   }
+  if (t < ncols) sums[t] = scratch[t];
   __syncthreads();
 }
 
@@ -169,6 +160,17 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
 // workgroups keep every CU busy (one workgroup per sample left 3/4 of the waves idle: 20 us -> ~5 us).
 // NCHW element (c, p) of sample b: b*32*P + c*P + p ; NHWC element: b*32*P + p*32 + c.  `nq` = P / 64 slabs per sample.
 #define QPIX 64
+// scalar store / round-trip of an activation element (float or bfloat16 bits in an unsigned short; conv_common.h has
+// the vector forms used by the convolution kernels)
+template <typename T> __device__ __forceinline__ float ava_stored_bn(float v);
+template <> __device__ __forceinline__ float ava_stored_bn<float>(float v) { return v; }
+template <> __device__ __forceinline__ float ava_stored_bn<unsigned short>(float v) { return (float)(__bf16)v; }
+template <typename T> __device__ __forceinline__ void ava_store_bn(T* p, float v);
+template <> __device__ __forceinline__ void ava_store_bn<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void ava_store_bn<unsigned short>(unsigned short* p, float v) {
+  const __bf16 b = (__bf16)v;
+  *p = *reinterpret_cast<const unsigned short*>(&b);
+}
 __device__ __forceinline__ void load_nchw_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q, int P) {
   for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
     const int c = i / QPIX, p = i % QPIX;                    // 64 consecutive pixels of one channel: coalesced
@@ -182,9 +184,11 @@ __device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const
   }
 }
 
-// f8 [B][32*256] (c*256+p) -> out [B][256][32], plus per-channel {sum, sum^2} partials for bn8
-__global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out,
+// f8 [B][32*P] (c*P+p) -> out [B][P][32] (an ACTIVATION: stored as ACT), plus per-channel {sum, sum^2} partials for bn8
+template <typename ACT>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out_,
                                                                  float* __restrict__ partials, int B, int P) {
+  ACT* __restrict__ out = reinterpret_cast<ACT*>(out_);
   __shared__ float tile[32][QPIX + 1];
   __shared__ float red[8][64];
   const int t = threadIdx.x;
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
     __syncthreads();
     for (int i = t; i < 32 * QPIX; i += 256) {
       const int p = i >> 5, c = i & 31;     // c == t & 31 for every i of this thread
-      const float v = tile[c][p];
-      out[(size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i] = v;
+      const float v = ava_stored_bn<ACT>(tile[c][p]);     // statistics of what is stored
+      ava_store_bn<ACT>(out + (size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i, v);
       s1 += v;
       s2 = fmaf(v, v, s2);
     }
@@ -342,11 +346,13 @@ int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, 
 }
 
 // internal (model.hip)
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int* nparts, hipStream_t st) {
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int act_bf16, int* nparts,
+                           hipStream_t st) {
   if (P < QPIX || P % QPIX != 0) return AVA_EINVAL;
   const int nw = (P / QPIX) * B;
   const int grid = nw < 1024 ? nw : 1024;
-  hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel, dim3(grid), dim3(256), 0, st, in, out, partials, B, P);
+  if (act_bf16) hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, in, out, partials, B, P);
+  else hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel<float>, dim3(grid), dim3(256), 0, st, in, out, partials, B, P);
   AVA_CHECK_LAUNCH();
   *nparts = grid;
   return AVA_OK;

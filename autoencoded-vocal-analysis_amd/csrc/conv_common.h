@@ -26,6 +26,7 @@ struct ConvArgs {
   float prec;
   int tiles_y, tiles_x, ntiles;
   int part_rows; // rows of `partials` the caller sized ([ava_conv_grid]); rows beyond the launched grid are zero-filled
+  int act_bf16;  // 1: activations (layer inputs / saved outputs) are stored as bfloat16 (see ava_bf16 below)
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };
 
@@ -106,7 +107,37 @@ __device__ __forceinline__ avaf4 ava_load_f4_async(const float* p) {
 template <int N>
 __device__ __forceinline__ void ava_wait_vm0(avaf4 (&r)[N]) {}
 
-template <int CIN, int PRO, int R, int C, bool PLANES = false, int NT = 256>
+// ---- activation storage type (BASELINE configs[4]: "bf16 conv + fp32 ELBO") ------------------------------------
+// Activations between the convolutions (the tensors kept for the backward pass: the bulk of the step's HBM traffic)
+// can be stored as bfloat16: a kernel template parameter ACT selects how they are loaded / stored, everything is
+// computed in fp32 (matrix cores accumulate fp32; BatchNorm statistics, gradients, ELBO, Adam stay fp32).  A bf16
+// value is the upper half of its fp32 pattern; stores round to nearest even (v_cvt_pk_bf16_f32).
+typedef unsigned short ava_bf16;
+
+template <typename T> __device__ __forceinline__ avaf4 ava_ld4(const T* p);
+template <> __device__ __forceinline__ avaf4 ava_ld4<float>(const float* p) { return *reinterpret_cast<const avaf4*>(p); }
+template <> __device__ __forceinline__ avaf4 ava_ld4<ava_bf16>(const ava_bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return avaf4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xffff0000u)};
+}
+// the value as it will read back from storage of type T
+template <typename T> __device__ __forceinline__ float ava_stored(float v);
+template <> __device__ __forceinline__ float ava_stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float ava_stored<ava_bf16>(float v) { return (float)(__bf16)v; }
+template <typename T> __device__ __forceinline__ void ava_st4(T* p, avaf4 v);
+template <> __device__ __forceinline__ void ava_st4<float>(float* p, avaf4 v) { *reinterpret_cast<avaf4*>(p) = v; }
+template <> __device__ __forceinline__ void ava_st4<ava_bf16>(ava_bf16* p, avaf4 v) {
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  const bf4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  *reinterpret_cast<bf4*>(p) = b;
+}
+// typed view of an untyped (float*) argument: offsets are in ELEMENTS either way
+template <typename T> __device__ __forceinline__ const T* ava_as(const float* p) { return reinterpret_cast<const T*>(p); }
+template <typename T> __device__ __forceinline__ T* ava_as(float* p) { return reinterpret_cast<T*>(p); }
+
+// TIN / TIN2: storage types of `in` and of `in2` (the saved activation of prologue PRO_BWD)
+template <int CIN, int PRO, int R, int C, bool PLANES = false, int NT = 256, typename TIN = float, typename TIN2 = float>
 struct TileStager {
   static_assert(CIN % 4 == 0, "vector staging needs a multiple of 4 channels");
   static constexpr int Q = CIN / 4;
@@ -141,16 +172,16 @@ struct TileStager {
   __device__ __forceinline__ void load(const float* __restrict__ in, const float* __restrict__ in2, int b, int Hi,
                                        int Wi, int gy0, int gx0) {
     inb = 0u;
-    const float* __restrict__ base = in + (size_t)b * Hi * Wi * CIN;
-    const float* __restrict__ base2 = PRO == PRO_BWD ? in2 + (size_t)b * Hi * Wi * CIN : nullptr;
+    const TIN* __restrict__ base = ava_as<TIN>(in) + (size_t)b * Hi * Wi * CIN;
+    const TIN2* __restrict__ base2 = PRO == PRO_BWD ? ava_as<TIN2>(in2) + (size_t)b * Hi * Wi * CIN : nullptr;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int gy = gy0 + (rc[i] >> 16), gx = gx0 + (rc[i] & 0xffff);
       const bool ok = ((live >> i) & 1u) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
       const int cy = min(max(gy, 0), Hi - 1), cx = min(max(gx, 0), Wi - 1);
       const int off = (cy * Wi + cx) * CIN + q4[i];
-      v[i] = ava_load_f4_async(base + off);
-      if (PRO == PRO_BWD) v2[i] = ava_load_f4_async(base2 + off);
+      v[i] = ava_ld4<TIN>(base + off);
+      if (PRO == PRO_BWD) v2[i] = ava_ld4<TIN2>(base2 + off);
       inb |= ok ? (1u << i) : 0u;
     }
   }
@@ -229,6 +260,7 @@ struct WgradArgs {
   float* partials;     // [grid][9*CIN*COUT + COUT]
   int B, Hi, Wi, Ho, Wo;
   int tiles_y, tiles_x, ntiles;
+  int act_bf16;        // x and dy2 (activations) are stored as bfloat16
 };
 
 // all 14 weight-gradient reductions in one launch (model.hip)

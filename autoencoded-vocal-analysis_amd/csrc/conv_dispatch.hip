@@ -149,22 +149,24 @@ extern "C" int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode) {
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s);
+                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, ava_stream_t s);
 
 extern "C" int ava_conv3x3(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                            const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                            const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi,
                            int Cin, int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s) {
   return ava_conv3x3_ex(in, in2, pa, pb, pc, G, bias, out, out2, epi_x, epi_mean, epi_invstd, partials, B, Hi, Wi, Cin,
-                        Cout, mode, pro, epi, relu, prec, s);
+                        Cout, mode, pro, epi, relu, prec, 0, s);
 }
 
-// the same entry for the model driver (model.hip)
+// the same entry for the model driver (model.hip); act_bf16: the activations among the operands (a forward layer's
+// input and output, the saved activation in2, the raw x of the BatchNorm-backward sums) are stored as bfloat16
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s) {
+                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, ava_stream_t s) {
   ConvArgs a;
+  a.act_bf16 = act_bf16;
   a.in = in; a.in2 = in2; a.pa = pa; a.pb = pb; a.pc = pc; a.G = G; a.bias = bias; a.out = out; a.out2 = out2;
   a.epi_x = epi_x; a.epi_mean = epi_mean; a.epi_invstd = epi_invstd; a.partials = partials;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.prec = prec;
@@ -195,10 +197,19 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
 #endif
 }
 
+int ava_conv3x3_wgrad_ex(const float* x, const float* xa, const float* xb, const float* dy, const float* dy2,
+                         const float* da, const float* db_, const float* dc, float* partials, int B, int Hi, int Wi,
+                         int Cin, int Cout, int mode, int dy_pro, int act_bf16, ava_stream_t s);
 extern "C" int ava_conv3x3_wgrad(const float* x, const float* xa, const float* xb, const float* dy, const float* dy2,
                                  const float* da, const float* db_, const float* dc, float* partials, int B, int Hi,
                                  int Wi, int Cin, int Cout, int mode, int dy_pro, ava_stream_t s) {
+  return ava_conv3x3_wgrad_ex(x, xa, xb, dy, dy2, da, db_, dc, partials, B, Hi, Wi, Cin, Cout, mode, dy_pro, 0, s);
+}
+int ava_conv3x3_wgrad_ex(const float* x, const float* xa, const float* xb, const float* dy, const float* dy2,
+                         const float* da, const float* db_, const float* dc, float* partials, int B, int Hi, int Wi,
+                         int Cin, int Cout, int mode, int dy_pro, int act_bf16, ava_stream_t s) {
   WgradArgs a;
+  a.act_bf16 = act_bf16;
   a.x = x; a.xa = xa; a.xb = xb; a.dy = dy; a.dy2 = dy2; a.da = da; a.db = db_; a.dc = dc; a.partials = partials;
   a.B = B; a.Hi = Hi; a.Wi = Wi;
   a.Ho = mode == MODE_S1 ? Hi : (mode == MODE_DOWN ? Hi / 2 : Hi * 2);
@@ -226,8 +237,13 @@ extern "C" int ava_conv3x3_wgrad(const float* x, const float* xa, const float* x
 
 // partial rows ava_conv3x3_wgrad writes for this shape (<= ava_conv_wgrad_grid): the matrix-core kernels launch one
 // resident wave of workgroups, which depends on the kernel's occupancy
+int ava_conv_wgrad_rows_ex(int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro, int act_bf16);
 extern "C" int ava_conv_wgrad_rows(int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro) {
+  return ava_conv_wgrad_rows_ex(B, Hi, Wi, Cin, Cout, mode, dy_pro, 0);
+}
+int ava_conv_wgrad_rows_ex(int B, int Hi, int Wi, int Cin, int Cout, int mode, int dy_pro, int act_bf16) {
   WgradArgs a = {};
+  a.act_bf16 = act_bf16;
   a.B = B; a.Hi = Hi; a.Wi = Wi;
   a.Ho = mode == MODE_S1 ? Hi : (mode == MODE_DOWN ? Hi / 2 : Hi * 2);
   a.Wo = mode == MODE_S1 ? Wi : (mode == MODE_DOWN ? Wi / 2 : Wi * 2);

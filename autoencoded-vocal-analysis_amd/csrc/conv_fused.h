@@ -19,6 +19,7 @@ struct FusedArgs {
   float* wg_partials;    // [grid][9*CI*CO + CO]
   int B, Hi, Wi, Ho, Wo;
   int tiles_y, tiles_x, ntiles;
+  int act_bf16;          // x and dy2 (activations) are stored as bfloat16; dy and dx (gradients) are always fp32
   int sweep;             // thin kernels: workgroups sweep the tile list together instead of per-XCD chunks
 };
 

@@ -28,7 +28,8 @@ struct FGeom {
   static constexpr int OW = LMODE == MODE_DOWN ? 2 * TW : TW;
 };
 
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
+// ACT: storage type of the activations x (layer input) and dy2 (saved output); dy and dx are fp32 gradients.
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW, typename ACT>
 __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const FusedArgs a) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
     else if (LMODE == MODE_DOWN) { gy = y0; gx = x0; }
     else { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
   };
-  TileStager<CI, PRO_BN, XR, XC> sx;
-  TileStager<CO, DYPRO, DR, DC> sd;
+  TileStager<CI, PRO_BN, XR, XC, false, 256, ACT, ACT> sx;
+  TileStager<CO, DYPRO, DR, DC, false, 256, float, ACT> sd;
   sx.init();
   sd.init();
   auto prefetch = [&](int tl) {
@@ -138,14 +139,14 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
     int b, y0, x0;
     origin(tl, b, y0, x0);
     const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
-    const float* __restrict__ xb = a.x + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
+    const ACT* __restrict__ xb = ava_as<ACT>(a.x) + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int cb4 = 16 * mt + cq;
         // lanes whose 4-channel slot lies beyond CI re-read slot 0: stays in bounds
-        ex[gi * MT + mt] = *reinterpret_cast<const avaf4*>(
+        ex[gi * MT + mt] = ava_ld4<ACT>(
             xb + group_out(wave * GPW + gi) + (cb4 < CI ? lane_out + 16 * mt : lane_out - 4 * kg));
       }
   };
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
   for (int e = t; e < NW + CO; e += 256) prow[e] = wacc[e];
 }
 
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW, typename ACT>
 __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMODE == MODE_DOWN)) ? 2 : 4) void conv3x3_bwd_fused_ws_kernel(const FusedArgs a) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
@@ -357,8 +358,8 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
 
   if (stager) {
     // ---------------- staging waves (threadIdx.x 0..255: what TileStager assumes) ----------------
-    TileStager<CI, PRO_BN, XR, XC> sx;
-    TileStager<CO, DYPRO, DR, DC> sd;
+    TileStager<CI, PRO_BN, XR, XC, false, 256, ACT, ACT> sx;
+    TileStager<CO, DYPRO, DR, DC, false, 256, float, ACT> sd;
     sx.init();
     sd.init();
     auto prefetch = [&](int tl) {
@@ -443,14 +444,14 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
     int b, y0, x0;
     origin(tl, b, y0, x0);
     const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
-    const float* __restrict__ xb = a.x + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
+    const ACT* __restrict__ xb = ava_as<ACT>(a.x) + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int cb4 = 16 * mt + cq;
         // lanes whose 4-channel slot lies beyond CI re-read slot 0: stays in bounds
-        ex[gi * MT + mt] = *reinterpret_cast<const avaf4*>(
+        ex[gi * MT + mt] = ava_ld4<ACT>(
             xb + group_out(wave * GPW + gi) + (cb4 < CI ? lane_out + 16 * mt : lane_out - 4 * kg));
       }
   };
@@ -612,8 +613,8 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
 // ------------------------------------------------------------------------------------------------
 static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap);
 
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
-static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW, typename ACT>
+static int launch_fused_t(const FusedArgs& a, int grid, hipStream_t st) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int MT = (CI + 15) / 16;
   // wave-specialised variant (staging waves beside matrix-core waves, two tile buffers) where it wins: fused_defaults
@@ -627,10 +628,10 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   const size_t red_f = (size_t)9 * CI * CO + CO;
   const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
 #ifdef AVA_LAB
-  const void* kfn = ws ? reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>)
-                       : reinterpret_cast<const void*>(&conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>);
+  const void* kfn = ws ? reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>)
+                       : reinterpret_cast<const void*>(&conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>);
 #else
-  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>);
+  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>);
 #endif
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
@@ -645,12 +646,18 @@ static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
 #ifdef AVA_LAB
-  if (!ws) hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(256), lds, st, b);
+  if (!ws) hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>), dim3(grid), dim3(256), lds, st, b);
   else
 #endif
-  hipLaunchKernelGGL((conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW>), dim3(grid), dim3(512), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
+}
+
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
+static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
+  if (a.act_bf16) return launch_fused_t<CI, CO, LMODE, DYPRO, TW, TH, MINW, ava_bf16>(a, grid, st);
+  return launch_fused_t<CI, CO, LMODE, DYPRO, TW, TH, MINW, float>(a, grid, st);
 }
 
 // shapes with a fused instantiation: (cin, cout, mode, variant) -> low-resolution tile, occupancy hint.
@@ -763,6 +770,7 @@ extern "C" int ava_conv3x3_bwd_fused(const float* x, const float* xa, const floa
   FusedArgs a = {};
   a.x = x; a.xa = xa; a.xb = xb; a.dy = dy; a.dy2 = dy2; a.da = da; a.db = db; a.dc = dc; a.Gb = Gb; a.dx = dx;
   a.mean = mean; a.invstd = invstd; a.bn_partials = bn_partials; a.wg_partials = wg_partials;
+  a.act_bf16 = 0;
   a.B = B; a.Hi = Hi; a.Wi = Wi;
   a.Ho = mode == MODE_S1 ? Hi : (mode == MODE_DOWN ? Hi / 2 : Hi * 2);
   a.Wo = mode == MODE_S1 ? Wi : (mode == MODE_DOWN ? Wi / 2 : Wi * 2);

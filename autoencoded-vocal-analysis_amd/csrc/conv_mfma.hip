@@ -19,8 +19,11 @@
 // MSPLIT (layers with two cout tiles): waves 0,2 compute cout tile 0 and waves 1,3 tile 1, each for half of the pixel
 // groups -- half the weight registers per wave (112 -> 56 for 24 -> 24 channels), so two workgroups fit on a CU.
 // PAIR (stride 1, 8 output channels): two output rows share one MFMA tile (PairFrag) -- a third fewer MFMAs.
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR>
+// ACT: storage type of the activations read (forward input / saved activation in2 / raw x of EPI_BWD).  This kernel's
+// OUTPUT is always fp32: in the library it only runs conv7's forward, whose output feeds the fully connected layers.
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR, typename ACT>
 __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(const ConvArgs a) {
+  using TIN = typename std::conditional<PRO == PRO_BN, ACT, float>::type;
   static_assert(!PAIR || (MODE == MODE_S1 && COUT == 8 && !MSPLIT && TH % 2 == 0), "PAIR: stride 1, 8 output channels");
   using G = Geom<MODE, TW, TH>;
   constexpr int IR = G::IR, IC = G::IC;
@@ -82,17 +85,17 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   };
   avaf4 exn[EPI == EPI_BWD ? GPW * MT : 1];
   auto load_ex = [&](int b, int oy0, int ox0) {
-    const float* __restrict__ xb = a.epi_x + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * COUT;
+    const ACT* __restrict__ xb = ava_as<ACT>(a.epi_x) + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * COUT;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int cb = 16 * (mtb + mt) + cq;
         // lanes whose 4-channel slot lies beyond COUT (COUT = 8 or 24) re-read slot 0: stays in bounds
-        exn[gi * MT + mt] = ava_load_f4_async(xb + group_out(group_of(gi)) + (cb < COUT ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
+        exn[gi * MT + mt] = ava_ld4<ACT>(xb + group_out(group_of(gi)) + (cb < COUT ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
       }
   };
-  TileStager<CIN, PRO, IR, IC> stg;
+  TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT> stg;
   stg.init();
   TileWalk walk(a.ntiles);
   if (walk.valid()) {
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
-static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, typename ACT>
+static int launch_mfma_t(const ConvArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   constexpr int MT = (COUT + 15) / 16;
   constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // the register-bound shapes
@@ -252,7 +255,7 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   const size_t lds = (size_t)(G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
@@ -262,14 +265,24 @@ static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   // one resident wave of workgroups; the partial rows of the workgroups not launched are zero-filled by the kernel
-  static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>, lds);
+  static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>, lds);
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
   if (grid > resident) grid = resident;
   { const char* e = ava_env("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>), dim3(grid), dim3(256), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
+}
+
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
+static int launch_mfma(const ConvArgs& a, int grid, hipStream_t st) {
+  if (a.act_bf16) {
+    // bf16 activations: this kernel writes fp32, so it may only stand in where the consumer reads fp32 (conv7)
+    if (EPI == EPI_FWD && a.out2 == nullptr) return AVA_EINVAL;
+    return launch_mfma_t<CIN, COUT, MODE, PRO, EPI, TW, TH, ava_bf16>(a, grid, st);
+  }
+  return launch_mfma_t<CIN, COUT, MODE, PRO, EPI, TW, TH, float>(a, grid, st);
 }
 
 #ifdef AVA_LAB
@@ -336,7 +349,7 @@ int ava_conv3x3_mfma(const ConvArgs& a, int grid, int Cin, int Cout, int mode, i
 // and the workgroup writes one partial row [9*CIN*COUT + COUT] (same format as the VALU kernel).
 // The bias gradient is the column sum of the B fragments (one VALU add per LDS read).
 // ================================================================================================
-template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH, typename ACT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const WgradArgs a) {
   using G = Geom<MODE, TW, TH>;
   constexpr int IR = G::IR, IC = G::IC;
@@ -378,8 +391,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const WgradArgs
     else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
-  TileStager<CIN, PRO_BN, IR, IC> sx;
-  TileStager<COUT, DYPRO, TH, TW> sd;
+  TileStager<CIN, PRO_BN, IR, IC, false, 256, ACT, ACT> sx;       // x: activation
+  TileStager<COUT, DYPRO, TH, TW, false, 256, float, ACT> sd;      // dy: fp32 gradient, dy2: saved activation
   sx.init();
   sd.init();
   TileWalk walk(a.ntiles);
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const WgradArgs
   for (int e = t; e < NW + COUT; e += 256) prow[e] = wacc[e];
 }
 
-template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH, typename ACT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArgs a) {
   using G = Geom<MODE, TW, TH>;
   constexpr int IR = G::IR, IC = G::IC;
@@ -509,8 +522,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArg
     else if (MODE == MODE_DOWN) { gy0 = 2 * oy0 - 1; gx0 = 2 * ox0 - 1; }
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
-  TileStager<CIN, PRO_BN, IR, IC> sx;
-  TileStager<COUT, DYPRO, TH, TW> sd;
+  TileStager<CIN, PRO_BN, IR, IC, false, 256, ACT, ACT> sx;       // x: activation
+  TileStager<COUT, DYPRO, TH, TW, false, 256, float, ACT> sd;      // dy: fp32 gradient, dy2: saved activation
   sx.init();
   sd.init();
   TileWalk walk(a.ntiles);
@@ -596,13 +609,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArg
   if (t < COUT) prow[NW + t] = (wacc[NW + t] + wacc[NW + COUT + t]) + (wacc[NW + 2 * COUT + t] + wacc[NW + 3 * COUT + t]);
 }
 
-template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
-static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH, typename ACT>
+static int launch_wgrad_mfma_t(const WgradArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   // layers with many (tap, cin) rows deal the M tiles out to the waves (fewer registers, no cross-wave reduction)
   constexpr bool SPLIT = CIN >= 24 && COUT > 16;   // measured: 24->24, 24->32, 32->24 gain 10-55 %, 16-channel sides lose
-  const auto kernel = SPLIT ? &conv3x3_wgrad_split_kernel<CIN, COUT, MODE, DYPRO, TW, TH>
-                            : &conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH>;
+  const auto kernel = SPLIT ? &conv3x3_wgrad_split_kernel<CIN, COUT, MODE, DYPRO, TW, TH, ACT>
+                            : &conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH, ACT>;
   const size_t tiles_f = (size_t)G::IR * G::IC * CIN + TH * TW * COUT + 16 + 192;
   const size_t red_f = (size_t)9 * CIN * COUT + 4 * COUT;
   const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
@@ -625,6 +638,12 @@ static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
+}
+
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>
+static int launch_wgrad_mfma(const WgradArgs& a, int grid, hipStream_t st) {
+  if (a.act_bf16) return launch_wgrad_mfma_t<CIN, COUT, MODE, DYPRO, TW, TH, ava_bf16>(a, grid, st);
+  return launch_wgrad_mfma_t<CIN, COUT, MODE, DYPRO, TW, TH, float>(a, grid, st);
 }
 
 int ava_conv3x3_wgrad_mfma(const WgradArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {

@@ -16,6 +16,7 @@
 // a thread owns a vertical strip of 4 pixels, the 8-channel window is staged in LDS with the prologue applied) remain
 // as alternatives behind environment switches (tools/README.md) and for the shapes the tests exercise through
 // ava_conv3x3 / ava_conv3x3_wgrad.  Same ConvArgs / WgradArgs / partial-row conventions as conv.hip.
+#include <type_traits>
 #include "conv_common.h"
 #include "conv_fused.h"
 
@@ -120,8 +121,11 @@ __device__ __forceinline__ void thin_stage1(float* __restrict__ lds, const float
 // lines); with one thread per pixel and two 16-byte stores per pixel each instruction wrote every other 16-byte
 // slot and the layer ran at 3.8 TB/s of a possible ~5.  Weights depend on h, so they live in vector registers
 // (36 per thread) as channel pairs for v_pk_fma_f32.
-template <int W, int PRO, int EPI>
+// ACT: storage type of the 8-channel ACTIVATION this launch touches (EPI_FWD: the output; EPI_BWD: epi_x); the
+// 8-channel output of the data-gradient forms (EPI_BWD / EPI_NONE) is an fp32 gradient.
+template <int W, int PRO, int EPI, typename ACT = float>
 __global__ __launch_bounds__(2 * W) void thin_1to8_kernel(const ConvArgs a) {
+  using TOUT = typename std::conditional<EPI == EPI_FWD, ACT, float>::type;
   __shared__ float tile[THIN_IR * THIN_IC];
   __shared__ float red[THIN_NW][2][8];
   const int t = threadIdx.x, h = t & 1, x = t >> 1, lane = t & 63, wave = t >> 6;
@@ -182,18 +186,20 @@ __global__ __launch_bounds__(2 * W) void thin_1to8_kernel(const ConvArgs a) {
       if (EPI == EPI_FWD) {
         v0 += bias2[0]; v1 += bias2[1];
         if (relu) { v0 = avaf2{fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)}; v1 = avaf2{fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)}; }
+        v0 = avaf2{ava_stored<TOUT>(v0[0]), ava_stored<TOUT>(v0[1])};          // statistics of what is stored
+        v1 = avaf2{ava_stored<TOUT>(v1[0]), ava_stored<TOUT>(v1[1])};
         s1[0] += v0; s1[1] += v1;
         s2[0] = __builtin_elementwise_fma(v0, v0, s2[0]);
         s2[1] = __builtin_elementwise_fma(v1, v1, s2[1]);
       } else if (EPI == EPI_BWD) {
-        const avaf4 xr = *reinterpret_cast<const avaf4*>(a.epi_x + off);
+        const avaf4 xr = ava_ld4<ACT>(ava_as<ACT>(a.epi_x) + off);
         const avaf2 xh0 = {(xr[0] - emean[0]) * einv[0], (xr[1] - emean[1]) * einv[1]};
         const avaf2 xh1 = {(xr[2] - emean[2]) * einv[2], (xr[3] - emean[3]) * einv[3]};
         s1[0] += v0; s1[1] += v1;
         s2[0] = __builtin_elementwise_fma(v0, xh0, s2[0]);
         s2[1] = __builtin_elementwise_fma(v1, xh1, s2[1]);
       }
-      if (a.out != nullptr) *reinterpret_cast<avaf4*>(a.out + off) = avaf4{v0[0], v0[1], v1[0], v1[1]};
+      if (a.out != nullptr) ava_st4<TOUT>(ava_as<TOUT>(a.out) + off, avaf4{v0[0], v0[1], v1[0], v1[1]});
     }
   }
   if (EPI == EPI_NONE) return;
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
 //   y[r][x] = bias + sum_h sum_kx u_h[r][kx] at column x + kx - 1.
 // No staging role, three workgroups per CU resident, ten independent 16-byte loads per thread in flight; the
 // LDS-staged wave-specialised form kept one 41.6 KB window per workgroup in flight.
-template <int W, int PRO, int EPI>
+template <int W, int PRO, int EPI, typename ACT = float>
 __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs a) {
   static_assert(PRO == PRO_BN && EPI == EPI_SSE, "only convt7's forward uses this form");
   __shared__ float U[2][3][THIN_TH][THIN_IC];           // [half][kx][row][column + 1]; columns 0 and 129 stay zero
@@ -456,13 +462,13 @@ __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs 
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     // ---- phase 1: own pixel column, 10 rows ----
-    const float* __restrict__ xin = a.in + ((size_t)b * a.Hi * W + x) * 8 + 4 * h;
+    const ACT* __restrict__ xin = ava_as<ACT>(a.in) + ((size_t)b * a.Hi * W + x) * 8 + 4 * h;
     avaf2 xn[THIN_IR][2];
 #pragma unroll
     for (int j = 0; j < THIN_IR; ++j) {
       const int gy = oy0 - 1 + j;
       const bool ok = gy >= 0 && gy < a.Hi;             // wave-uniform
-      const avaf4 v = *reinterpret_cast<const avaf4*>(xin + (size_t)min(max(gy, 0), a.Hi - 1) * W * 8);
+      const avaf4 v = ava_ld4<ACT>(xin + (size_t)min(max(gy, 0), a.Hi - 1) * W * 8);
       xn[j][0] = ok ? avaf2{fmaf(ca[0], v[0], cb[0]), fmaf(ca[1], v[1], cb[1])} : avaf2{0.f, 0.f};
       xn[j][1] = ok ? avaf2{fmaf(ca[2], v[2], cb[2]), fmaf(ca[3], v[3], cb[3])} : avaf2{0.f, 0.f};
     }
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(2 * W, W == 128 ? 2 : 1) void thin_wgrad_8to1_kerne
 // ---------------------------------------------------------------------------------------------------------
 // Thread mapping: lane pair (2x, 2x+1) shares pixel column x; thread (x, h) owns channels 4h..4h+3 of the 8 rows
 // of the tile, so every g / y load is one 16-byte slot per lane, contiguous across the wave.
-template <int W, int DYPRO>
+template <int W, int DYPRO, typename ACT = float>
 __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];             // xhat0 window
   __shared__ float red[THIN_NW][2][44];                       // per wave, per channel half: dG' [9][4], T [4], border sums
@@ -702,7 +708,10 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
     for (int p = 0; p < THIN_TH; ++p) {
       const float4 g = *reinterpret_cast<const float4*>(a.dy + o0 + (size_t)p * W * 8);
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (DYPRO == PRO_BWD) y = *reinterpret_cast<const float4*>(a.dy2 + o0 + (size_t)p * W * 8);
+      if (DYPRO == PRO_BWD) {
+        const avaf4 yv = ava_ld4<ACT>(ava_as<ACT>(a.dy2) + o0 + (size_t)p * W * 8);
+        y = make_float4(yv[0], yv[1], yv[2], yv[3]);
+      }
       du[p][0] = prologue<DYPRO>(g.x, y.x, da[0], db[0], dc[0]);
       du[p][1] = prologue<DYPRO>(g.y, y.y, da[1], db[1], dc[1]);
       du[p][2] = prologue<DYPRO>(g.z, y.z, da[2], db[2], dc[2]);
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
 // the tile, exactly like thin_bwd_fused_1to8_kernel), and only the 1-channel dU window goes through LDS (5 KB).
 // The LDS-staged form keeps one 41.6 KB window per workgroup in flight and runs at 2.7 TB/s; this one has no staging
 // role at all, more resident workgroups and eight independent 16-byte loads per thread in flight.
-template <int W, int DYPRO>
+template <int W, int DYPRO, typename ACT = float>
 __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(const FusedArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];             // dU window (prologue applied, zero outside the image)
   __shared__ float red[THIN_NW][2][36];                       // per wave, per channel half: dG' [9][4]
@@ -983,7 +992,7 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(con
     avaf2 xh[THIN_TH][2];
 #pragma unroll
     for (int r = 0; r < THIN_TH; ++r) {
-      const avaf4 v = *reinterpret_cast<const avaf4*>(a.x + o0 + (size_t)r * W * 8);
+      const avaf4 v = ava_ld4<ACT>(ava_as<ACT>(a.x) + o0 + (size_t)r * W * 8);
       xh[r][0] = avaf2{fmaf(ha[0], v[0], hb[0]), fmaf(ha[1], v[1], hb[1])};
       xh[r][1] = avaf2{fmaf(ha[2], v[2], hb[2]), fmaf(ha[3], v[3], hb[3])};
     }
@@ -1088,6 +1097,7 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(con
 // G[ky][kx] . x_n(r + (ky == 0), c + (kx == 0));  every store instruction writes 1 KB of full lines.
 // ---------------------------------------------------------------------------------------------------------
 #define UP88_WSTRIDE 49     // float4 per (px, h) weight set: 48 used, padded so the four sets start in different banks
+template <typename ACT>
 __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
   __shared__ __align__(16) float wt[4 * UP88_WSTRIDE * 4];   // [px][h][ky][slot][ci] x 4 output channels
   __shared__ float red[4][2][8];
@@ -1123,8 +1133,8 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
       for (int j = 0; j < 5; ++j) {
         const int gy = r0 + j;
         const bool ok = colok && gy < a.Hi;
-        const float* __restrict__ pp = a.in + (((size_t)b * a.Hi + min(gy, a.Hi - 1)) * a.Wi + min(c + slot, a.Wi - 1)) * 8;
-        const avaf4 v0 = *reinterpret_cast<const avaf4*>(pp), v1 = *reinterpret_cast<const avaf4*>(pp + 4);
+        const ACT* __restrict__ pp = ava_as<ACT>(a.in) + (((size_t)b * a.Hi + min(gy, a.Hi - 1)) * a.Wi + min(c + slot, a.Wi - 1)) * 8;
+        const avaf4 v0 = ava_ld4<ACT>(pp), v1 = ava_ld4<ACT>(pp + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xn[j][e] = ok ? fmaf(sca[e], v0[e], shf[e]) : 0.f;
@@ -1157,10 +1167,12 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
       avaf2 v0 = acc[j][0] + bias2[0], v1 = acc[j][1] + bias2[1];
       v0 = avaf2{fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)};
       v1 = avaf2{fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)};
+      v0 = avaf2{ava_stored<ACT>(v0[0]), ava_stored<ACT>(v0[1])};               // statistics of what is stored
+      v1 = avaf2{ava_stored<ACT>(v1[0]), ava_stored<ACT>(v1[1])};
       s1[0] += v0; s1[1] += v1;
       s2[0] = __builtin_elementwise_fma(v0, v0, s2[0]);
       s2[1] = __builtin_elementwise_fma(v1, v1, s2[1]);
-      *reinterpret_cast<avaf4*>(a.out + o0 + (size_t)j * a.Wo * 8) = avaf4{v0[0], v0[1], v1[0], v1[1]};
+      ava_st4<ACT>(ava_as<ACT>(a.out) + o0 + (size_t)j * a.Wo * 8, avaf4{v0[0], v0[1], v1[0], v1[1]});
     }
   }
   // ---- per-channel sums: lanes of equal parity hold the same 4 channels; waves, then workgroup, fixed order ----
@@ -1190,11 +1202,12 @@ int ava_conv3x3_up88_direct(const ConvArgs& a0, int grid, int Cin, int Cout, int
   ConvArgs a = a0;
   a.ntiles = a.B * (a.Ho / 8);
   a.part_rows = grid;
-  static const int resident = ava_resident_grid(&up88_direct_kernel, 0);
+  static const int resident = ava_resident_grid(&up88_direct_kernel<float>, 0);
   int g = grid < resident ? grid : resident;
   { const char* e = ava_env("AVA_UP88_GRID"); if (e && atoi(e) >= 8 && atoi(e) < g) g = atoi(e); }
   if (g > a.ntiles) g = a.ntiles;
-  hipLaunchKernelGGL(up88_direct_kernel, dim3(g), dim3(256), 0, st, a);
+  if (a.act_bf16) hipLaunchKernelGGL(up88_direct_kernel<ava_bf16>, dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(up88_direct_kernel<float>, dim3(g), dim3(256), 0, st, a);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
@@ -1258,8 +1271,9 @@ static int thin_bwd_fused_launch_w(const FusedArgs& a0, int grid, int Cin, int d
   const dim3 block(2 * W);
   if (Cin == 1) {
     if (a.dx != nullptr) return AVA_EINVAL;              // this layer's data gradient is never formed
-    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
-    else hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);
+    if (dy_pro == PRO_BWD && a.act_bf16) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD, ava_bf16>), dim3(grid), block, 0, st, a);
+    else if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
+    else hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);      // no activation read
     AVA_CHECK_LAUNCH();
     return AVA_OK;
   }
@@ -1300,8 +1314,13 @@ static int thin_bwd_fused_launch_w(const FusedArgs& a0, int grid, int Cin, int d
     }
   }
 #endif
-  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
-  else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);
+  if (a.act_bf16) {
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_BWD, ava_bf16>), dim3(grid), block, 0, st, a);
+    else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_ID, ava_bf16>), dim3(grid), block, 0, st, a);
+  } else {
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
+    else hipLaunchKernelGGL((thin_wgrad_stats_8to1_direct_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);
+  }
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
@@ -1335,7 +1354,9 @@ static int conv3x3_thin_w(const ConvArgs& a0, int grid, int Cin, int Cout, int p
       static const int res = thin_resident(&thin_1to8_kernel<W, PRO_BN, EPI_FWD>, W, 0);
       if (grid > res) grid = res;
     }
-    if (pro == PRO_BN && epi == EPI_FWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BN, EPI_FWD>), dim3(grid), block, 0, st, a);
+    if (a.act_bf16 && !(pro == PRO_BN && epi == EPI_FWD)) return AVA_EINVAL;   // bf16 activations: only the model's launches
+    if (pro == PRO_BN && epi == EPI_FWD && a.act_bf16) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BN, EPI_FWD, ava_bf16>), dim3(grid), block, 0, st, a);
+    else if (pro == PRO_BN && epi == EPI_FWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BN, EPI_FWD>), dim3(grid), block, 0, st, a);
     else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_ID, EPI_BWD>), dim3(grid), block, 0, st, a);
     else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BWD, EPI_BWD>), dim3(grid), block, 0, st, a);
     else return AVA_EINVAL;
@@ -1373,8 +1394,10 @@ static int conv3x3_thin_w(const ConvArgs& a0, int grid, int Cin, int Cout, int p
       if (g > 512) g = 512;                               // in-step A/B: 512 / 768 / 1023 workgroups -> 34.1 / 34.7 / 37.0 us
       { const char* e = ava_env("AVA_THIN_FWD_GRID"); if (e && atoi(e) >= 8 && atoi(e) < a.part_rows) g = atoi(e); }
       if (g > a.ntiles) g = a.ntiles;
-      hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE>), dim3(g), block, 0, st, a);
+      if (a.act_bf16) hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE, ava_bf16>), dim3(g), block, 0, st, a);
+      else hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE>), dim3(g), block, 0, st, a);
     }
+    else if (a.act_bf16) return AVA_EINVAL;
     else if (pro == PRO_BWD && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<W, PRO_BWD, EPI_BWD>), dim3(grid), block, kThin8Lds, st, a);
     else if (pro == PRO_ID && epi == EPI_BWD) hipLaunchKernelGGL((thin_8to1_kernel<W, PRO_ID, EPI_BWD>), dim3(grid), block, kThin8Lds, st, a);
     else return AVA_EINVAL;
@@ -1396,6 +1419,7 @@ static int conv3x3_wgrad_thin_w(const WgradArgs& a0, int grid, int Cin, int Cout
   const size_t kThin8Lds = (size_t)(THIN_IR * THIN_IC * 8 + 96 + 8) * sizeof(float);
   const dim3 block(2 * W);
   WgradArgs a = a0;
+  if (a.act_bf16) return AVA_EINVAL;                     // per-op kernels: fp32 activations only
   a.ntiles = a.B * (a.Ho / THIN_TH);
   if (Cin == 1 && Cout == 8) {
     if (W == 256 && grid > 256) grid = 256;              // 200-register kernel: one 512-thread workgroup per CU

@@ -9,9 +9,14 @@
 #include <type_traits>
 #include "conv_mfma.h"
 
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR>
+// ACT: storage type of the activations this launch touches -- the input of a forward layer (PRO_BN), the saved
+// activation in2 of the ReLU/BatchNorm-backward prologue (PRO_BWD), the raw x of the BatchNorm-backward sums (EPI_BWD)
+// and the output of a forward layer (EPI_FWD).  Gradients (PRO_BWD / PRO_ID inputs, EPI_BWD outputs) are always fp32.
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR, typename ACT>
 __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) {
   using G = Geom<MODE, TW, TH>;
+  using TIN = typename std::conditional<PRO == PRO_BN, ACT, float>::type;
+  using TOUT = typename std::conditional<EPI == EPI_FWD, ACT, float>::type;
   constexpr int IR = G::IR, IC = G::IC;
   constexpr int MTA = (COUT + 15) / 16;             // cout tiles of the layer
   constexpr int MT = MSPLIT ? 1 : MTA;              // cout tiles of one matrix-core wave (see conv3x3_mfma_kernel)
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
 
   if (stager) {
     // ---------------- staging waves (threadIdx.x 0..255, exactly what TileStager assumes) ----------------
-    TileStager<CIN, PRO, IR, IC> stg;
+    TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT> stg;
     stg.init();
     int b, oy0, ox0, gy0, gx0;
     if (walk.valid()) {
@@ -120,13 +125,13 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   auto load_ex = [&](int tl) {
     int b, oy0, ox0, gy0, gx0;
     origin(tl, b, oy0, ox0, gy0, gx0);
-    const float* __restrict__ xb = a.epi_x + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * COUT;
+    const ACT* __restrict__ xb = ava_as<ACT>(a.epi_x) + (((size_t)b * a.Ho + oy0) * a.Wo + ox0) * COUT;
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int cb = 16 * (mtb + mt) + cq;
-        exn[gi * MT + mt] = *reinterpret_cast<const avaf4*>(
+        exn[gi * MT + mt] = ava_ld4<ACT>(
             xb + group_out(group_of(gi)) + (cb < COUT ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
       }
   };
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     origin(walk.cur, b, oy0, ox0, gy0, gx0);
     const float* tile = tile0 + (it & 1) * TILE_F;
     const size_t tile_pix = ((size_t)b * a.Ho + oy0) * a.Wo + ox0;
-    float* __restrict__ obase = a.out != nullptr ? a.out + tile_pix * COUT : nullptr;
+    TOUT* __restrict__ obase = a.out != nullptr ? ava_as<TOUT>(a.out) + tile_pix * COUT : nullptr;
     avaf4 ex[GPW * MT];
     if (EPI == EPI_BWD) {
 #pragma unroll
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
           if (EPI == EPI_FWD) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float x = fmaxf(v[r] + bias[mt][r], 0.f);
+              const float x = ava_stored<TOUT>(fmaxf(v[r] + bias[mt][r], 0.f));   // statistics of what is stored
               v[r] = x;
               s1[mt][r] += x;
               s2[mt][r] = fmaf(x, x, s2[mt][r]);
@@ -188,8 +193,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
               s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);      // raw x: centred after the loop
             }
           }
-          if (obase != nullptr)
-            *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+          if (obase != nullptr) ava_st4<TOUT>(obase + gout + 16 * (mtb + mt), avaf4{v[0], v[1], v[2], v[3]});
         }
       }
     }
@@ -233,8 +237,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   __syncthreads();
 }
 
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
-int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, typename ACT>
+int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   constexpr int MT = (COUT + 15) / 16;
   constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // same rules as launch_mfma
@@ -242,7 +246,7 @@ int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
   const size_t lds = (size_t)(2 * G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
@@ -254,16 +258,22 @@ int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
   int per_cu = 1;
   static int resident = 0;
   if (resident == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     resident = per_cu * 256;
   }
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
   if (grid > resident) grid = resident;
   { const char* e = ava_env("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
-  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR>), dim3(grid), dim3(512), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
+}
+
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
+int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
+  if (a.act_bf16) return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, ava_bf16>(a, grid, st);
+  return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, float>(a, grid, st);
 }
 
 template <int CIN, int COUT, int MODE, int TW, int TH>

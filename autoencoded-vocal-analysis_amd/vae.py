@@ -80,12 +80,18 @@ class VAE(nn.Module):
     """Variational Autoencoder for single-channel spectrograms, 128x128 unless ``x_shape`` says otherwise
     (reference: ``ava/models/vae.py:40-122``)."""
 
-    def __init__(self, save_dir='', lr=1e-3, z_dim=32, model_precision=10.0, device_name="auto", *, x_shape=X_SHAPE):
+    def __init__(self, save_dir='', lr=1e-3, z_dim=32, model_precision=10.0, device_name="auto", *, x_shape=X_SHAPE,
+                 act_dtype="float32"):
         """Reference signature (vae.py:80-81) plus one keyword-only extension: ``x_shape`` -- the reference fixes the
         spectrogram size in the module constant ``X_SHAPE = (128, 128)`` and the literal 8192 (vae.py:33,142,153);
         here the layers scale with ``(H, W)`` (width 128 or 256, height a multiple of 128; BASELINE config 5 is
-        256 x 256) and ``fc1.in = fc8.out = 32 * H/8 * W/8``."""
+        256 x 256) and ``fc1.in = fc8.out = 32 * H/8 * W/8``; ``act_dtype`` -- ``"float32"`` (the reference) or
+        ``"bfloat16"``: the activations between the 14 conv layers are stored as bf16 (``ava_model_create_ex``), all
+        arithmetic, BatchNorm statistics, the ELBO and Adam stay fp32 (BASELINE config 5: "bf16 conv + fp32 ELBO")."""
         super(VAE, self).__init__()
+        if act_dtype not in ("float32", "bfloat16"):
+            raise ValueError("act_dtype must be 'float32' or 'bfloat16'")
+        self.act_dtype = act_dtype
         self.x_shape = check_x_shape(x_shape)
         self.x_dim = self.x_shape[0] * self.x_shape[1]
         self.save_dir = save_dir
@@ -268,7 +274,8 @@ class VAE(nn.Module):
         nbytes = lib.ava_workspace_bytes_hw(self.z_dim, H, W, cap)
         self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         h = ctypes.c_void_p()
-        rc = lib.ava_model_create_hw(ctypes.byref(h), self.z_dim, H, W, cap, float(self.model_precision),
+        rc = lib.ava_model_create_ex(ctypes.byref(h), self.z_dim, H, W, 1 if self.act_dtype == "bfloat16" else 0, cap,
+                                     float(self.model_precision),
                                   self._params.data_ptr(), self._grads.data_ptr(), self._exp_avg.data_ptr(),
                                   self._exp_avg_sq.data_ptr(), self._bn_running.data_ptr(),
                                   self._bn_batches.data_ptr(), self._workspace.data_ptr(), nbytes)
@@ -400,6 +407,9 @@ class VAE(nn.Module):
         ev.record(torch.cuda.current_stream(self.device))
         self._status_poll = (self._status_host, ev)
 
+    # intermediates that are ACTIVATIONS between the convolutions: bfloat16 when act_dtype says so
+    _ACT_BUFFERS = frozenset(["y%d" % i for i in range(1, 7)] + ["d%d" % i for i in range(1, 7)] + ["f8t"])
+
     def _workspace_tensor(self, name, shape):
         n = ctypes.c_int64()
         p = _lib.load().ava_debug_buffer(self._handle, name.encode(), ctypes.byref(n))
@@ -407,6 +417,8 @@ class VAE(nn.Module):
             raise KeyError(name)
         off = p - self._workspace.data_ptr()
         numel = int(np.prod(shape))
+        if name in self._ACT_BUFFERS and self.act_dtype == "bfloat16":
+            return self._workspace[off:off + 2 * numel].view(torch.bfloat16).view(shape)
         return self._workspace[off:off + 4 * numel].view(torch.float32).view(shape)
 
     # ------------------------------------------------------------------ reference API

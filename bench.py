@@ -54,6 +54,8 @@ def parse(argv=None):
     ap.add_argument("--z-dim", type=int, default=32)
     ap.add_argument("--height", type=int, default=128, help="spectrogram height (reference: 128; configs[4]: 256)")
     ap.add_argument("--width", type=int, default=128, help="spectrogram width (128 or 256)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage of the activations between the conv layers (configs[4]: bf16); arithmetic is fp32 either way")
     ap.add_argument("--pool", type=int, default=8, help="distinct device-resident batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two HIP-event passes")
@@ -61,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
                     help="bounded: 1 warm-up + 4 timed steps (best thread count) and 1 + 2 (all cores), ~40 s; "
                          "full: BASELINE.md section 3's 3 warm-up + 10 timed steps for both")
+    ap.add_argument("--lr", type=float, default=1e-3, help=argparse.SUPPRESS)   # what-if probes of the lab build use 0
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)    # 'gloo': ranks share cuda:0 (tests on a 1-GPU box)
     ap.add_argument("--master-port", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -214,7 +217,8 @@ def main():
 
     torch.manual_seed(1234)
     H, W = args.height, args.width
-    model = VAE(z_dim=args.z_dim, device_name="cuda", x_shape=(H, W))
+    model = VAE(z_dim=args.z_dim, device_name="cuda", x_shape=(H, W), lr=args.lr,
+                act_dtype="bfloat16" if args.dtype == "bf16" else "float32")
     adist.broadcast_parameters(model)
     model.train()
 
@@ -300,7 +304,11 @@ def main():
         conv_ms = sum(ms2[i] for i, c in enumerate(CATS) if c in CONV_FAMILY) / args.steps
         coarse_sum_ms = sum(ms2[i] for i in range(len(CATS))) / args.steps
         coarse_events = sum(cnt2[i] for i in range(len(CATS))) // args.steps
-        a_conv = A_CONV_PER_PIXEL * H * W
+        # per layer forward reads in + writes out (activations), backward reads dOut + saved in and writes
+        # dIn; sum over layers of in = out = 35.25*H*W elements, conv1 forms no dIn.  Activations take s_a bytes (4, or
+        # 2 with bf16 storage), gradients always 4:  A_conv = H*W*(35.25*(3*s_a + 8) - 4)  (= 175.25*4*H*W in fp32)
+        s_a = 2 if args.dtype == "bf16" else 4
+        a_conv = H * W * (35.25 * (3 * s_a + 8) - 4)
         achieved = B * a_conv / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
         # HBM bytes of the same kernels from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
         # passes of this command; tools/pmc_traffic.py) -- counters cannot be read from inside this process, so the
@@ -342,7 +350,8 @@ def main():
     out = {"metric": "spectrograms/sec, VAE train step (fwd+bwd+Adam), %dx%d, batch %d per GPU" % (H, W, B),
            "value": round(value, 1), "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if args.dtype == "f32" else "f32 arithmetic, bf16 activation storage", "data": "synthetic",
            "config": {"workload": "configs[%d]: mouse_sylls VAE, batch %d synthetic %dx%d fp32 spectrograms per GPU, z=%d, "
                                   "train step = zero_grad+forward+backward%s+Adam, device-resident batches"
                                   % (4 if (H, W) != (128, 128) else (3 if world > 1 else (2 if args.z_dim == 64 else 1)), B, H, W, args.z_dim,

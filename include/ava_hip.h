@@ -62,6 +62,15 @@ size_t ava_workspace_bytes_hw(int z_dim, int H, int W, int max_batch);
 int ava_model_create_hw(ava_model** out, int z_dim, int H, int W, int max_batch, float model_precision,
                         float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                         float* bn_running, int64_t* bn_batches, void* workspace, size_t workspace_bytes);
+/* ... and with the storage type of the activations between the convolutions (BASELINE configs[4]: "bf16 conv + fp32
+ * ELBO"): act_dtype 0 = float32 (the reference), 1 = bfloat16 -- the thirteen tensors that connect the 14 conv layers
+ * (and are kept for the backward pass) are stored as bf16, rounded to nearest even by the producing kernel; every
+ * product still accumulates in fp32 on the matrix cores / packed FMAs, and BatchNorm statistics (taken of the
+ * rounded values), gradients, the fully connected layers, the ELBO and Adam (fp32 master weights) stay fp32.  Same
+ * workspace size as ava_workspace_bytes_hw. */
+int ava_model_create_ex(ava_model** out, int z_dim, int H, int W, int act_dtype, int max_batch, float model_precision,
+                        float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                        float* bn_running, int64_t* bn_batches, void* workspace, size_t workspace_bytes);
 
 /* ---- whole-path entry points ------------------------------------------------------------------ */
 /* VAE.forward (vae.py:273-327): encode -> rsample -> decode -> -ELBO.

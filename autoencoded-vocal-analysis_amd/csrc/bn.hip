@@ -253,6 +253,8 @@ __global__ __launch_bounds__(256) void relu_mask_to_nhwc_kernel(const float* __r
 }
 
 // dF8 (NCHW-flatten) = (f8 > 0) ? A[c]*g + Bc[c]*f8 + Cc[c] : 0 ; g = dXhat8 (NHWC)   (bn8 backward + ReLU of fc8)
+// ACT: bn8's input is the STORED copy of f8 (X[7]); with bf16 storage the Bc*x term must use the rounded value
+template <typename ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* __restrict__ g_nhwc,
                                                                    const float* __restrict__ f8_nchw,
                                                                    const float* __restrict__ A,
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* 
     for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
       const int c = i / QPIX, p = i % QPIX;
       const size_t o = (size_t)b * 32 * P + (size_t)c * P + q * QPIX + p;
-      const float f = f8_nchw[o];
+      const float f = ava_stored_bn<ACT>(f8_nchw[o]);
       out_nchw[o] = f > 0.f ? fmaf(A[c], tile[c][p], fmaf(Bc[c], f, Cc[c])) : 0.f;
     }
   }
@@ -369,8 +371,9 @@ int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, 
   return AVA_OK;
 }
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
-                             float* out, int B, int P, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P);
+                             float* out, int B, int P, int act_bf16, hipStream_t st) {
+  if (act_bf16) hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel<unsigned short>, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P);
+  else hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel<float>, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

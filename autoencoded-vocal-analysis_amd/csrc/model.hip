@@ -24,7 +24,7 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
 int ava_nhwc_to_nchw(const float* in, float* out, int B, int P, hipStream_t st);
 int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, int P, hipStream_t st);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
-                             float* out, int B, int P, hipStream_t st);
+                             float* out, int B, int P, int act_bf16, hipStream_t st);
 int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, float* A, float* Bc, float* Cc, int eval,
                            hipStream_t st);
@@ -836,7 +836,7 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
     float* t = gcur; gcur = gnext; gnext = t;
   }
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
-  TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, m->P8, st));
+  TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, m->P8, m->act_bf16, st));
   mark(m, CAT_LAYOUT, st);
   if (!whole) TRY(reduce_wgrads(m, 7, NCONV, B, st));
   TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), m->F, 1024, B, 0, 0, ACT_NONE, st));

@@ -116,24 +116,33 @@ def _relu(u, name, masks):
     return F.relu(u)
 
 
-def _store(h, act_dtype):
+def _store(h, act_dtype, name=None, stored=None):
     """Activation storage of this build's bf16 mode (BASELINE configs[4]; not in the reference): the tensors between the
     convolutions are STORED as bfloat16, rounded to nearest even by the producing kernel, and every consumer -- forward
     and backward -- reads the rounded values.  The rounding has no derivative of its own (straight-through): the
-    gradient with respect to the stored value is used as the gradient with respect to the unrounded one."""
+    gradient with respect to the stored value is used as the gradient with respect to the unrounded one.
+
+    ``stored`` (tests only): a dict name -> the tensor another evaluation actually stored; it REPLACES the rounding
+    (value = that tensor, gradient straight through).  Needed for a tight comparison: two evaluations of a
+    bf16-rounded network decorrelate within a few layers -- a perturbation eps flips the rounding of a fraction
+    eps/2^-8 of the elements by one bf16 ulp, which is a perturbation sqrt(eps * 2^-8) for the next layer, with fixed
+    point 2^-8 -- and then disagree on ~0.4 % of the ReLU masks, i.e. by 5-10 % on gradients (measured even between
+    an fp32 and an fp64 evaluation of the same rounded oracle, tools/bf16_probe.py)."""
+    if stored is not None and name in stored:
+        return h + (stored[name].to(h.dtype) - h).detach()
     if act_dtype is None:
         return h
     return h + (h.detach().to(act_dtype).to(h.dtype) - h.detach())
 
 
-def encode(P, x, running=None, train=True, record=None, masks=None, act_dtype=None):
+def encode(P, x, running=None, train=True, record=None, masks=None, act_dtype=None, stored=None):
     """vae.py:216-233.  ``x`` is ``[B,128,128]``; returns mu [B,z], u [B,z], d [B,z]."""
     h = x.unsqueeze(1)
     for conv, bn, stride in ENC:
         h = batchnorm(h, bn, P, running, train, record)
         h = _relu(F.conv2d(h, P[conv + ".weight"], P[conv + ".bias"], stride=stride, padding=1), conv, masks)
         if conv != "conv7":
-            h = _store(h, act_dtype)                             # conv7's output feeds the fp32 fully connected layers
+            h = _store(h, act_dtype, conv, stored)               # conv7's output feeds the fp32 fully connected layers
         if record is not None:
             record[conv + ".out"] = h
     h = h.reshape(h.shape[0], -1)                               # vae.py:224 (NCHW flatten; 8192 features at 128 x 128)
@@ -149,7 +158,7 @@ def encode(P, x, running=None, train=True, record=None, masks=None, act_dtype=No
     return mu, u, torch.exp(a)                                   # vae.py:232
 
 
-def decode(P, z, running=None, train=True, record=None, masks=None, x_shape=(128, 128), act_dtype=None):
+def decode(P, z, running=None, train=True, record=None, masks=None, x_shape=(128, 128), act_dtype=None, stored=None):
     """vae.py:258-270.  Returns x_rec ``[B, H*W]`` (``[B,16384]`` at the reference's X_SHAPE; ``x_shape`` other than
     (128, 128) is this build's size extension: fc8.out = 32 * H/8 * W/8)."""
     h = _relu(F.linear(z, P["fc5.weight"], P["fc5.bias"]), "fc5", masks)
@@ -159,13 +168,13 @@ def decode(P, z, running=None, train=True, record=None, masks=None, x_shape=(128
     if record is not None:
         record["fc8.out"] = h
     h = h.reshape(-1, 32, x_shape[0] // 8, x_shape[1] // 8)     # vae.py:262 (32 x 16 x 16 at 128 x 128)
-    h = _store(h, act_dtype)                                     # the NHWC copy convt1 reads
+    h = _store(h, act_dtype, "fc8", stored)                      # the NHWC copy convt1 reads
     for i, (convt, bn, stride) in enumerate(DEC):
         h = batchnorm(h, bn, P, running, train, record)
         h = F.conv_transpose2d(h, P[convt + ".weight"], P[convt + ".bias"], stride=stride,
                                padding=1, output_padding=stride - 1)
         if i < 6:
-            h = _store(_relu(h, convt, masks), act_dtype)        # no ReLU after convt7 (vae.py:269)
+            h = _store(_relu(h, convt, masks), act_dtype, convt, stored)   # no ReLU after convt7 (vae.py:269)
         if record is not None:
             record[convt + ".out"] = h
     return h.reshape(-1, x_shape[0] * x_shape[1])
@@ -204,14 +213,14 @@ def loss_terms(x, x_rec, z, u, d, model_precision=10.0):
 
 
 def forward(P, x, eps_w, eps_d, running=None, train=True, model_precision=10.0, record=None, masks=None,
-            act_dtype=None):
+            act_dtype=None, stored=None):
     """vae.py:311-327 with the two normal draws injected.  Raises ValueError
     like the reference's argument validation when ``d`` is not positive."""
-    mu, u, d = encode(P, x, running, train, record, masks, act_dtype)
+    mu, u, d = encode(P, x, running, train, record, masks, act_dtype, stored)
     if not bool((d > 0).all()):
         raise ValueError("cov_diag must be positive")
     z = rsample(mu, u, d, eps_w, eps_d)
-    x_rec = decode(P, z, running, train, record, masks, tuple(x.shape[1:]), act_dtype)
+    x_rec = decode(P, z, running, train, record, masks, tuple(x.shape[1:]), act_dtype, stored)
     loss, sum_z2, sse, sum_h = loss_terms(x, x_rec, z, u, d, model_precision)
     out = dict(loss=loss, sum_z2=sum_z2, sse=sse, sum_h=sum_h, mu=mu, u=u, d=d, z=z, x_rec=x_rec)
     return out

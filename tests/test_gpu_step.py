@@ -663,16 +663,38 @@ def test_size_extension_forward_backward_vs_oracle(shape, B, z):
         model.forward(torch.zeros(B, 128, 128) if shape != (128, 128) else torch.zeros(B, 64, 64))
 
 
+def _hip_stored(model, B):
+    """the activations the device stored between the conv layers, by oracle layer name, NCHW float64"""
+    H, W = model.x_shape
+    ch = {"conv1": (8, 1), "conv2": (8, 2), "conv3": (16, 2), "conv4": (16, 4), "conv5": (24, 4), "conv6": (24, 8),
+          "convt1": (24, 8), "convt2": (24, 4), "convt3": (16, 4), "convt4": (16, 2), "convt5": (8, 2), "convt6": (8, 1)}
+    st = {}
+    for i in range(1, 7):
+        c, d = ch["conv%d" % i]
+        st["conv%d" % i] = model._workspace_tensor("y%d" % i, (B, H // d, W // d, c)).permute(0, 3, 1, 2).double().cpu()
+        c, d = ch["convt%d" % i]
+        st["convt%d" % i] = model._workspace_tensor("d%d" % i, (B, H // d, W // d, c)).permute(0, 3, 1, 2).double().cpu()
+    st["fc8"] = model._workspace_tensor("f8t", (B, H // 8, W // 8, 32)).permute(0, 3, 1, 2).double().cpu()
+    return st
+
+
 @pytest.mark.parametrize("shape,B,z", [((128, 128), 8, 32), ((256, 256), 4, 128)], ids=["128x128", "config5_256x256_z128"])
 def test_bf16_activation_storage(shape, B, z):
     """BASELINE configs[4] "bf16 conv + fp32 ELBO": VAE(act_dtype='bfloat16') stores the thirteen activation tensors
     between the conv layers as bfloat16 (rounded to nearest even by the producing kernel); products accumulate in fp32
     and BatchNorm statistics / gradients / fully connected layers / ELBO / Adam stay fp32.
-    Oracle: the fp32 CPU oracle with the same storage rounding imposed (straight-through gradient, oracle._store).
-    Tolerances (stated): against that oracle -ELBO 1e-4 relative and every gradient tensor 5e-3 relative L2 (what is
-    left are elements whose fp32 value sits within rounding noise of a bf16 rounding boundary and lands on the other
-    neighbour: ~2e-4 of the elements, each off by one bf16 ulp = 0.4 %); against the UNROUNDED fp32 oracle the mode
-    itself costs 3e-3 on -ELBO and gradient directions stay within cosine 0.99."""
+
+    Tolerances (stated):
+    * tight: against the fp64 oracle evaluated ON THE TENSORS THE DEVICE STORED (oracle._store(stored=...): value =
+      the device's bf16 tensor, straight-through gradient) with the device's ReLU masks -- the exact derivative of the
+      function the device evaluated: -ELBO 1e-6 relative, every gradient tensor 1e-4;
+    * the stored tensors themselves: bfloat16, equal to round-to-nearest-even of the fp32 oracle's first activation
+      on > 99.8 % of the elements (the rest sit on a rounding boundary within fp32 noise);
+    * what the mode costs against the plain fp32 oracle: -ELBO within 1e-3 relative (measured 2e-5); gradients are
+      NOT comparable tensor by tensor -- any two evaluations of a bf16-rounded network decorrelate to one bf16 ulp
+      (0.4 %) per element within a few layers and then disagree on ~0.4 % of the ReLU masks (5-25 % per gradient
+      tensor, the same between an fp32 and an fp64 run of the rounded oracle: tools/bf16_probe.py) -- so only the
+      direction is held (cosine > 0.9 on every weight tensor) plus loss decrease under Adam."""
     from ava_amd.vae import VAE
     H, W = shape
     fp = syn.fixture_parameters(z, shape)
@@ -688,38 +710,38 @@ def test_bf16_activation_storage(shape, B, z):
     loss = model.forward(x)
     loss.backward()
     got = {n: p.grad.detach().cpu().double().numpy().ravel() for n, p in model.named_parameters()}
-    # the stored activations ARE bfloat16 and equal the rounded oracle activations almost everywhere
     y1 = model._workspace_tensor("y1", (B, H, W, 8))
     assert y1.dtype == torch.bfloat16
-    P = O.to_params(fp, requires_grad=True)
-    rec = {}
-    out = O.forward(P, x, torch.from_numpy(ew), torch.from_numpy(ed), None, True, record=rec, act_dtype=torch.bfloat16)
+    # ---- tight: fp64 oracle on the device's stored tensors and masks ----
+    P = O.to_params(fp, dtype=torch.float64, requires_grad=True)
+    out = O.forward(P, x.double(), torch.from_numpy(ew).double(), torch.from_numpy(ed).double(), None, True,
+                    masks=_hip_masks(model, B), stored=_hip_stored(model, B))
     out["loss"].backward()
-    want_y1 = rec["conv1.out"].detach().permute(0, 2, 3, 1)
-    mism = float((y1.float().cpu() != want_y1).float().mean())
-    assert mism < 2e-3, mism
-    assert rel(float(loss.item()), float(out["loss"].detach())) < 1e-4
+    assert rel(float(loss.item()), float(out["loss"].detach())) < 1e-6
+    cb = float(P["conv1.bias"].grad.norm())
     bad = {}
-    cb = float(P["conv1.bias"].grad.double().norm())
     for n, p in P.items():
-        r = p.grad.double().numpy().ravel()
+        r = p.grad.numpy().ravel()
         scale = max(np.linalg.norm(r), cb if n.split(".")[0] in ("conv1", "bn1") else 0.0, 1e-300)
         e = np.linalg.norm(got[n] - r) / scale
-        if e > 5e-3:
+        if e > 1e-4:
             bad[n] = e
     assert not bad, bad
-    # what the mode costs against plain fp32
+    # ---- the stored tensor is the rounded fp32 activation ----
     P32 = O.to_params(fp, requires_grad=True)
-    o32 = O.forward(P32, x, torch.from_numpy(ew), torch.from_numpy(ed), None, True)
+    rec = {}
+    o32 = O.forward(P32, x, torch.from_numpy(ew), torch.from_numpy(ed), None, True, record=rec)
     o32["loss"].backward()
-    assert rel(float(loss.item()), float(o32["loss"].detach())) < 3e-3
+    want_y1 = rec["conv1.out"].detach().permute(0, 2, 3, 1).bfloat16()
+    assert float((y1.cpu() != want_y1).float().mean()) < 2e-3
+    # ---- cost of the mode against plain fp32 ----
+    assert rel(float(loss.item()), float(o32["loss"].detach())) < 1e-3
     for n, p in P32.items():
-        r = p.grad.double().numpy().ravel()
-        if n.split(".")[0] in ("conv1", "bn1"):
-            continue
-        cos = float(np.dot(got[n], r) / max(np.linalg.norm(got[n]) * np.linalg.norm(r), 1e-300))
-        assert cos > 0.99, (n, cos)
-    # bitwise determinism and a few Adam steps
+        if n.endswith(".weight") and not n.startswith("bn"):
+            r = p.grad.double().numpy().ravel()
+            cos = float(np.dot(got[n], r) / max(np.linalg.norm(got[n]) * np.linalg.norm(r), 1e-300))
+            assert cos > 0.9, (n, cos)
+    # ---- bitwise determinism, a few Adam steps, encode ----
     g1 = model._grads.clone()
     model.optimizer.zero_grad()
     model.forward(x).backward()

@@ -1,0 +1,127 @@
+// BatchNorm sums accumulated INSIDE the producing kernel, finalised in the prologue of the consuming kernel:
+// removes the one-workgroup bn_finalize launches (5 us kernel + a dependent-launch boundary each, 28 per step) from
+// the step's critical path for the layer pairs whose kernels use it (model.hip: acc_pair_fwd / acc_pair_bwd).
+//
+// Determinism.  Every workgroup adds its fp32 partial sums with INTEGER atomics, so the total does not depend on the
+// order of arrival: a partial p is split exactly into three 32-bit limbs of the fixed-point number |p| * 2^48
+// (|p| < 2^48; bits below 2^-48 are truncated, a deterministic function of p) and the signed limbs are added to three
+// int64 counters -- 1024 workgroups cannot overflow them.  The reader recombines sum(limb_k) * 2^(32k - 48) in fp64.
+// Non-finite partials raise a flag word instead (the reader then yields NaN, as a sum containing them would).
+// Contention.  The counters of a slot are replicated over 8 shards (workgroup index mod 8): one shard takes at most
+// 1/8 of the arrivals; measured cost of 64 values x 3 limbs at the end of a 512-workgroup kernel: +1.1 us
+// (tools/lab/atomic_probe.hip; a single shard costs +9 us).
+#pragma once
+#include "common.h"
+
+#define AVA_ACC_SHARDS 8
+#define AVA_ACC_SHARD_LL 200            // per shard: [3 limbs][64 values] + flag word at 192 (+ padding)
+#define AVA_ACC_SLOT_LL (AVA_ACC_SHARDS * AVA_ACC_SHARD_LL)
+#define AVA_ACC_SLOTS 28                // BatchNorm l forward statistics: slot l; backward sums: slot 14 + l
+#define AVA_BN_EPS_D 1e-5
+#define AVA_BN_MOM_D 0.1
+
+// What the consumer needs to turn the accumulated sums of one BatchNorm layer into its prologue coefficients.
+struct BnFin {
+  const long long* acc;        // slot base; null: the launch reads ready-made coefficient arrays instead
+  const float* gamma;
+  const float* beta;           // forward only
+  const float* mean;           // backward: forward statistics of the layer (bn_save)
+  const float* invstd;
+  float* save;                 // forward: bn_save row [4][32] = mean, invstd, scale, shift   (published by workgroup 0)
+  float* running_mean;         // forward, training: momentum update by workgroup 0 (may be null)
+  float* running_var;
+  long long* num_batches;
+  float* dgamma;               // backward: gradient arena entries (published by workgroup 0)
+  float* dbeta;
+  float* abc;                  // backward: bn_bwd row [3][32] = A, Bc, Cc (published by workgroup 0)
+  double n;                    // elements per channel
+  int C;
+  int backward;                // 0: sums are {sum x, sum x^2}; 1: {sum g, sum g*xhat}
+  int eval;                    // backward of a forward that ran on running statistics: Bc = Cc = 0
+};
+
+#ifdef __HIPCC__
+// producer: add the workgroup's partial sum of value `idx` (0..63: [which][32 channels]) to the slot
+__device__ __forceinline__ void bn_acc_add(long long* slot, int idx, float p) {
+  long long* a = slot + (size_t)(blockIdx.x & (AVA_ACC_SHARDS - 1)) * AVA_ACC_SHARD_LL;
+  const double ad = fabs((double)p) * 0x1p48;                 // exact
+  if (!(ad < 0x1p95)) {                                       // NaN, Inf or |p| >= 2^47: poison the slot
+    atomicOr(reinterpret_cast<unsigned long long*>(a + 192), 1ull);
+    return;
+  }
+  const double l2 = floor(ad * 0x1p-64), r1 = ad - l2 * 0x1p64;
+  const double l1 = floor(r1 * 0x1p-32), l0 = floor(r1 - l1 * 0x1p32);
+  const long long sg = p < 0.f ? -1 : 1;
+  if (l0 != 0.0) atomicAdd(reinterpret_cast<unsigned long long*>(a + idx), (unsigned long long)(sg * (long long)l0));
+  if (l1 != 0.0) atomicAdd(reinterpret_cast<unsigned long long*>(a + 64 + idx), (unsigned long long)(sg * (long long)l1));
+  if (l2 != 0.0) atomicAdd(reinterpret_cast<unsigned long long*>(a + 128 + idx), (unsigned long long)(sg * (long long)l2));
+}
+
+// consumer: value `idx` of the slot (fixed shard order: deterministic); NaN when the slot is poisoned
+__device__ __forceinline__ double bn_acc_read(const long long* slot, int idx) {
+  double s = 0.0;
+  unsigned long long bad = 0;
+#pragma unroll
+  for (int sh = 0; sh < AVA_ACC_SHARDS; ++sh) {
+    const long long* a = slot + (size_t)sh * AVA_ACC_SHARD_LL;
+    // relaxed agent-scope loads: the counters were written by atomics of the PREVIOUS kernel (memory side)
+    const long long v0 = __hip_atomic_load(a + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long v1 = __hip_atomic_load(a + 64 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long v2 = __hip_atomic_load(a + 128 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bad |= (unsigned long long)__hip_atomic_load(a + 192, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s += ((double)v0 + (double)v1 * 0x1p32 + (double)v2 * 0x1p64) * 0x1p-48;
+  }
+  return bad ? __builtin_nan("") : s;
+}
+
+// Consumer prologue, called by ALL threads of the workgroup (>= 64 threads; contains barriers): fills coef[3][32]
+// (LDS) with {scale, shift, 0} (forward) or {A, Bc, Cc} (backward), zero beyond C, exactly as bn_finalize_kernel /
+// bn_finalize_bwd_kernel compute them; workgroup 0 also publishes what later kernels read from global memory.
+// `vals`: 64 doubles of LDS scratch.  Threads t0 .. t0+63 read the counters (pick a wave with nothing slow in flight:
+// a wave's loads return in order, so reads queued behind a tile prefetch would wait for it), t0 .. t0+31 finalise.
+__device__ __forceinline__ void bn_coef_from_acc(float* coef, double* vals, const BnFin& f, int t0 = 0) {
+  const int t = (int)threadIdx.x - t0;
+  if (t >= 0 && t < 64) vals[t] = ((t & 31) < f.C) ? bn_acc_read(f.acc, t) : 0.0;
+  __syncthreads();
+  if (t >= 0 && t < 32) {
+    const int c = t;
+    float k0 = 0.f, k1 = 0.f, k2 = 0.f;
+    if (c < f.C) {
+      const bool pub = blockIdx.x == 0;
+      if (!f.backward) {
+        const double mean = vals[c] / f.n;
+        double var = vals[32 + c] / f.n - mean * mean;          // biased variance
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean;
+        const float invstd = (float)(1.0 / sqrt(var + AVA_BN_EPS_D));
+        const float sc = f.gamma[c] * invstd;
+        k0 = sc;
+        k1 = f.beta[c] - meanf * sc;
+        if (pub) {
+          f.save[c] = meanf; f.save[32 + c] = invstd; f.save[64 + c] = k0; f.save[96 + c] = k1;
+          if (f.running_mean != nullptr) {
+            const double unb = f.n > 1.0 ? var * (f.n / (f.n - 1.0)) : var;
+            f.running_mean[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)f.running_mean[c] + AVA_BN_MOM_D * mean);
+            f.running_var[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)f.running_var[c] + AVA_BN_MOM_D * unb);
+          }
+        }
+      } else {
+        const double dB = vals[c], dG = vals[32 + c];
+        const double is = (double)f.invstd[c], gm = (double)f.gamma[c], mu = (double)f.mean[c];
+        const double a = gm * is;
+        const double b = f.eval ? 0.0 : -gm * is * is * dG / f.n;
+        k0 = (float)a;
+        k1 = (float)b;
+        k2 = f.eval ? 0.f : (float)(-a * dB / f.n - b * mu);
+        if (pub) {
+          f.dgamma[c] = (float)dG; f.dbeta[c] = (float)dB;
+          f.abc[c] = k0; f.abc[32 + c] = k1; f.abc[64 + c] = k2;
+        }
+      }
+    }
+    coef[c] = k0; coef[32 + c] = k1; coef[64 + c] = k2;
+    if (c == 0 && blockIdx.x == 0 && !f.backward && f.num_batches != nullptr) *f.num_batches += 1;
+  }
+  __syncthreads();
+}
+#endif

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "bn_fuse.h"
+#include "bn_acc.h"
 
 enum { MODE_S1 = 0, MODE_DOWN = 1, MODE_UP = 2 };
 enum { PRO_BN = 0, PRO_BWD = 1, PRO_ID = 2 };
@@ -27,6 +28,8 @@ struct ConvArgs {
   int tiles_y, tiles_x, ntiles;
   int part_rows; // rows of `partials` the caller sized ([ava_conv_grid]); rows beyond the launched grid are zero-filled
   int act_bf16;  // 1: activations (layer inputs / saved outputs) are stored as bfloat16 (see ava_bf16 below)
+  long long* acc_out;  // != null: the per-channel sums of the epilogue are accumulated here (bn_acc.h) instead of partial rows
+  BnFin fin;     // fin.acc != null: the prologue coefficients are derived from accumulated sums instead of pa / pb / pc
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };
 
@@ -246,6 +249,12 @@ struct TileWalk {
   __device__ __forceinline__ bool has_next() const { return cur + step < end; }
   __device__ __forceinline__ int next() const { return cur + step; }
   __device__ __forceinline__ void advance() { cur += step; }
+};
+
+// optional accumulator hook-up of one conv launch (model driver): see bn_acc.h
+struct ConvAcc {
+  long long* acc_out;    // producer side (null: partial rows)
+  BnFin fin;             // consumer side (fin.acc null: coefficient arrays)
 };
 
 struct WgradArgs {

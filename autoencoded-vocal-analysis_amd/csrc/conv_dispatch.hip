@@ -149,14 +149,14 @@ extern "C" int ava_conv_wgrad_grid(int B, int Ho, int Wo, int mode) {
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, ava_stream_t s);
+                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, const ConvAcc* acc, ava_stream_t s);
 
 extern "C" int ava_conv3x3(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                            const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                            const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi,
                            int Cin, int Cout, int mode, int pro, int epi, int relu, float prec, ava_stream_t s) {
   return ava_conv3x3_ex(in, in2, pa, pb, pc, G, bias, out, out2, epi_x, epi_mean, epi_invstd, partials, B, Hi, Wi, Cin,
-                        Cout, mode, pro, epi, relu, prec, 0, s);
+                        Cout, mode, pro, epi, relu, prec, 0, nullptr, s);
 }
 
 // the same entry for the model driver (model.hip); act_bf16: the activations among the operands (a forward layer's
@@ -164,9 +164,13 @@ extern "C" int ava_conv3x3(const float* in, const float* in2, const float* pa, c
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, ava_stream_t s) {
+                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, const ConvAcc* acc,
+                   ava_stream_t s) {
   ConvArgs a;
   a.act_bf16 = act_bf16;
+  a.acc_out = acc != nullptr ? acc->acc_out : nullptr;
+  if (acc != nullptr) a.fin = acc->fin;
+  else { a.fin = BnFin{}; a.fin.acc = nullptr; }
   a.in = in; a.in2 = in2; a.pa = pa; a.pb = pb; a.pc = pc; a.G = G; a.bias = bias; a.out = out; a.out2 = out2;
   a.epi_x = epi_x; a.epi_mean = epi_mean; a.epi_invstd = epi_invstd; a.partials = partials;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.relu = relu; a.prec = prec;

@@ -19,6 +19,8 @@ struct FusedArgs {
   float* wg_partials;    // [grid][9*CI*CO + CO]
   int B, Hi, Wi, Ho, Wo;
   int tiles_y, tiles_x, ntiles;
+  long long* acc_out;    // != null: sum dx, sum dx*xhat are accumulated here (bn_acc.h) instead of bn_partials rows
+  BnFin fin;             // fin.acc != null: da / db / dc are derived from the accumulated sums of the layer above
   int act_bf16;          // x and dy2 (activations) are stored as bfloat16; dy and dx (gradients) are always fp32
   int sweep;             // thin kernels: workgroups sweep the tile list together instead of per-XCD chunks
 };

@@ -327,13 +327,6 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   const bool stager = wave8 < 4;             // waves 0-3 stage tiles, waves 4-7 run the two matrix-core phases
   const int wave = wave8 & 3;
   const int n = lane & 15, kg = lane >> 4;
-  if (t < 96) {
-    const int which = t >> 5, c = t & 31;
-    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
-    const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
-    cx[t] = (sx != nullptr && c < CI) ? sx[c] : 0.f;
-    cd[t] = (sd != nullptr && c < CO) ? sd[c] : 0.f;
-  }
   if (t < 32) smem[(t >> 4) * BUF_F + XF + DR * DC * CO + (t & 15)] = 0.f;
 
   // tile -> image, low-resolution origin, window origins
@@ -354,24 +347,43 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
     else { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
   };
   TileWalk walk(a.ntiles);
+  TileStager<CI, PRO_BN, XR, XC, false, 256, ACT, ACT> sx;      // staging waves only (threadIdx.x 0..255)
+  TileStager<CO, DYPRO, DR, DC, false, 256, float, ACT> sd;
+  auto prefetch = [&](int tl) {
+    int b, y0, x0, gy, gx;
+    origin(tl, b, y0, x0);
+    x_origin(y0, x0, gy, gx);
+    sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy, gx);
+    d_origin(y0, x0, gy, gx);
+    sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
+  };
+  if (stager) {
+    sx.init();
+    sd.init();
+    if (walk.valid()) prefetch(walk.cur);    // tile 0 goes in flight BEFORE the coefficient prologue
+  }
+  __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
+  if (a.fin.acc != nullptr) {
+    // A, Bc, Cc of the BatchNorm above finalised here from the accumulated sums of the kernel that ran before
+    // (by the first matrix-core wave, under the staging waves' first tile load)
+    bn_coef_from_acc(cd, accvals, a.fin, 256);
+    if (t < 96) {
+      const int which = t >> 5, c = t & 31;
+      const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+      cx[t] = (sx != nullptr && c < CI) ? sx[c] : 0.f;
+    }
+  } else if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
+    cx[t] = (sx != nullptr && c < CI) ? sx[c] : 0.f;
+    cd[t] = (sd != nullptr && c < CO) ? sd[c] : 0.f;
+  }
   __syncthreads();                           // cx / cd / zero pads visible
 
   if (stager) {
-    // ---------------- staging waves (threadIdx.x 0..255: what TileStager assumes) ----------------
-    TileStager<CI, PRO_BN, XR, XC, false, 256, ACT, ACT> sx;
-    TileStager<CO, DYPRO, DR, DC, false, 256, float, ACT> sd;
-    sx.init();
-    sd.init();
-    auto prefetch = [&](int tl) {
-      int b, y0, x0, gy, gx;
-      origin(tl, b, y0, x0);
-      x_origin(y0, x0, gy, gx);
-      sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy, gx);
-      d_origin(y0, x0, gy, gx);
-      sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
-    };
+    // ---------------- staging waves ----------------
     if (walk.valid()) {
-      prefetch(walk.cur);
       sx.store(smem, cx);
       sd.store(smem + XF, cd);
       if (walk.has_next()) prefetch(walk.next());
@@ -579,8 +591,9 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   if (tc < 2 * CI) {
     const int which = tc / CI, ci = tc - which * CI;
     const int idx = which * 16 * MT + ci;
-    a.bn_partials[(size_t)blockIdx.x * 2 * CI + tc] =
-        (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]);
+    const float tot = (red[idx] + red[32 * MT + idx]) + (red[64 * MT + idx] + red[96 * MT + idx]);
+    if (a.acc_out != nullptr) bn_acc_add(a.acc_out, which * 32 + ci, tot);
+    else a.bn_partials[(size_t)blockIdx.x * 2 * CI + tc] = tot;
   }
   __syncthreads();
 
@@ -771,6 +784,8 @@ extern "C" int ava_conv3x3_bwd_fused(const float* x, const float* xa, const floa
   a.x = x; a.xa = xa; a.xb = xb; a.dy = dy; a.dy2 = dy2; a.da = da; a.db = db; a.dc = dc; a.Gb = Gb; a.dx = dx;
   a.mean = mean; a.invstd = invstd; a.bn_partials = bn_partials; a.wg_partials = wg_partials;
   a.act_bf16 = 0;
+  a.acc_out = nullptr;
+  a.fin = BnFin{};
   a.B = B; a.Hi = Hi; a.Wi = Wi;
   a.Ho = mode == MODE_S1 ? Hi : (mode == MODE_DOWN ? Hi / 2 : Hi * 2);
   a.Wo = mode == MODE_S1 ? Wi : (mode == MODE_DOWN ? Wi / 2 : Wi * 2);

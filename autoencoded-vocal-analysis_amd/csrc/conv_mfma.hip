@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   const int n = lane & 15, kg = lane >> 4;
   const int mtb = MSPLIT ? (wave & 1) : 0;  // first cout tile of this wave
   const int wp = wave >> 1;                 // MSPLIT: which half of the pixel groups
-  if (t < 96) {
+  __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
+  if (a.fin.acc != nullptr) {
+    bn_coef_from_acc(coef, accvals, a.fin);   // BatchNorm finalised here from the producer's accumulated sums
+  } else if (t < 96) {
     const int which = t >> 5, c = t & 31;
     const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
     coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
@@ -235,7 +238,11 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
       }
     }
   __syncthreads();
-  if (t < 2 * COUT && a.partials != nullptr) {
+  if (t < 2 * COUT && a.acc_out != nullptr) {
+    const int which = t / COUT, co = t - which * COUT;
+    const int idx = which * 16 * MTA + co;
+    bn_acc_add(a.acc_out, which * 32 + co, (red[idx] + red[32 * MTA + idx]) + (red[64 * MTA + idx] + red[96 * MTA + idx]));
+  } else if (t < 2 * COUT && a.partials != nullptr) {
     const int which = t / COUT, co = t - which * COUT;
     const int idx = which * 16 * MTA + co;
     a.partials[(size_t)blockIdx.x * 2 * COUT + t] =

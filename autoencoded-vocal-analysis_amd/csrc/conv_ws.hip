@@ -28,16 +28,12 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   float* tile0 = smem;                      // two tile buffers
   float* coef = smem + 2 * TILE_F;          // [3][32]
   float* red = coef + 96;                   // [4][2*16*MTA]
+  __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
 
   const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
   const bool stager = wave8 < 4;
   const int wave = wave8 & 3;
   const int n = lane & 15, kg = lane >> 4;
-  if (t < 96) {
-    const int which = t >> 5, c = t & 31;
-    const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
-    coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
-  }
   auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
     b = tl / (a.tiles_y * a.tiles_x);
     const int rem = tl - b * (a.tiles_y * a.tiles_x);
@@ -48,16 +44,37 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
   TileWalk walk(a.ntiles);
+  TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT> stg;       // staging waves only (threadIdx.x 0..255)
+  // stride-2 gathers hold the most staging registers: keeping their first tile in flight across the prologue raised
+  // conv2's forward from 70 to 112 VGPRs (3 -> 2 resident workgroups per CU, 42 -> 50 us); they load after it instead
+  constexpr bool HOIST = MODE != MODE_DOWN;
+  if (stager) {
+    stg.init();
+    if (HOIST && walk.valid()) {                                // tile 0 goes in flight BEFORE the coefficient prologue
+      int b, oy0, ox0, gy0, gx0;
+      origin(walk.cur, b, oy0, ox0, gy0, gx0);
+      stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+    }
+  }
+  if (a.fin.acc != nullptr) {
+    // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h), by the first matrix-core wave, under
+    // the staging waves' first tile load
+    bn_coef_from_acc(coef, accvals, a.fin, 256);
+  } else if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
+    coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
+  }
   __syncthreads();                          // coef[] visible
 
   if (stager) {
-    // ---------------- staging waves (threadIdx.x 0..255, exactly what TileStager assumes) ----------------
-    TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT> stg;
-    stg.init();
+    // ---------------- staging waves ----------------
     int b, oy0, ox0, gy0, gx0;
     if (walk.valid()) {
-      origin(walk.cur, b, oy0, ox0, gy0, gx0);
-      stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+      if (!HOIST) {
+        origin(walk.cur, b, oy0, ox0, gy0, gx0);
+        stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+      }
       stg.store(tile0, coef);                                   // tile 0 -> buffer 0
       if (walk.has_next()) {
         origin(walk.next(), b, oy0, ox0, gy0, gx0);
@@ -227,7 +244,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     }
   __syncthreads();                                              // (C)
   const int tc = t - 256;
-  if (tc < 2 * COUT && a.partials != nullptr) {
+  if (tc < 2 * COUT && a.acc_out != nullptr) {
+    const int which = tc / COUT, co = tc - which * COUT;
+    const int idx = which * 16 * MTA + co;
+    bn_acc_add(a.acc_out, which * 32 + co, (red[idx] + red[32 * MTA + idx]) + (red[64 * MTA + idx] + red[96 * MTA + idx]));
+  } else if (tc < 2 * COUT && a.partials != nullptr) {
     const int which = tc / COUT, co = tc - which * COUT;
     const int idx = which * 16 * MTA + co;
     a.partials[(size_t)blockIdx.x * 2 * COUT + tc] =

@@ -20,7 +20,7 @@ int ava_bn_eval_all(const float* const* gamma, const float* const* beta, const i
 int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const float* pb, const float* pc,
                    const float* G, const float* bias, float* out, float* out2, const float* epi_x,
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
-                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, ava_stream_t s);
+                   int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, const ConvAcc* acc, ava_stream_t s);
 int ava_nhwc_to_nchw(const float* in, float* out, int B, int P, hipStream_t st);
 int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, int P, hipStream_t st);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
@@ -142,6 +142,7 @@ struct ava_model {
   float* bn_part;           // [1024][64]
   float* bn_save;           // [14][4][32]: mean, invstd, scale, shift
   float* bn_bwd;            // [14][3][32]: A, Bc, Cc
+  long long* bn_acc;        // [28 slots][8 shards][200]: in-kernel BatchNorm sums (bn_acc.h), zeroed by the pack launch
   float* Gf[NCONV];
   float* Gb[NCONV];
   float *gA, *gB;           // gradient ping-pong, B*131072 floats each
@@ -228,6 +229,7 @@ static void carve(ava_model* m, void* ws, size_t* total) {
   m->bn_part = c.take(1024 * 64);
   m->bn_save = c.take(NCONV * 4 * 32);
   m->bn_bwd = c.take(NCONV * 3 * 32);
+  m->bn_acc = reinterpret_cast<long long*>(c.take((size_t)AVA_ACC_SLOTS * AVA_ACC_SLOT_LL * 2));
   for (int l = 0; l < NCONV; ++l) {
     m->Gf[l] = c.take(9 * kLayers[l].cin * kLayers[l].cout);
     m->Gb[l] = c.take(9 * kLayers[l].cin * kLayers[l].cout);
@@ -416,8 +418,12 @@ extern "C" int ava_profile_read(ava_model* m, float* ms, int* launches) {
 
 // ---- all 28 weight tables in one launch ---------------------------------------------------------------
 struct PackEntry { const float* w; float* g; int c0, c1, swap, flip; };
-struct PackTable { PackEntry e[2 * NCONV]; };
+struct PackTable { PackEntry e[2 * NCONV]; long long* acc; int nacc; };   // acc: BatchNorm accumulators to zero (bn_acc.h)
 __global__ void pack_all_kernel(const PackTable tab) {
+  {
+    const int gt = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, nt = gridDim.x * gridDim.y * blockDim.x;
+    for (int i = gt; i < tab.nacc; i += nt) tab.acc[i] = 0;
+  }
   const PackEntry e = tab.e[blockIdx.y];
   const int n = e.c0 * e.c1 * 9;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const PackTable tab, co
                                                          float* __restrict__ partials, int nstats, float* __restrict__ eps,
                                                          int64_t neps, uint64_t seed, uint64_t offset) {
   constexpr int NPACK = 7 * 2 * NCONV;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < tab.nacc; i += gridDim.x * 256) tab.acc[i] = 0;   // every block first
   if ((int)blockIdx.x >= nstats + NPACK) {              // third role: the step's rsample noise (ava_forward_noise)
     const int nb = gridDim.x - nstats - NPACK, bi = blockIdx.x - nstats - NPACK;
     for (int64_t i = (int64_t)bi * 256 + threadIdx.x; i < neps; i += (int64_t)nb * 256)
@@ -489,6 +496,8 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
     tab.e[2 * l] = {w, m->Gf[l], c0, c1, (kf == 0) ? 1 : 0, (kf == 1) ? 1 : 0};
     tab.e[2 * l + 1] = {w, m->Gb[l], c0, c1, (kb == 5 || kb == 6) ? 1 : 0, (kb == 3) ? 1 : 0};
   }
+  tab.acc = m->bn_acc;
+  tab.nacc = AVA_ACC_SLOTS * AVA_ACC_SLOT_LL;
   mark(m, -1, st);
   static const bool fuse = [] { const char* e = ava_env("AVA_PACK_STATS"); return e == nullptr || atoi(e) != 0; }();
   if (x_stats != nullptr && nstats_out != nullptr && fuse && (reinterpret_cast<uintptr_t>(x_stats) & 15) == 0) {
@@ -527,6 +536,62 @@ static bool lab_skip_bn_fin() {
 #else
 static constexpr bool lab_skip_bn_fin() { return false; }
 #endif
+
+// ---- BatchNorm sums accumulated in the producing kernel and finalised in the consumer's prologue (bn_acc.h) ----------
+// Forward: BatchNorm j (input of layer j) when layer j-1 runs the wave-specialised / plain matrix-core forward kernel
+// and layer j too: j = 2..6 (conv3..conv7) and 8..11 (convt2..convt5).  Backward: BatchNorm j when the backward of layer
+// j (fused kernel; for j = 5 the wave-specialised data-gradient kernel) hands over to the FUSED backward of layer j-1:
+// j = 12, 11, 10, 5, 4, 3, 2.  The other 12 layers keep their finalisation launch (thin / direct / layout kernels).
+static bool acc_enabled(bool bwd) {
+#ifdef AVA_LAB
+  static const int on = [] {
+    const char* e = ava_env("AVA_BN_ACC");
+    if (e != nullptr) return atoi(e);
+    const char* f = ava_env("AVA_CONV_FUSED"); const char* w = ava_env("AVA_FUSED_WS"); const char* c = ava_env("AVA_CONV_IMPL");
+    return ((f && atoi(f) == 0) || (w && atoi(w) == 0) || c != nullptr) ? 0 : 1;     // kernel-selection switches: launches only
+  }();
+  (void)bwd;
+  return on != 0;
+#else
+  (void)bwd;
+  return true;
+#endif
+}
+static bool acc_pair_fwd(const ava_model* m, int j) {
+  (void)m;
+  return acc_enabled(false) && ((j >= 2 && j <= 6) || (j >= 8 && j <= 11));
+}
+static bool acc_pair_bwd(const ava_model* m, int j) {
+  (void)m;
+  return acc_enabled(true) && (j == 12 || j == 11 || j == 10 || (j >= 2 && j <= 5));
+}
+static long long* acc_slot(ava_model* m, int slot) { return m->bn_acc + (size_t)slot * AVA_ACC_SLOT_LL; }
+static BnFin fin_none() { BnFin f = {}; f.acc = nullptr; return f; }
+static BnFin fin_fwd(ava_model* m, int j, int B) {
+  const ConvLayer& L = kLayers[j];
+  BnFin f = {};
+  f.acc = acc_slot(m, j);
+  f.gamma = PP(m, L.pg); f.beta = PP(m, L.pbeta);
+  f.save = m->bn_save + (size_t)j * 4 * 32;
+  f.running_mean = m->bn_running + j * 32;
+  f.running_var = m->bn_running + (NCONV + j) * 32;
+  f.num_batches = reinterpret_cast<long long*>(m->bn_batches + j);
+  f.n = (double)B * m->lay[j].hi * m->lay[j].wi;
+  f.C = L.cin; f.backward = 0; f.eval = 0;
+  return f;
+}
+static BnFin fin_bwd(ava_model* m, int j, int B) {
+  const ConvLayer& L = kLayers[j];
+  BnFin f = {};
+  f.acc = acc_slot(m, 14 + j);
+  f.gamma = PP(m, L.pg);
+  f.mean = bn_mean(m, j); f.invstd = bn_invstd(m, j);
+  f.dgamma = GG(m, L.pg); f.dbeta = GG(m, L.pbeta);
+  f.abc = m->bn_bwd + (size_t)j * 3 * 32;
+  f.n = (double)B * m->lay[j].hi * m->lay[j].wi;
+  f.C = L.cin; f.backward = 1; f.eval = m->last_train ? 0 : 1;
+  return f;
+}
 
 static int finalize_fwd(ava_model* m, int l, int nparts, int64_t n, hipStream_t st) {
   if (lab_skip_bn_fin()) return AVA_OK;
@@ -603,11 +668,14 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
     float* out = l == 6 ? m->y7 : m->X[l + 1];
     // conv7's matrix-core kernel also writes the NCHW-flatten copy fc1 reads (saves the transpose launch)
     float* nchw = (l == 6 && conv7_writes_nchw()) ? m->y7t : nullptr;
+    ConvAcc acc;
+    acc.fin = (train && acc_pair_fwd(m, l)) ? fin_fwd(m, l, B) : fin_none();                 // BatchNorm l: finalised in this kernel
+    acc.acc_out = (train && l < 6 && acc_pair_fwd(m, l + 1)) ? acc_slot(m, l + 1) : nullptr;    // BatchNorm l+1: summed by this kernel
     TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nchw,
                        nullptr, nullptr, nullptr, m->bn_part, B, D.hi, D.wi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
-                       0.f, m->act_bf16, reinterpret_cast<ava_stream_t>(st)));
+                       0.f, m->act_bf16, &acc, reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_CONV_FWD, st);
-    if (train && l < 6)
+    if (train && l < 6 && acc.acc_out == nullptr)
       TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, D.ho, D.wo, L.mode), (int64_t)B * D.ho * D.wo, st));
   }
   if (!conv7_writes_nchw()) TRY(ava_nhwc_to_nchw(m->y7, m->y7t, B, m->P8, st));
@@ -641,12 +709,15 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
     const LayerDims& D = m->lay[l];
     const bool last = l == NCONV - 1;
     float* out = last ? xrec : m->X[l + 1];
+    ConvAcc acc;
+    acc.fin = (train && acc_pair_fwd(m, l)) ? fin_fwd(m, l, B) : fin_none();
+    acc.acc_out = (train && !last && acc_pair_fwd(m, l + 1)) ? acc_slot(m, l + 1) : nullptr;
     TRY(ava_conv3x3_ex(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
                        last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, D.hi, D.wi,
-                       L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, m->act_bf16,
+                       L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, m->act_bf16, &acc,
                        reinterpret_cast<ava_stream_t>(st)));
     mark(m, CAT_CONV_FWD, st);
-    if (train && !last)
+    if (train && !last && acc.acc_out == nullptr)
       TRY(finalize_fwd(m, l + 1, ava_conv_grid(B, D.ho, D.wo, L.mode), (int64_t)B * D.ho * D.wo, st));
     if (last) m->sse_parts = ava_conv_grid(B, D.ho, D.wo, L.mode);
   }
@@ -735,9 +806,15 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
     a.bn_partials = m->bn_part; a.wg_partials = m->wg_part[l];
     a.B = B; a.Hi = D.hi; a.Wi = D.wi; a.Ho = D.ho; a.Wo = D.wo;
     a.act_bf16 = m->act_bf16;
+    // BatchNorm l+1's A, Bc, Cc finalised in this kernel / BatchNorm l's sums accumulated by it (bn_acc.h); the thin
+    // kernels of conv1 / convt7 (Cin or Cout = 1) keep arrays and partial rows
+    const bool thin = L.cin == 1 || L.cout == 1;
+    a.fin = (!thin && pro == PRO_BWD && acc_pair_bwd(m, l + 1)) ? fin_bwd(m, l + 1, B) : fin_none();
+    a.acc_out = (!thin && acc_pair_bwd(m, l)) ? acc_slot(m, 14 + l) : nullptr;
     a.tiles_y = a.tiles_x = a.ntiles = 0;
     TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
     mark(m, CAT_CONV_BWD_DATA, st);
+    if (a.acc_out != nullptr) return AVA_OK;                  // finalised by the next backward kernel
     return finalize_bwd(m, l, fgrid, (int64_t)B * D.hi * D.wi, st);
   }
   // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
@@ -746,11 +823,14 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   mark(m, CAT_CONV_WGRAD, st);
   // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
   const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
+  ConvAcc acc;
+  acc.fin = fin_none();                                      // unfused consumers read the A, Bc, Cc arrays
+  acc.acc_out = acc_pair_bwd(m, l) ? acc_slot(m, 14 + l) : nullptr;
   TRY(ava_conv3x3_ex(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
-                     m->bn_part, B, D.ho, D.wo, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f, m->act_bf16,
+                     m->bn_part, B, D.ho, D.wo, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f, m->act_bf16, &acc,
                      reinterpret_cast<ava_stream_t>(st)));
   mark(m, CAT_CONV_BWD_DATA, st);
-  TRY(finalize_bwd(m, l, ava_conv_grid(B, D.hi, D.wi, bmode), (int64_t)B * D.hi * D.wi, st));
+  if (acc.acc_out == nullptr) TRY(finalize_bwd(m, l, ava_conv_grid(B, D.hi, D.wi, bmode), (int64_t)B * D.hi * D.wi, st));
   return AVA_OK;
 }
 

@@ -10,6 +10,7 @@
 #include <string.h>
 #include "common.h"
 #include "bn_fuse.h"
+#include "bn_acc.h"
 
 #define BN_EPS AVA_BN_EPS
 #define BN_MOMENTUM AVA_BN_MOMENTUM
@@ -187,7 +188,8 @@ __device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const
 // f8 [B][32*P] (c*P+p) -> out [B][P][32] (an ACTIVATION: stored as ACT), plus per-channel {sum, sum^2} partials for bn8
 template <typename ACT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out_,
-                                                                 float* __restrict__ partials, int B, int P) {
+                                                                 float* __restrict__ partials, int B, int P,
+                                                                 long long* acc_out) {
   ACT* __restrict__ out = reinterpret_cast<ACT*>(out_);
   __shared__ float tile[32][QPIX + 1];
   __shared__ float red[8][64];
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k][t];
-    partials[(size_t)blockIdx.x * 64 + t] = s;
+    if (acc_out != nullptr) bn_acc_add(acc_out, t, s);       // t = which * 32 + channel: accumulated for the consumer (bn_acc.h)
+    else partials[(size_t)blockIdx.x * 64 + t] = s;
   }
 }
 
@@ -348,13 +351,13 @@ int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, 
 }
 
 // internal (model.hip)
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int act_bf16, int* nparts,
-                           hipStream_t st) {
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int act_bf16, long long* acc_out,
+                           int* nparts, hipStream_t st) {
   if (P < QPIX || P % QPIX != 0) return AVA_EINVAL;
   const int nw = (P / QPIX) * B;
   const int grid = nw < 1024 ? nw : 1024;
-  if (act_bf16) hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, in, out, partials, B, P);
-  else hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel<float>, dim3(grid), dim3(256), 0, st, in, out, partials, B, P);
+  if (act_bf16) hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, in, out, partials, B, P, acc_out);
+  else hipLaunchKernelGGL(nchw_to_nhwc_stats_kernel<float>, dim3(grid), dim3(256), 0, st, in, out, partials, B, P, acc_out);
   AVA_CHECK_LAUNCH();
   *nparts = grid;
   return AVA_OK;

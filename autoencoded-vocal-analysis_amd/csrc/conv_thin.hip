@@ -214,6 +214,12 @@ __global__ __launch_bounds__(2 * W) void thin_1to8_kernel(const ConvArgs a) {
     if (lane < 2) red[wave][lane][i] = v;              // lane = h
   }
   __syncthreads();
+  if (t < 16 && a.acc_out != nullptr) {                    // sums accumulated for the consumer's prologue (bn_acc.h)
+    const int which = t >> 3, co = t & 7, hh = co >> 2, i = which * 4 + (co & 3);
+    bn_acc_add(a.acc_out, which * 32 + co, thin_sum_waves<THIN_NW>([&](int w) { return red[w][hh][i]; }));
+    return;
+  }
+  if (a.acc_out != nullptr) return;
   if (t < 16 && a.partials != nullptr) {
     const int which = t >> 3, co = t & 7, hh = co >> 2, i = which * 4 + (co & 3);
     a.partials[(size_t)blockIdx.x * 16 + t] = thin_sum_waves<THIN_NW>([&](int w) { return red[w][hh][i]; });
@@ -1081,7 +1087,8 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(con
     const int which = t >> 3, ci = t & 7;
     float s = 0.f;
     for (int tap = 0; tap < 9; ++tap) s += scratch[which][tap * 8 + ci];
-    a.bn_partials[(size_t)blockIdx.x * 16 + t] = s;
+    if (a.acc_out != nullptr) bn_acc_add(a.acc_out, which * 32 + ci, s);     // accumulated for the consumer's prologue
+    else a.bn_partials[(size_t)blockIdx.x * 16 + t] = s;
   }
 }
 

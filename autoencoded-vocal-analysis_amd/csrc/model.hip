@@ -9,8 +9,8 @@
 #include "conv_fused.h"
 
 // internal entry points of the other translation units
-int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int act_bf16, int* nparts,
-                           hipStream_t st);
+int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int act_bf16, long long* acc_out,
+                           int* nparts, hipStream_t st);
 int ava_conv3x3_wgrad_ex(const float* x, const float* xa, const float* xb, const float* dy, const float* dy2,
                          const float* da, const float* db_, const float* dc, float* partials, int B, int Hi, int Wi,
                          int Cin, int Cout, int mode, int dy_pro, int act_bf16, ava_stream_t s);
@@ -538,10 +538,12 @@ static constexpr bool lab_skip_bn_fin() { return false; }
 #endif
 
 // ---- BatchNorm sums accumulated in the producing kernel and finalised in the consumer's prologue (bn_acc.h) ----------
-// Forward: BatchNorm j (input of layer j) when layer j-1 runs the wave-specialised / plain matrix-core forward kernel
-// and layer j too: j = 2..6 (conv3..conv7) and 8..11 (convt2..convt5).  Backward: BatchNorm j when the backward of layer
-// j (fused kernel; for j = 5 the wave-specialised data-gradient kernel) hands over to the FUSED backward of layer j-1:
-// j = 12, 11, 10, 5, 4, 3, 2.  The other 12 layers keep their finalisation launch (thin / direct / layout kernels).
+// Forward: BatchNorm j (input of layer j) when layer j runs the wave-specialised / plain matrix-core forward kernel (the
+// consumer side) and its input comes from such a kernel, from conv1's packed-FMA kernel (j = 1) or from the
+// fc8 -> NHWC layout kernel (j = 7): j = 1..11.  Backward: BatchNorm j when the backward of layer j (fused kernel; j = 5:
+// the wave-specialised data-gradient kernel; j = 13: convt7's weight-gradient + sums kernel) hands over to the FUSED
+// backward of layer j-1: j = 13, 12, 11, 10, 5, 4, 3, 2.  The other 9 keep their finalisation launch (consumers:
+// convt6 / convt7 forward, the unfused 16x16 layers, bn8's layout kernel, conv1's backward, bn1's own gradient).
 static bool acc_enabled(bool bwd) {
 #ifdef AVA_LAB
   static const int on = [] {
@@ -559,11 +561,11 @@ static bool acc_enabled(bool bwd) {
 }
 static bool acc_pair_fwd(const ava_model* m, int j) {
   (void)m;
-  return acc_enabled(false) && ((j >= 2 && j <= 6) || (j >= 8 && j <= 11));
+  return acc_enabled(false) && ((j >= 1 && j <= 6) || (j >= 7 && j <= 11));
 }
 static bool acc_pair_bwd(const ava_model* m, int j) {
   (void)m;
-  return acc_enabled(true) && (j == 12 || j == 11 || j == 10 || (j >= 2 && j <= 5));
+  return acc_enabled(true) && (j == 13 || j == 12 || j == 11 || j == 10 || (j >= 2 && j <= 5));
 }
 static long long* acc_slot(ava_model* m, int slot) { return m->bn_acc + (size_t)slot * AVA_ACC_SLOT_LL; }
 static BnFin fin_none() { BnFin f = {}; f.acc = nullptr; return f; }
@@ -701,9 +703,10 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
   TRY(gemm(m, m->h6, 0, PP(m, FC7), 0, PP(m, FC7 + 1), m->h7, 0, nullptr, nullptr, B, 1024, 256, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, m->F, 1024, 1, 1, ACT_RELU, st));
   int nparts = 0;
-  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, m->P8, m->act_bf16, &nparts, st));
+  long long* acc7 = (train && acc_pair_fwd(m, 7)) ? acc_slot(m, 7) : nullptr;     // bn8's sums: finalised by convt1's kernel
+  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, m->P8, m->act_bf16, acc7, &nparts, st));
   mark(m, CAT_LAYOUT, st);
-  if (train) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * m->P8, st));
+  if (train && acc7 == nullptr) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * m->P8, st));
   for (int l = 7; l < NCONV; ++l) {
     const ConvLayer& L = kLayers[l];
     const LayerDims& D = m->lay[l];
@@ -810,7 +813,7 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
     // kernels of conv1 / convt7 (Cin or Cout = 1) keep arrays and partial rows
     const bool thin = L.cin == 1 || L.cout == 1;
     a.fin = (!thin && pro == PRO_BWD && acc_pair_bwd(m, l + 1)) ? fin_bwd(m, l + 1, B) : fin_none();
-    a.acc_out = (!thin && acc_pair_bwd(m, l)) ? acc_slot(m, 14 + l) : nullptr;
+    a.acc_out = ((!thin || l == 13) && acc_pair_bwd(m, l)) ? acc_slot(m, 14 + l) : nullptr;   // l = 13: convt7's sums kernel
     a.tiles_y = a.tiles_x = a.ntiles = 0;
     TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
     mark(m, CAT_CONV_BWD_DATA, st);

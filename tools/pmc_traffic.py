@@ -8,7 +8,8 @@ bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SI
 """
 import collections, csv, json, sys
 
-CONV_PREFIX = ("conv3x3", "thin_", "bn_stats", "bn_finalize", "pack_all", "wgrad_reduce")
+# the kernels bench.py counts into the conv family (forward, backward, weight gradient, BatchNorm, weight packing)
+CONV_PREFIX = ("conv3x3", "thin_", "up88_direct", "bn_stats", "bn_finalize", "pack_all", "pack_stats", "wgrad_reduce")
 
 
 def per_kernel(path, counter):

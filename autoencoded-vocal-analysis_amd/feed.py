@@ -115,6 +115,8 @@ class DeviceFeeder:
             if n > slot.dev.shape[0] or tuple(batch.shape[1:]) != tuple(slot.dev.shape[1:]):
                 slot.dev = torch.empty(tuple(batch.shape), dtype=torch.float32, device=self.device)
             ring_slot = _RING_SLOTS.get(batch.data_ptr()) if batch.device.type == "cpu" else None
+            if batch.device.type != "cpu":                   # produced on the device by the caller's stream: order the copy
+                copy_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(copy_stream):
                 if batch.dtype == torch.float32 or batch.dtype not in _CAST or batch.device.type != "cpu":
                     slot.dev[:n].copy_(batch, non_blocking=True)             # fp32 (or an exotic dtype: torch converts)

@@ -127,3 +127,42 @@ def get_synthetic_data_loaders(num_train, num_test=0, batch_size=64, shuffle=(Tr
     test = DataLoader(SyntheticSpecDataset(num_test, salt + 1), batch_size=batch_size,
                       shuffle=shuffle[1], num_workers=num_workers)
     return {"train": train, "test": test}
+
+
+# ---- synthetic recordings for the shotgun-spectrogram path ----------------------------
+FINCH_PARAMS = {          # examples/finch_window_mwe.py:29-49 (the numeric entries)
+    'fs': 32000, 'num_freq_bins': X_SHAPE[0], 'num_time_bins': X_SHAPE[1], 'nperseg': 512, 'noverlap': 256,
+    'max_dur': 1e9, 'window_length': 0.12, 'min_freq': 400, 'max_freq': 10e3, 'spec_min_val': 2.0,
+    'spec_max_val': 6.5, 'mel': True, 'time_stretch': False, 'within_syll_normalize': False,
+}
+MOUSE_PARAMS = {          # examples/mouse_window_mwe.py:29-49
+    'fs': 250000, 'num_freq_bins': X_SHAPE[0], 'num_time_bins': X_SHAPE[1], 'nperseg': 1024, 'noverlap': 512,
+    'max_dur': 1e9, 'window_length': 0.20, 'min_freq': 30e3, 'max_freq': 110e3, 'spec_min_val': -6.5,
+    'spec_max_val': -2.0, 'mel': False, 'time_stretch': False, 'within_syll_normalize': False,
+}
+
+
+def recordings(n_files=3, fs=32000, seconds=2.0, salt=4004, dtype=np.int16, amplitude=3000.0):
+    """``n_files`` synthetic mono recordings (frequency sweeps with harmonics over noise, bursts separated by near
+    silence) of slightly different lengths, and per file an ``[n_i, 2]`` array of vocalisation segments (onset, offset
+    in seconds) as ``np.loadtxt(roi_file, ndmin=2)`` returns it.  Pure numpy, hash-seeded: identical wherever generated."""
+    audio, rois = [], []
+    for f in range(n_files):
+        n = int(fs * seconds * (1.0 + 0.13 * f))
+        t = np.arange(n) / fs
+        noise = gauss(n, salt + 17 * f)
+        f0 = 0.06 * fs * (1.0 + 0.5 * f / max(1, n_files))
+        phase = 2.0 * np.pi * (f0 * t + 0.04 * fs * np.sin(2.0 * np.pi * 3.0 * t) / (2.0 * np.pi * 3.0))
+        env = (np.sin(2.0 * np.pi * 2.5 * t + f) > -0.2).astype(np.float64)          # bursts
+        x = amplitude * env * (np.sin(phase) + 0.4 * np.sin(2.1 * phase) + 0.15 * np.sin(3.3 * phase))
+        x = x + 0.02 * amplitude * noise + 0.01 * amplitude                           # noise floor + a DC offset
+        if np.issubdtype(np.dtype(dtype), np.integer):
+            x = np.clip(np.rint(x), np.iinfo(dtype).min, np.iinfo(dtype).max)
+        else:
+            x = x / 32768.0
+        audio.append(x.astype(dtype))
+        dur = n / fs
+        k = 3 + f
+        edges = np.linspace(0.02, dur - 0.02, 2 * k)
+        rois.append(np.stack([edges[0::2], edges[1::2]], axis=1))
+    return audio, rois

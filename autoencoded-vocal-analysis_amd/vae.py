@@ -287,6 +287,8 @@ class VAE(nn.Module):
     def _feed(self, loader):
         """Batches of ``loader`` on the device, one batch ahead on a copy stream (``feed.DeviceFeeder``), unless
         ``self.prefetch`` is False, in which case every batch is moved synchronously like vae.py:349 does."""
+        if getattr(loader, "device_resident", False):
+            return loader                 # batches are produced on the device (spec.DeviceWindowLoader): nothing to copy
         if getattr(self, "prefetch", True) and self.device.type == "cuda":
             return DeviceFeeder(loader, self.device)
         return loader

@@ -265,6 +265,31 @@ int ava_mmd2_linear(const double* latent, int z, const int64_t* i1, const int64_
 int ava_pair_sqdist(const double* latent, int z, const int64_t* a, const int64_t* b, int n, double* out,
                     ava_stream_t s);
 
+/* ---- shotgun spectrograms on the device -------------------------------------------
+ * get_spec (ava/preprocessing/utils.py:18-110) for a batch of n windows as FixedWindowDataset.__getitem__ issues it
+ * (ava/models/window_vae_dataset.py:213-224: get_spec(max(0, onset - shoulder), offset + shoulder, audio[file], p,
+ * fs=fs, target_times=linspace(onset, offset, T))), with the audio of all files resident in ONE device buffer.
+ *   audio / audio_dtype   concatenated samples of all files; 0 = int16, 1 = int32, 2 = float32, 3 = float64
+ *                         (what scipy.io.wavfile.read returns, window_vae_dataset.py:167)
+ *   file_off, file_len    [files] first sample / number of samples of each file in `audio` (device)
+ *   file_idx, t1, t2      [n] file of each window, get_spec's t1 / t2 in seconds (device)
+ *   target_times          [n][T] get_spec's target_times (device); target_freqs [F] (utils.py:80-88, device)
+ *   max_samples           >= max over windows of round(t2 fs) - round(t1 fs): sizes the STFT scratch
+ *   window, scale         scipy.signal.get_window('hann', nperseg) (device) and sqrt(1 / sum(window)^2): what
+ *                         scipy.signal.stft(..., scaling='spectrum') applies (utils.py:74)
+ *   spec_min, spec_max    p['spec_min_val'], p['spec_max_val'] (utils.py:100-103); fill_value utils.py:19
+ *   out [n][F][T] fp32    the clipped spectrograms; out_max [n] or NULL: their maxima (min_spec_val test,
+ *                         window_vae_dataset.py:229-231)
+ * nperseg: a power of two in 64..2048, 0 <= noverlap < nperseg; within_syll_normalize is not covered.
+ * All arithmetic is fp64.  Windows the reference answers with zeros (utils.py:68-69) come out as zeros. */
+size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap);
+int ava_get_spec_batch(const void* audio, int audio_dtype, const int64_t* file_off, const int64_t* file_len,
+                       const int32_t* file_idx, const double* t1, const double* t2, const double* target_times,
+                       int n, int max_samples, double fs, int nperseg, int noverlap, const double* window,
+                       double scale, const double* target_freqs, int F, int T, double spec_min, double spec_max,
+                       double fill_value, int remove_dc, float* out, float* out_max, void* ws, size_t ws_bytes,
+                       ava_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -357,7 +357,58 @@ def mmd_case():
     return out
 
 
+def shotgun_case():
+    """Window selection of the REAL ``FixedWindowDataset`` (ava/models/window_vae_dataset.py:143-256) over synthetic wav
+    files.  The reference's own ``get_spec`` cannot run in this image (``scipy.interpolate.interp2d`` was removed from
+    SciPy 1.14+, ava/preprocessing/utils.py:11,77), so the class is driven through its ``p['get_spec']`` hook with a
+    recorder: what is pinned here is everything ``__getitem__`` does around that call -- the draws of file, segment and
+    onset for a seed, the arguments handed to ``get_spec`` and the redraw rule for windows below ``min_spec_val``."""
+    from scipy.io import wavfile
+    from ava.models.window_vae_dataset import FixedWindowDataset
+    out = {}
+    for name, params in (("finch", syn.FINCH_PARAMS), ("mouse", syn.MOUSE_PARAMS)):
+        fs = params['fs']
+        audio, rois = syn.recordings(n_files=3, fs=fs, seconds=2.0 if name == "finch" else 1.0)
+        with tempfile.TemporaryDirectory() as tmp:
+            wavs, roifs = [], []
+            for i, (a, r) in enumerate(zip(audio, rois)):
+                wavs.append(os.path.join(tmp, "rec_%02d.wav" % i))
+                roifs.append(os.path.join(tmp, "rec_%02d.txt" % i))
+                wavfile.write(wavs[-1], fs, a)
+                np.savetxt(roifs[-1], r)
+            calls = []
+
+            def recorder(t1, t2, audio_arg, p, fs=32000, target_times=None):
+                # loudness is a pure function of the call, so that the redraw path is reproducible
+                loud = 0.25 + 0.75 * ((t1 * 1e3) % 1.0)
+                calls.append((t1, t2, len(audio_arg), fs, target_times[0], target_times[-1], len(target_times), loud))
+                return np.full((p['num_freq_bins'], p['num_time_bins']), loud), True
+
+            p = dict(params)
+            p['get_spec'] = recorder
+            for tag, min_spec_val, seed, n in (("plain", None, 11, 16), ("retry", 0.6, 12, 16), ("single", None, 13, 1)):
+                ds = FixedWindowDataset(wavs, roifs, p, transform=None, dataset_length=64, min_spec_val=min_spec_val)
+                del calls[:]
+                index = list(range(n)) if n > 1 else 0
+                specs, fidx, on, off = ds.__getitem__(index, seed=seed, return_seg_info=True)
+                if n == 1:
+                    specs, fidx, on, off = [specs], [fidx], [on], [off]
+                k = "%s.%s." % (name, tag)
+                out[k + "file_indices"] = np.array(fidx, dtype=np.int64)
+                out[k + "onsets"] = np.array(on, dtype=np.float64)
+                out[k + "offsets"] = np.array(off, dtype=np.float64)
+                out[k + "loud"] = np.array([s[0, 0] for s in specs])
+                out[k + "calls"] = np.array(calls, dtype=np.float64)          # every get_spec call, rejected ones included
+            out[name + ".file_weights"] = ds.file_weights
+            out[name + ".fs_read"] = np.float64(ds.fs)
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "shotgun":
+        np.savez_compressed(os.path.join(HERE, "shotgun.npz"), **shotgun_case())
+        print("shotgun.npz written")
+        return
     for B, z, steps in ((8, 32, 3), (8, 64, 1), (64, 32, 1)):
         out, _ = forward_backward_case(B, z, steps)
         if (B, z) == (8, 32):
@@ -369,6 +420,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "harness.npz"), **harness_case())
     np.savez_compressed(os.path.join(HERE, "callers.npz"), **callers_with_selfnoise())
     np.savez_compressed(os.path.join(HERE, "mmd.npz"), **mmd_case())
+    np.savez_compressed(os.path.join(HERE, "shotgun.npz"), **shotgun_case())
     assert not _QUEUE
     print("golden vectors written to", HERE)
 

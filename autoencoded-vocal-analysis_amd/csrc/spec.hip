@@ -24,7 +24,8 @@ enum { AVA_AUDIO_I16 = 0, AVA_AUDIO_I32 = 1, AVA_AUDIO_F32 = 2, AVA_AUDIO_F64 = 
 struct SpecMeta {        // one per window, written by spec_prep_kernel
   long long lo;          // first sample of the slice inside the concatenated audio buffer
   int n;                 // samples in the slice
-  int nframes;           // STFT frames (0: the reference returns zeros for this window)
+  int nframes;           // STFT frames (0: the reference returns zeros for this window; -1: scratch too small)
+  int j0, j1;            // frames the interpolation can touch (inclusive): the others are never computed
   double mean;           // subtracted DC offset (0 when remove_dc_offset is off)
   double t_shift;        // max(0, t1)
 };
@@ -40,10 +41,13 @@ struct SpecArgs {
   const double* target_freqs;    // [F]
   const double* window;          // [nperseg]
   SpecMeta* meta;
+  double* twiddle;               // [nperseg/2][2]: exp(-2 pi i k / nperseg), written by spec_prep_kernel's workgroup 0
+  double* ftimes;                // [n][maxframes]: frame times of each window, written by spec_prep_kernel
+  int* krange;                   // [2]: first / last frequency bin the target frequencies can touch (workgroup 0)
   double* logmag;                // [n][maxframes][nperseg/2 + 1]
   float* out;                    // [n][F][T]
   float* out_max;                // [n] or null
-  double fs, scale, spec_min, range, fill_value;
+  double fs, scale, spec_min, range, fill_value, fbin;    // fbin: rfftfreq's 1 / (nperseg * (1 / fs))
   int n, maxframes, nperseg, nstep, F, T, dtype, remove_dc;
 };
 
@@ -56,11 +60,49 @@ __device__ __forceinline__ double audio_at(const void* base, int dtype, long lon
   }
 }
 
+// frame time j of a window: scipy's  arange(nperseg/2, ..., hop) / fs - (nperseg/2) / fs, then utils.py:75's + max(0, t1)
+__device__ __forceinline__ double frame_time(int j, const SpecArgs& a, double t_shift) {
+  const double half = 0.5 * (double)a.nperseg;
+  const double c = __ddiv_rn(half + (double)j * (double)a.nstep, a.fs);
+  return __dadd_rn(__dsub_rn(c, __ddiv_rn(half, a.fs)), t_shift);
+}
+
+#define AVA_SPEC_PREP_T 1024
 // utils.py:58-73: sample range of the window, the "too short" rule, the mean of the slice.  Fixed-order sum (thread
 // strides, then a tree): deterministic; exact for integer audio (|sum| < 2^53), where it equals numpy's pairwise sum.
-__global__ __launch_bounds__(256) void spec_prep_kernel(const SpecArgs a) {
-  __shared__ double red[256];
+// int16 recordings (the usual wav) are read 8 samples per load.  Also: the range of frames the target times of this
+// window can fall between, and (workgroup 0) the twiddle table of the transform.
+__global__ __launch_bounds__(AVA_SPEC_PREP_T) void spec_prep_kernel(const SpecArgs a) {
+  __shared__ double red[AVA_SPEC_PREP_T];
+  __shared__ double tlo[64], thi[64];
   const int w = blockIdx.x, t = threadIdx.x;
+  if (w == 0)
+    for (int k = t; k < a.nperseg / 2; k += AVA_SPEC_PREP_T) {
+      double sn, cs;
+      sincospi(-2.0 * (double)k / (double)a.nperseg, &sn, &cs);      // k / nperseg is exact (power of two)
+      a.twiddle[2 * k] = cs;
+      a.twiddle[2 * k + 1] = sn;
+    }
+  if (w == 0 && t < 64) {                                       // bins the target frequencies lie between (+- 2 of slack)
+    double mnf = 1e300, mxf = -1e300;
+    for (int i = t; i < a.F; i += 64) {
+      const double y = a.target_freqs[i];
+      if (y < mnf) mnf = y;
+      if (y > mxf) mxf = y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double m2 = __shfl_xor(mnf, o, 64), x2 = __shfl_xor(mxf, o, 64);
+      mnf = m2 < mnf ? m2 : mnf;
+      mxf = x2 > mxf ? x2 : mxf;
+    }
+    if (t == 0) {
+      const int K1 = a.nperseg / 2;
+      const double b0 = floor(mnf / a.fbin) - 2.0, b1 = floor(mxf / a.fbin) + 3.0;
+      a.krange[0] = b0 > 0.0 ? (b0 < (double)K1 ? (int)b0 : K1) : 0;
+      a.krange[1] = b1 < (double)K1 ? (b1 > 0.0 ? (int)b1 : 0) : K1;
+    }
+  }
   const long long len = a.file_len[a.file_idx[w]];
   const long long base = a.file_off[a.file_idx[w]];
   const double t1 = a.t1[w], t2 = a.t2[w];
@@ -70,13 +112,52 @@ __global__ __launch_bounds__(256) void spec_prep_kernel(const SpecArgs a) {
   const long long cnt = hi - lo;
   const bool valid = !(cnt < a.nperseg || s2 <= 0 || s1 >= len);
   double s = 0.0;
-  if (valid && a.remove_dc)
-    for (long long i = t; i < cnt; i += 256) s += audio_at(a.audio, a.dtype, base + lo + i);
+  if (valid && a.remove_dc) {
+    const long long e0 = base + lo, e1 = e0 + cnt;
+    if (a.dtype == AVA_AUDIO_I16) {
+      const short* p = reinterpret_cast<const short*>(a.audio);
+      long long a0 = (e0 + 7) & ~7ll, a1 = e1 & ~7ll;                 // 16-byte aligned body [a0, a1)
+      if (a0 > a1) { a0 = e1; a1 = e1; }
+      for (long long i = e0 + t; i < a0; i += AVA_SPEC_PREP_T) s += (double)p[i];
+      const int4* p8 = reinterpret_cast<const int4*>(p + a0);
+      const long long nv = (a1 - a0) >> 3;
+      for (long long v = t; v < nv; v += AVA_SPEC_PREP_T) {
+        const int4 q = p8[v];
+        const int ws[4] = {q.x, q.y, q.z, q.w};
+        int acc = 0;                                                   // 8 int16: exact in int32
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (int)(short)(ws[u] & 0xffff) + (ws[u] >> 16);
+        s += (double)acc;
+      }
+      for (long long i = a1 + t; i < e1; i += AVA_SPEC_PREP_T) s += (double)p[i];
+    } else {
+      for (long long i = e0 + t; i < e1; i += AVA_SPEC_PREP_T) s += audio_at(a.audio, a.dtype, i);
+    }
+  }
   red[t] = s;
+  // smallest / largest target time of the window (NaNs ignored)
+  double mn = 1e300, mx = -1e300;
+  for (int i = t; i < a.T; i += AVA_SPEC_PREP_T) {
+    const double x = a.target_times[(size_t)w * a.T + i];
+    if (x < mn) mn = x;
+    if (x > mx) mx = x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double m2 = __shfl_xor(mn, o, 64), x2 = __shfl_xor(mx, o, 64);
+    mn = m2 < mn ? m2 : mn;
+    mx = x2 > mx ? x2 : mx;
+  }
+  if ((t & 63) == 0) { tlo[t >> 6] = mn; thi[t >> 6] = mx; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = AVA_SPEC_PREP_T / 2; o > 0; o >>= 1) {
     if (t < o) red[t] += red[t + o];
     __syncthreads();
+  }
+  {
+    const int nfa = valid ? (int)((cnt + a.nstep - 1) / a.nstep) + 1 : 0;
+    if (nfa <= a.maxframes)
+      for (int j = t; j < nfa; j += AVA_SPEC_PREP_T) a.ftimes[(size_t)w * a.maxframes + j] = frame_time(j, a, t1 > 0.0 ? t1 : 0.0);
   }
   if (t == 0) {
     SpecMeta m;
@@ -89,62 +170,137 @@ __global__ __launch_bounds__(256) void spec_prep_kernel(const SpecArgs a) {
     m.nframes = nf;
     m.mean = (valid && a.remove_dc) ? red[0] / (double)cnt : 0.0;
     m.t_shift = t1 > 0.0 ? t1 : 0.0;
+    for (int i = 1; i < AVA_SPEC_PREP_T / 64; ++i) {
+      mn = tlo[i] < mn ? tlo[i] : mn;
+      mx = thi[i] > mx ? thi[i] : mx;
+    }
+    // frames l, l+1 bracket a target time x when l = floor((x - t_0) fs / hop); two frames of slack either side
+    int j0 = 0, j1 = nf - 1;
+    if (nf > 0) {
+      const double x0 = frame_time(0, a, m.t_shift), per = a.fs / (double)a.nstep;
+      const double f0 = floor((mn - x0) * per) - 2.0, f1 = floor((mx - x0) * per) + 3.0;
+      if (f0 > 0.0) j0 = f0 < (double)(nf - 1) ? (int)f0 : nf - 1;
+      if (f1 < (double)(nf - 1)) j1 = f1 > 0.0 ? (int)f1 : 0;
+    }
+    m.j0 = j0; m.j1 = j1;
     a.meta[w] = m;
     if (a.out_max != nullptr) a.out_max[w] = 0.f;
   }
 }
 
-// One frame: window, N-point FFT (radix-2 decimation in time in LDS, twiddle table in LDS), log-magnitude of the
-// one-sided spectrum.
+// Frames of one window: Hann window, N-point transform of the real frame as an N/2-point complex FFT of the
+// even/odd-interleaved samples (radix-2 decimation in time in LDS) + the split step, log-magnitude of the one-sided
+// spectrum.  A workgroup walks the needed frames of its window with stride gridDim.x; the twiddle table is loaded once.
+#define PD(i) ((i) + ((i) >> 3))
 template <int LOGN>
 __global__ __launch_bounds__(256) void spec_stft_kernel(const SpecArgs a) {
-  constexpr int N = 1 << LOGN;
-  __shared__ double re[N], im[N];
-  __shared__ double twr[N / 2], twi[N / 2];
-  const int j = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+  constexpr int N = 1 << LOGN, H = N / 2, LOGH = LOGN - 1;
+  // every LDS array is indexed through PD(i) = i + i / 8: one pad double per eight spreads the power-of-two strides of
+  // the bit-reversed store, the butterflies and the twiddle look-ups over the banks (73 % of the LDS cycles of the
+  // unpadded kernel were bank conflicts)
+  __shared__ double re[H + H / 8 + 1], im[H + H / 8 + 1];
+  __shared__ double twr[H + H / 8 + 1], twi[H + H / 8 + 1];       // exp(-2 pi i k / N), k < N/2
+  const int w = blockIdx.y, t = threadIdx.x;
   const SpecMeta m = a.meta[w];
-  if (j >= m.nframes) return;
-  for (int k = t; k < N / 2; k += 256) {
-    double sn, cs;
-    sincospi(-2.0 * (double)k / (double)N, &sn, &cs);      // exp(-2 pi i k / N); k / N is exact
-    twr[k] = cs;
-    twi[k] = sn;
+  if (m.nframes <= 0 || m.j0 + (int)blockIdx.x > m.j1) return;
+  for (int k = t; k < H; k += 256) {
+    twr[PD(k)] = a.twiddle[2 * k];
+    twi[PD(k)] = a.twiddle[2 * k + 1];
   }
-  for (int i = t; i < N; i += 256) {
-    const long long idx = (long long)j * a.nstep + i - N / 2;      // position in the slice (zeros outside)
-    double v = 0.0;
-    if (idx >= 0 && idx < m.n) v = __dmul_rn(audio_at(a.audio, a.dtype, m.lo + idx) - m.mean, a.window[i]);
-    const int r = (int)(__brev((unsigned)i) >> (32 - LOGN));
-    re[r] = v;
-    im[r] = 0.0;
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int s = 0; s < LOGN; ++s) {
-    const int half = 1 << s;
-    for (int b = t; b < N / 2; b += 256) {
-      const int pos = b & (half - 1);
-      const int i0 = ((b >> s) << (s + 1)) + pos, i1 = i0 + half;
-      const int tk = pos << (LOGN - 1 - s);
-      const double wr = twr[tk], wi = twi[tk];
-      const double xr = re[i1], xi = im[i1];
-      const double pr = wr * xr - wi * xi, pi = wr * xi + wi * xr;
-      const double ur = re[i0], ui = im[i0];
-      re[i0] = ur + pr; im[i0] = ui + pi;
-      re[i1] = ur - pr; im[i1] = ui - pi;
+  const int k0 = a.krange[0], k1 = a.krange[1];             // bins outside are never read by the interpolation
+  // samples of a frame: thread t owns the pairs (2 i, 2 i + 1), i = t + 256 u; raw values are fetched one frame ahead
+  constexpr int U = H / 256 > 0 ? H / 256 : 1;
+  double raw[U][2];
+  auto fetch = [&](int j) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = t + 256 * u;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const long long idx = (long long)j * a.nstep + 2 * i + e - N / 2;      // position in the slice (zeros outside)
+        const bool in = i < H && idx >= 0 && idx < m.n;
+        const double x = audio_at(a.audio, a.dtype, m.lo + (in ? idx : 0));      // unconditional load, clamped address
+        raw[u][e] = in ? x - m.mean : 0.0;                                       // zero boundary / padding
+      }
     }
+  };
+  fetch(m.j0 + blockIdx.x);
+  for (int j = m.j0 + blockIdx.x; j <= m.j1; j += gridDim.x) {
+    __syncthreads();                                       // twiddles ready / previous frame's reads retired
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = t + 256 * u;
+      if (i < H) {
+        const double v0 = __dmul_rn(raw[u][0], a.window[2 * i]);
+        const double v1 = __dmul_rn(raw[u][1], a.window[2 * i + 1]);
+        const int r = (int)(__brev((unsigned)i) >> (32 - LOGH));
+        re[PD(r)] = v0;
+        im[PD(r)] = v1;
+      }
+    }
+    if (j + (int)gridDim.x <= m.j1) fetch(j + gridDim.x);  // in flight under this frame's butterflies
     __syncthreads();
+    // Two radix-2 stages (half = h, then 2 h) per pass over LDS: the four points i0 + {0, h, 2h, 3h} of a group are
+    // combined in registers (same operations, same order as two separate stages; half the LDS traffic, which bounds
+    // this kernel).  An odd stage count ends with one plain radix-2 pass.
+    int st = 0;
+#pragma unroll 1
+    for (; st + 1 < LOGH; st += 2) {
+      const int h = 1 << st;
+      for (int b = t; b < H / 4; b += 256) {
+        const int pos = b & (h - 1);
+        const int i0 = ((b >> st) << (st + 2)) + pos, i1 = i0 + h, i2 = i1 + h, i3 = i2 + h;
+        const int k1 = pos << (LOGN - 1 - st), k2 = pos << (LOGN - 2 - st);
+        const double w1r = twr[PD(k1)], w1i = twi[PD(k1)], w2r = twr[PD(k2)], w2i = twi[PD(k2)];
+        const double x1r = re[PD(i1)], x1i = im[PD(i1)], x3r = re[PD(i3)], x3i = im[PD(i3)];
+        const double p1r = w1r * x1r - w1i * x1i, p1i = w1r * x1i + w1i * x1r;
+        const double p3r = w1r * x3r - w1i * x3i, p3i = w1r * x3i + w1i * x3r;
+        const double u0r = re[PD(i0)], u0i = im[PD(i0)], u2r = re[PD(i2)], u2i = im[PD(i2)];
+        const double b0r = u0r + p1r, b0i = u0i + p1i, b1r = u0r - p1r, b1i = u0i - p1i;     // stage st
+        const double b2r = u2r + p3r, b2i = u2i + p3i, b3r = u2r - p3r, b3i = u2i - p3i;
+        const double q2r = w2r * b2r - w2i * b2i, q2i = w2r * b2i + w2i * b2r;               // stage st + 1: W^pos
+        // twiddle of the pair (i1, i3) is W_{4h}^{pos + h} = exp(-2 pi i (pos + h) / (4 h)): entry k2 + N/4 of the table
+        const double w3r = twr[PD(k2 + H / 2)], w3i = twi[PD(k2 + H / 2)];
+        const double q3r = w3r * b3r - w3i * b3i, q3i = w3r * b3i + w3i * b3r;
+        re[PD(i0)] = b0r + q2r; im[PD(i0)] = b0i + q2i;
+        re[PD(i2)] = b0r - q2r; im[PD(i2)] = b0i - q2i;
+        re[PD(i1)] = b1r + q3r; im[PD(i1)] = b1i + q3i;
+        re[PD(i3)] = b1r - q3r; im[PD(i3)] = b1i - q3i;
+      }
+      __syncthreads();
+    }
+    if (st < LOGH) {
+      const int half = 1 << st;
+      for (int b = t; b < H / 2; b += 256) {
+        const int pos = b & (half - 1);
+        const int i0 = ((b >> st) << (st + 1)) + pos, i1 = i0 + half;
+        const int tk = pos << (LOGN - 1 - st);               // exp(-2 pi i pos / (2 half)) in units of the N table
+        const double wr = twr[PD(tk)], wi = twi[PD(tk)];
+        const double xr = re[PD(i1)], xi = im[PD(i1)];
+        const double pr = wr * xr - wi * xi, pi = wr * xi + wi * xr;
+        const double ur = re[PD(i0)], ui = im[PD(i0)];
+        re[PD(i0)] = ur + pr; im[PD(i0)] = ui + pi;
+        re[PD(i1)] = ur - pr; im[PD(i1)] = ui - pi;
+      }
+      __syncthreads();
+    }
+    // split: X_k = E_k + W_N^k O_k,  E_k = (Z_k + conj Z_{H-k}) / 2,  O_k = -i (Z_k - conj Z_{H-k}) / 2,  k = 0 .. H
+    double* dst = a.logmag + ((size_t)w * a.maxframes + j) * (H + 1);
+    for (int k = k0 + t; k <= k1; k += 256) {
+      const int ka = k & (H - 1), kb = (H - k) & (H - 1);
+      const double zr = re[PD(ka)], zi = im[PD(ka)], cr = re[PD(kb)], ci = -im[PD(kb)];
+      const double er = 0.5 * (zr + cr), ei = 0.5 * (zi + ci);
+      const double dr = 0.5 * (zr - cr), di = 0.5 * (zi - ci);
+      const double orr = di, oi = -dr;                                  // -i (dr + i di)
+      const double wr = k == H ? -1.0 : twr[PD(k)], wi = k == H ? 0.0 : twi[PD(k)];
+      const double xr = er + (wr * orr - wi * oi), xi = ei + (wr * oi + wi * orr);
+      // |X|: no overflow / underflow guard needed at audio magnitudes (numpy's abs is hypot: same value to an ulp)
+      dst[k] = log(__dadd_rn(__dmul_rn(sqrt(xr * xr + xi * xi), a.scale), AVA_SPEC_EPS));
+    }
   }
-  double* dst = a.logmag + ((size_t)w * a.maxframes + j) * (N / 2 + 1);
-  for (int k = t; k <= N / 2; k += 256) dst[k] = log(__dadd_rn(__dmul_rn(hypot(re[k], im[k]), a.scale), AVA_SPEC_EPS));
 }
 
-// frame time j of a window: scipy's  arange(nperseg/2, ..., hop) / fs - (nperseg/2) / fs, then utils.py:75's + max(0, t1)
-__device__ __forceinline__ double frame_time(int j, const SpecArgs& a, double t_shift) {
-  const double half = 0.5 * (double)a.nperseg;
-  const double c = __ddiv_rn(half + (double)j * (double)a.nstep, a.fs);
-  return __dadd_rn(__dsub_rn(c, __ddiv_rn(half, a.fs)), t_shift);
-}
+#undef PD
 
 // utils.py:77-103 for one output pixel.  Linear B-spline evaluation in FITPACK's order (fpbspl: h0 = f (t[l+1] - x),
 // h1 = f (x - t[l]) with f = 1 / (t[l+1] - t[l]); fpbisp: sum over x then y of (c * hx) * hy), then interp2d's
@@ -160,9 +316,9 @@ __global__ __launch_bounds__(256) void spec_interp_kernel(const SpecArgs a) {
   if (m.nframes < 0) { *o = __builtin_nanf(""); return; }            // workspace too small for this window: loud
   const int K = a.nperseg / 2 + 1;
   const double x = a.target_times[(size_t)w * a.T + ti], y = a.target_freqs[fi];
-  // bin frequencies: rfftfreq(n, d) = arange(n/2 + 1) * (1 / (n d)), d = 1 / fs
-  const double val = __ddiv_rn(1.0, __dmul_rn((double)a.nperseg, __ddiv_rn(1.0, a.fs)));
-  const double xmin = frame_time(0, a, m.t_shift), xmax = frame_time(m.nframes - 1, a, m.t_shift);
+  const double* ft = a.ftimes + (size_t)w * a.maxframes;
+  const double val = a.fbin;                       // bin frequencies: rfftfreq(n, d) = arange(n/2 + 1) * (1 / (n d)), d = 1 / fs
+  const double xmin = ft[0], xmax = ft[m.nframes - 1];
   const double ymin = 0.0, ymax = __dmul_rn((double)(K - 1), val);
   double v;
   if (x < xmin || x > xmax || y < ymin || y > ymax || !(x == x) || !(y == y)) {
@@ -170,13 +326,13 @@ __global__ __launch_bounds__(256) void spec_interp_kernel(const SpecArgs a) {
   } else {
     int l = (int)floor((x - xmin) * a.fs / (double)a.nstep);
     l = l < 0 ? 0 : (l > m.nframes - 2 ? m.nframes - 2 : l);
-    while (l > 0 && x < frame_time(l, a, m.t_shift)) --l;
-    while (l < m.nframes - 2 && x >= frame_time(l + 1, a, m.t_shift)) ++l;
+    while (l > 0 && x < ft[l]) --l;
+    while (l < m.nframes - 2 && x >= ft[l + 1]) ++l;
     int q = (int)floor(y / val);
     q = q < 0 ? 0 : (q > K - 2 ? K - 2 : q);
     while (q > 0 && y < __dmul_rn((double)q, val)) --q;
     while (q < K - 2 && y >= __dmul_rn((double)(q + 1), val)) ++q;
-    const double tl = frame_time(l, a, m.t_shift), tr = frame_time(l + 1, a, m.t_shift);
+    const double tl = ft[l], tr = ft[l + 1];
     const double fx = __ddiv_rn(1.0, __dsub_rn(tr, tl));
     const double hx0 = __dmul_rn(fx, __dsub_rn(tr, x)), hx1 = __dmul_rn(fx, __dsub_rn(x, tl));
     const double yl = __dmul_rn((double)q, val), yr = __dmul_rn((double)(q + 1), val);
@@ -209,7 +365,8 @@ static bool spec_shape_ok(int nperseg, int noverlap) {
 extern "C" size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap) {
   if (n <= 0 || max_samples <= 0 || !spec_shape_ok(nperseg, noverlap)) return 0;
   const size_t frames = (size_t)frames_for(max_samples, nperseg - noverlap);
-  return 256 + (size_t)n * sizeof(SpecMeta) + (size_t)n * frames * (size_t)(nperseg / 2 + 1) * sizeof(double);
+  return 256 + 16 + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15) + (size_t)nperseg * sizeof(double) +
+         (size_t)n * frames * sizeof(double) + (size_t)n * frames * (size_t)(nperseg / 2 + 1) * sizeof(double);
 }
 
 extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int64_t* file_off, const int64_t* file_len,
@@ -231,16 +388,21 @@ extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int6
   a.t1 = t1; a.t2 = t2; a.target_times = target_times; a.target_freqs = target_freqs; a.window = window;
   char* base = reinterpret_cast<char*>(ws);
   base += (256 - (reinterpret_cast<uintptr_t>(base) & 255)) & 255;
+  a.krange = reinterpret_cast<int*>(base);
+  base += 16;
   a.meta = reinterpret_cast<SpecMeta*>(base);
-  a.logmag = reinterpret_cast<double*>(base + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15));
+  a.twiddle = reinterpret_cast<double*>(base + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15));
+  a.ftimes = a.twiddle + nperseg;
+  a.logmag = a.ftimes + (size_t)n * frames_for(max_samples, nperseg - noverlap);
   a.out = out; a.out_max = out_max;
   a.fs = fs; a.scale = scale; a.spec_min = spec_min; a.range = spec_max - spec_min; a.fill_value = fill_value;
+  a.fbin = 1.0 / ((double)nperseg * (1.0 / fs));      // host IEEE arithmetic: the very operations of scipy.fft.rfftfreq
   a.n = n; a.nperseg = nperseg; a.nstep = nperseg - noverlap; a.maxframes = frames_for(max_samples, a.nstep);
   a.F = F; a.T = T; a.dtype = audio_dtype; a.remove_dc = remove_dc;
   hipStream_t st = to_stream(s);
-  hipLaunchKernelGGL(spec_prep_kernel, dim3(n), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(spec_prep_kernel, dim3(n), dim3(AVA_SPEC_PREP_T), 0, st, a);
   AVA_CHECK_LAUNCH();
-  const dim3 fgrid(a.maxframes, n);
+  const dim3 fgrid(a.maxframes < 24 ? a.maxframes : 24, n);      // a workgroup strides over its window's needed frames
   switch (nperseg) {
     case 64: hipLaunchKernelGGL(spec_stft_kernel<6>, fgrid, dim3(256), 0, st, a); break;
     case 128: hipLaunchKernelGGL(spec_stft_kernel<7>, fgrid, dim3(256), 0, st, a); break;

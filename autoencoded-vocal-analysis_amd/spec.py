@@ -77,6 +77,35 @@ class DeviceAudio:
 
 
 _CONST_CACHE = {}
+_STAGING = {}       # device -> [ring of (page-locked uint8 buffer, event of the last DMA out of it)], next slot
+_WORKSPACE = {}     # (device, stream) -> scratch tensor; reuse is safe in stream order
+
+
+def _staging(dev, nbytes):
+    """next slot of the per-device ring of page-locked parameter buffers (waits for the DMA that last read it)"""
+    ring = _STAGING.setdefault(str(dev), [[], 0])
+    k = ring[1] % 4
+    ring[1] += 1
+    if len(ring[0]) <= k:
+        ring[0].append([None, None])
+    slot = ring[0][k]
+    if slot[0] is None or slot[0].numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8)
+        cuda = torch.device(dev).type == "cuda"
+        slot[0] = buf.pin_memory() if cuda else buf
+        slot[1] = torch.cuda.Event() if cuda else None
+    elif slot[1] is not None:
+        slot[1].synchronize()
+    return slot
+
+
+def _workspace(dev, nbytes):
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if torch.device(dev).type == "cuda" else 0)
+    ws = _WORKSPACE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+        _WORKSPACE[key] = ws
+    return ws
 
 
 def _stft_constants(nperseg, device):
@@ -129,14 +158,20 @@ def get_spec_batch(audio, file_idx, t1, t2, p, fs, target_times, target_freqs=No
     max_samples = int((s2 - s1).max())
     lib, dev = _lib.load(), audio.device
     window, scale = _stft_constants(nperseg, dev)
-    # one small pinned upload per batch: [file_idx | t1 | t2 | target_freqs | target_times] as float64
-    host = np.concatenate([file_idx.astype(np.float64), t1, t2, target_freqs, target_times.reshape(-1)])
-    params = torch.from_numpy(host).to(dev, non_blocking=True)
-    fidx = params[:n].to(torch.int32)
-    d_t1, d_t2 = params[n:2 * n], params[2 * n:3 * n]
-    d_tf, d_tt = params[3 * n:3 * n + F], params[3 * n + F:]
+    # one small upload per batch out of a page-locked ring: [t1 | t2 | target_freqs | target_times] float64, file_idx int32
+    nd = 2 * n + F + n * T
+    slot = _staging(dev, 8 * nd + 4 * n)
+    hd = slot[0][:8 * nd].numpy().view(np.float64)
+    hd[:n] = t1; hd[n:2 * n] = t2; hd[2 * n:2 * n + F] = target_freqs; hd[2 * n + F:] = target_times.reshape(-1)
+    slot[0][8 * nd:8 * nd + 4 * n].numpy().view(np.int32)[:] = file_idx
+    params = slot[0][:8 * nd + 4 * n].to(dev, non_blocking=True)
+    if slot[1] is not None:
+        slot[1].record()
+    pd = params[:8 * nd].view(torch.float64)
+    fidx = params[8 * nd:].view(torch.int32)
+    d_t1, d_t2, d_tf, d_tt = pd[:n], pd[n:2 * n], pd[2 * n:2 * n + F], pd[2 * n + F:]
     nbytes = lib.ava_spec_workspace_bytes(n, max_samples, nperseg, noverlap)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _workspace(dev, nbytes)
     out = torch.empty((n, F, T), dtype=torch.float32, device=dev)
     omax = torch.empty(n, dtype=torch.float32, device=dev) if return_max else None
     rc = lib.ava_get_spec_batch(audio.samples.data_ptr(), audio.code, audio.file_off.data_ptr(), audio.file_len.data_ptr(),
@@ -144,7 +179,7 @@ def get_spec_batch(audio, file_idx, t1, t2, p, fs, target_times, target_freqs=No
                                 float(fs), nperseg, noverlap, window.data_ptr(), scale, d_tf.data_ptr(), F, T,
                                 float(p['spec_min_val']), float(p['spec_max_val']), float(fill_value),
                                 1 if remove_dc_offset else 0, out.data_ptr(), omax.data_ptr() if return_max else None,
-                                ws.data_ptr(), nbytes, _lib.stream())
+                                ws.data_ptr(), ws.numel(), _lib.stream())
     _lib.check(rc, "ava_get_spec_batch")
     return (out, omax) if return_max else out
 

@@ -144,6 +144,53 @@ def loader_path(model, B, z_dim, shape):
     return out
 
 
+def shotgun_path(model, B):
+    """SURVEY 8 f4 (never `value`): VAE.train_epoch fed by spectrograms computed ON THE DEVICE from HBM-resident audio
+    (ava_amd.spec.DeviceWindowLoader: the reference's FixedWindowDataset + get_spec + DataLoader workers,
+    window_vae_dataset.py:102-256, preprocessing/utils.py:18-110), with the finch_window_mwe.py parameters; beside it
+    the oracle's get_spec on one host core, which is what one DataLoader worker of the reference does per item."""
+    import contextlib
+    import torch
+    from ava_amd import synthetic as syn
+    from ava_amd import spec as sp
+    from oracle import spec_oracle as so
+    p = dict(syn.FINCH_PARAMS)
+    nb = 16
+    audio, rois = syn.recordings(n_files=4, fs=p['fs'], seconds=20.0)
+    ds = sp.DeviceWindowDataset.from_arrays(audio, p['fs'], rois, p, dataset_length=B * nb)
+    loader = sp.DeviceWindowLoader(ds, batch_size=B)
+    idx = list(range(B))
+    for _ in range(3):
+        ds[idx]
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nb):
+        ds[idx]
+    e1.record()
+    torch.cuda.synchronize()
+    spec_ms = e0.elapsed_time(e1) / nb
+    with contextlib.redirect_stdout(sys.stderr):
+        model.train_epoch(loader)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            model.train_epoch(loader)
+        torch.cuda.synchronize()
+    rate = 2 * B * nb / (time.perf_counter() - t0)
+    oracle = so.FixedWindowOracle(audio, p['fs'], rois, p)
+    oracle.getitem(list(range(8)), seed=1)
+    n_cpu = 400
+    t0 = time.perf_counter()
+    oracle.getitem(list(range(n_cpu)), seed=2)
+    cpu_rate = n_cpu / (time.perf_counter() - t0)
+    return {"unit": "spectrograms/s", "workload": "finch_window_mwe.py parameters: 0.12 s windows at 32 kHz, nperseg 512 / noverlap 256, "
+            "batch %d, spectrograms made on the device from HBM-resident int16 audio" % B,
+            "train_epoch_fed_by_device_spectrograms": round(rate, 1),
+            "get_spec_batch_ms_per_batch": round(spec_ms, 4), "get_spec_batch_rate": round(B / (1e-3 * spec_ms), 1),
+            "cpu_get_spec_one_core": round(cpu_rate, 1), "cpu_sample": "%d windows through oracle/spec_oracle.py" % n_cpu}
+
+
 def physical_cores():
     """physical host cores (unique (package, core) pairs); falls back to os.cpu_count()"""
     try:
@@ -394,6 +441,8 @@ def main():
     if world == 1 and not args.no_loader_path:
         model._ensure(B)
         out["loader_path"] = loader_path(model, B, args.z_dim, (H, W))
+        if (H, W) == (128, 128):
+            out["shotgun_path"] = shotgun_path(model, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, args.z_dim, args.cpu_protocol, (H, W))
     if rank == 0:

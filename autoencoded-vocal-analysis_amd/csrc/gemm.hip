@@ -456,11 +456,20 @@ static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
   // small outputs with a short K (fc2, fc3x, fc6, fc7 and their dX): 64x64 tiles give 4x the workgroups per split,
   // so fewer, longer splits and a quarter of the slab traffic (measured -3.5 us per product at batch 256)
   if ((size_t)M * N <= 262144 && K <= 2048) *bm = 64;
+  // batch-sized M against a wide N (fc8 forward, fc1 dX: 256 x 8192, K = 1024): 64x64 tiles fill the chip (512
+  // workgroups) WITHOUT split-K, so no slabs and no reduce launch, bias / activation / mask in the epilogue
+  // (same-box: 59.2 -> 52.4 us and 65.4 -> 57.0 us including the reduce kernel they no longer need)
+  const bool wide = M <= 256 && K >= 512 && ceil_div(M, 64) * ceil_div(N, 64) >= 384;
+  // ... and against a long K (fc1 forward, fc8 dX: 256 x 1024, K = 8192): 64 tiles x 16 splits (59.1 -> 54.1 us, 16 MB
+  // of slabs instead of 32)
+  const bool deep = M <= 256 && K >= 4096 && (size_t)M * N <= 262144;
+  if (wide || deep) *bm = 64;
+  { const char* e = ava_env("AVA_GEMM_BM"); if (e && M <= 256) *bm = atoi(e); }      // lab: tile size for the M = batch shapes
   const int tiles = ceil_div(M, *bm) * ceil_div(N, *bm);
   int s = 1;
   if (tiles < 384) {
     // aim at >= 2 workgroups per CU so that one workgroup's loads overlap another's MFMAs
-    s = ceil_div(512, tiles);
+    s = ceil_div(deep ? 1024 : 512, tiles);
     const int max_s = K / 32 > 0 ? K / 32 : 1;      // at least 2 K-steps per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -528,7 +537,8 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
     if (bk32 && klen % 32 == 0) launch_gemm<128, 32, true>(g, a_kmajor, b_kmajor, grid, st);
     else launch_gemm<128, 16, true>(g, a_kmajor, b_kmajor, grid, st);
   } else {
-    launch_gemm<64, 16, true>(g, a_kmajor, b_kmajor, grid, st);
+    if (bk32 && klen % 32 == 0 && klen >= 512) launch_gemm<64, 32, true>(g, a_kmajor, b_kmajor, grid, st);   // the long-K 64-tile shapes
+    else launch_gemm<64, 16, true>(g, a_kmajor, b_kmajor, grid, st);
   }
   AVA_CHECK_LAUNCH();
   if (splits > 1) {

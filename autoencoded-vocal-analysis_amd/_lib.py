@@ -94,9 +94,9 @@ SIGNATURES = {
     "ava_mmd2": (_i, [_p, _i, _p, _i, _p, _i, _d, _p, _p, _sz, _p]),
     "ava_mmd2_linear": (_i, [_p, _i, _p, _p, _i, _d, _p, _p, _sz, _p]),
     "ava_pair_sqdist": (_i, [_p, _i, _p, _p, _i, _p, _p]),
-    "ava_spec_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ava_spec_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "ava_get_spec_batch": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _d, _i, _i, _p, _d, _p, _i, _i, _d, _d, _d, _i,
-                                _p, _p, _p, _sz, _p]),
+                                _i, _i, _d, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

@@ -47,6 +47,9 @@ struct SpecArgs {
   double* logmag;                // [n][maxframes][nperseg/2 + 1]
   float* out;                    // [n][F][T]
   float* out_max;                // [n] or null
+  double* vals;                  // [n][F*T]: clipped fp64 spectrograms handed to spec_normalize_kernel (normalize only)
+  double q_gamma;                // within_syll_normalize: np.quantile's interpolation weight ...
+  int q_lo, normalize;           // ... between the order statistics q_lo and q_lo + 1 (0-based)
   double fs, scale, spec_min, range, fill_value, fbin;    // fbin: rfftfreq's 1 / (nperseg * (1 / fs))
   int n, maxframes, nperseg, nstep, F, T, dtype, remove_dc;
 };
@@ -350,9 +353,94 @@ __global__ __launch_bounds__(256) void spec_interp_kernel(const SpecArgs a) {
   v = __dsub_rn(v, a.spec_min);
   v = __ddiv_rn(v, a.range);                                         // utils.py:101-102
   v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+  if (a.normalize) {                                                 // utils.py:104-108 follow in spec_normalize_kernel
+    a.vals[(size_t)w * a.F * a.T + p] = v;
+    return;
+  }
   const float vf = (float)v;
   *o = vf;
   if (a.out_max != nullptr && vf > 0.f) atomicMax(reinterpret_cast<int*>(a.out_max + w), __float_as_int(vf));
+}
+
+// within_syll_normalize (utils.py:104-108): spec -= np.quantile(spec, q); spec[spec < 0] = 0; spec /= max(spec) + EPSILON.
+// One workgroup per window.  The quantile is numpy's default ('linear'): a[lo] + (a[lo+1] - a[lo]) * gamma with lo and
+// gamma from the host (numpy's own expression for the virtual index), evaluated with numpy's two-sided lerp.  a[lo] is
+// found by an MSB-first radix select over the bit patterns (the values are in [0, 1], so the unsigned order of the
+// patterns is the numeric order; counts are integers: deterministic), a[lo+1] from one more counting pass.
+#define AVA_SPEC_NORM_T 1024
+__global__ __launch_bounds__(AVA_SPEC_NORM_T) void spec_normalize_kernel(const SpecArgs a) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long sh_prefix, sh_next;
+  __shared__ unsigned sh_k, sh_le;
+  __shared__ double sh_max[AVA_SPEC_NORM_T / 64];
+  const int w = blockIdx.x, t = threadIdx.x;
+  const SpecMeta m = a.meta[w];
+  if (m.nframes <= 0) return;                                        // zeros (or the NaN marker) were written already
+  const int n = a.F * a.T;
+  const double* v = a.vals + (size_t)w * n;
+  unsigned long long prefix = 0;
+  unsigned k = (unsigned)a.q_lo;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+    for (int i = t; i < n; i += AVA_SPEC_NORM_T) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+      if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255ull], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned c = 0, b = 0;
+      for (; b < 256; ++b) {
+        if (c + hist[b] > k) break;
+        c += hist[b];
+      }
+      sh_prefix = prefix | ((unsigned long long)b << shift);
+      sh_k = k - c;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    k = sh_k;
+    __syncthreads();
+  }
+  const double alo = __longlong_as_double((long long)prefix);
+  // a[lo + 1]: alo again when more than lo + 1 values are <= alo, else the smallest value above it; and the maximum
+  if (t == 0) { sh_le = 0; sh_next = ~0ull; }
+  __syncthreads();
+  unsigned le = 0;
+  unsigned long long nxt = ~0ull;
+  double mx = 0.0;
+  for (int i = t; i < n; i += AVA_SPEC_NORM_T) {
+    const double x = v[i];
+    const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+    if (key <= prefix) ++le; else if (key < nxt) nxt = key;
+    mx = x > mx ? x : mx;
+  }
+  atomicAdd(&sh_le, le);
+  atomicMin(&sh_next, nxt);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
+  if ((t & 63) == 0) sh_max[t >> 6] = mx;
+  __syncthreads();
+  for (int i = 0; i < AVA_SPEC_NORM_T / 64; ++i) mx = sh_max[i] > mx ? sh_max[i] : mx;
+  const double ahi = (sh_le >= (unsigned)a.q_lo + 2u || a.q_lo + 1 >= n) ? alo : __longlong_as_double((long long)sh_next);
+  // numpy's _lerp: a + (b - a) * t, replaced by b - (b - a) * (1 - t) where t >= 0.5
+  const double diff = __dsub_rn(ahi, alo);
+  double qv = __dadd_rn(alo, __dmul_rn(diff, a.q_gamma));
+  if (a.q_gamma >= 0.5) qv = __dsub_rn(ahi, __dmul_rn(diff, __dsub_rn(1.0, a.q_gamma)));
+  double top = __dsub_rn(mx, qv);                                    // max of the shifted, floored spectrogram
+  top = top < 0.0 ? 0.0 : top;
+  const double den = __dadd_rn(top, AVA_SPEC_EPS);
+  float fmax = 0.f;
+  float* o = a.out + (size_t)w * n;
+  for (int i = t; i < n; i += AVA_SPEC_NORM_T) {
+    double x = __dsub_rn(v[i], qv);
+    x = x < 0.0 ? 0.0 : x;
+    const float f = (float)__ddiv_rn(x, den);
+    o[i] = f;
+    fmax = f > fmax ? f : fmax;
+  }
+  if (a.out_max != nullptr && fmax > 0.f) atomicMax(reinterpret_cast<int*>(a.out_max + w), __float_as_int(fmax));
 }
 
 static int frames_for(int max_samples, int nstep) { return (max_samples + nstep - 1) / nstep + 1; }
@@ -362,26 +450,28 @@ static bool spec_shape_ok(int nperseg, int noverlap) {
   return noverlap >= 0 && noverlap < nperseg;
 }
 
-extern "C" size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap) {
-  if (n <= 0 || max_samples <= 0 || !spec_shape_ok(nperseg, noverlap)) return 0;
+extern "C" size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap, int F, int T, int normalize) {
+  if (n <= 0 || max_samples <= 0 || F <= 0 || T <= 0 || !spec_shape_ok(nperseg, noverlap)) return 0;
   const size_t frames = (size_t)frames_for(max_samples, nperseg - noverlap);
   return 256 + 16 + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15) + (size_t)nperseg * sizeof(double) +
-         (size_t)n * frames * sizeof(double) + (size_t)n * frames * (size_t)(nperseg / 2 + 1) * sizeof(double);
+         (size_t)n * frames * sizeof(double) + (size_t)n * frames * (size_t)(nperseg / 2 + 1) * sizeof(double) +
+         (normalize ? (size_t)n * F * T * sizeof(double) : 0);
 }
 
 extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int64_t* file_off, const int64_t* file_len,
                                   const int32_t* file_idx, const double* t1, const double* t2, const double* target_times,
                                   int n, int max_samples, double fs, int nperseg, int noverlap, const double* window,
                                   double scale, const double* target_freqs, int F, int T, double spec_min, double spec_max,
-                                  double fill_value, int remove_dc, float* out, float* out_max, void* ws, size_t ws_bytes,
-                                  ava_stream_t s) {
+                                  double fill_value, int remove_dc, int normalize, int q_lo, double q_gamma, float* out,
+                                  float* out_max, void* ws, size_t ws_bytes, ava_stream_t s) {
   if (audio == nullptr || file_off == nullptr || file_len == nullptr || file_idx == nullptr || t1 == nullptr ||
       t2 == nullptr || target_times == nullptr || window == nullptr || target_freqs == nullptr || out == nullptr)
     return AVA_EINVAL;
   if (n <= 0 || F <= 0 || T <= 0 || max_samples <= 0 || !(fs > 0.0) || !spec_shape_ok(nperseg, noverlap)) return AVA_EINVAL;
   if (audio_dtype < AVA_AUDIO_I16 || audio_dtype > AVA_AUDIO_F64) return AVA_EINVAL;
   if (!(spec_max != spec_min)) return AVA_EINVAL;
-  if (ws == nullptr || ws_bytes < ava_spec_workspace_bytes(n, max_samples, nperseg, noverlap)) return AVA_EWORKSPACE;
+  if (normalize && (q_lo < 0 || q_lo >= F * T || !(q_gamma >= 0.0 && q_gamma <= 1.0))) return AVA_EINVAL;
+  if (ws == nullptr || ws_bytes < ava_spec_workspace_bytes(n, max_samples, nperseg, noverlap, F, T, normalize)) return AVA_EWORKSPACE;
   SpecArgs a;
   a.audio = audio; a.file_off = reinterpret_cast<const long long*>(file_off);
   a.file_len = reinterpret_cast<const long long*>(file_len); a.file_idx = file_idx;
@@ -394,6 +484,8 @@ extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int6
   a.twiddle = reinterpret_cast<double*>(base + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15));
   a.ftimes = a.twiddle + nperseg;
   a.logmag = a.ftimes + (size_t)n * frames_for(max_samples, nperseg - noverlap);
+  a.vals = a.logmag + (size_t)n * frames_for(max_samples, nperseg - noverlap) * (size_t)(nperseg / 2 + 1);
+  a.normalize = normalize ? 1 : 0; a.q_lo = q_lo; a.q_gamma = q_gamma;
   a.out = out; a.out_max = out_max;
   a.fs = fs; a.scale = scale; a.spec_min = spec_min; a.range = spec_max - spec_min; a.fill_value = fill_value;
   a.fbin = 1.0 / ((double)nperseg * (1.0 / fs));      // host IEEE arithmetic: the very operations of scipy.fft.rfftfreq
@@ -414,5 +506,9 @@ extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int6
   AVA_CHECK_LAUNCH();
   hipLaunchKernelGGL(spec_interp_kernel, dim3(ceil_div(F * T, 256), n), dim3(256), 0, st, a);
   AVA_CHECK_LAUNCH();
+  if (normalize) {
+    hipLaunchKernelGGL(spec_normalize_kernel, dim3(n), dim3(AVA_SPEC_NORM_T), 0, st, a);
+    AVA_CHECK_LAUNCH();
+  }
   return AVA_OK;
 }

@@ -13,8 +13,8 @@ order, so that a seeded call picks the very windows the reference picks), and th
 produced by three launches (``csrc/spec.hip``) straight into the fp32 ``[batch, freq, time]`` tensor the VAE step
 consumes: no CPU workers, no host-to-device copy of spectrograms.
 
-Not covered: ``within_syll_normalize`` (a per-spectrogram quantile; off in every example script) raises
-``NotImplementedError``; ``nperseg`` must be a power of two in 64..2048.  There is no CPU fallback.
+Not covered: ``nperseg`` must be a power of two in 64..2048 (``NotImplementedError`` otherwise).  There is no CPU
+fallback.
 """
 import warnings
 
@@ -127,8 +127,6 @@ def get_spec_batch(audio, file_idx, t1, t2, p, fs, target_times, target_freqs=No
     offset in seconds; ``target_times`` [n, T] the interpolated times of each window (the shotgun dataset passes
     ``linspace(onset, offset, T)``, window_vae_dataset.py:218-219).  Returns the fp32 device tensor ``[n, F, T]`` (and
     the per-window maxima ``[n]`` with ``return_max``).  Enqueued on the current stream; nothing synchronises."""
-    if p.get('within_syll_normalize', False):
-        raise NotImplementedError("within_syll_normalize is not available in the device path")
     t1 = np.ascontiguousarray(t1, dtype=np.float64).reshape(-1)
     t2 = np.ascontiguousarray(t2, dtype=np.float64).reshape(-1)
     n = t1.shape[0]
@@ -170,7 +168,21 @@ def get_spec_batch(audio, file_idx, t1, t2, p, fs, target_times, target_freqs=No
     pd = params[:8 * nd].view(torch.float64)
     fidx = params[8 * nd:].view(torch.int32)
     d_t1, d_t2, d_tf, d_tt = pd[:n], pd[n:2 * n], pd[2 * n:2 * n + F], pd[2 * n + F:]
-    nbytes = lib.ava_spec_workspace_bytes(n, max_samples, nperseg, noverlap)
+    normalize, q_lo, q_gamma = 0, 0, 0.0
+    if p.get('within_syll_normalize', False):                                      # utils.py:104-108
+        q = float(p['normalize_quantile'])
+        if not 0.0 <= q <= 1.0:
+            raise ValueError("Quantiles must be in the range [0, 1]")               # np.quantile's own check
+        # numpy's 'linear' method: virtual index n q + (alpha + q (1 - alpha - beta)) - 1 with alpha = beta = 1
+        cnt = F * T
+        virtual = cnt * q + (1 + q * (1 - 1 - 1)) - 1
+        if virtual >= cnt - 1:
+            q_lo, q_gamma = cnt - 1, 0.0
+        else:
+            q_lo = int(np.floor(virtual))
+            q_gamma = float(virtual - np.floor(virtual))
+        normalize = 1
+    nbytes = lib.ava_spec_workspace_bytes(n, max_samples, nperseg, noverlap, F, T, normalize)
     ws = _workspace(dev, nbytes)
     out = torch.empty((n, F, T), dtype=torch.float32, device=dev)
     omax = torch.empty(n, dtype=torch.float32, device=dev) if return_max else None
@@ -178,7 +190,8 @@ def get_spec_batch(audio, file_idx, t1, t2, p, fs, target_times, target_freqs=No
                                 fidx.data_ptr(), d_t1.data_ptr(), d_t2.data_ptr(), d_tt.data_ptr(), n, max_samples,
                                 float(fs), nperseg, noverlap, window.data_ptr(), scale, d_tf.data_ptr(), F, T,
                                 float(p['spec_min_val']), float(p['spec_max_val']), float(fill_value),
-                                1 if remove_dc_offset else 0, out.data_ptr(), omax.data_ptr() if return_max else None,
+                                1 if remove_dc_offset else 0, normalize, q_lo, q_gamma, out.data_ptr(),
+                                omax.data_ptr() if return_max else None,
                                 ws.data_ptr(), ws.numel(), _lib.stream())
     _lib.check(rc, "ava_get_spec_batch")
     return (out, omax) if return_max else out

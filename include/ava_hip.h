@@ -280,15 +280,18 @@ int ava_pair_sqdist(const double* latent, int z, const int64_t* a, const int64_t
  *   spec_min, spec_max    p['spec_min_val'], p['spec_max_val'] (utils.py:100-103); fill_value utils.py:19
  *   out [n][F][T] fp32    the clipped spectrograms; out_max [n] or NULL: their maxima (min_spec_val test,
  *                         window_vae_dataset.py:229-231)
- * nperseg: a power of two in 64..2048, 0 <= noverlap < nperseg; within_syll_normalize is not covered.
+ *   normalize, q_lo,      p['within_syll_normalize'] (utils.py:104-108): subtract np.quantile(spec, p['normalize_quantile']),
+ *   q_gamma               floor at 0, divide by max + 1e-12; the quantile is a[q_lo] + (a[q_lo+1] - a[q_lo]) * q_gamma over the
+ *                         sorted F*T values (numpy's 'linear' method: q_lo and q_gamma as numpy derives them from q and F*T)
+ * nperseg: a power of two in 64..2048, 0 <= noverlap < nperseg.
  * All arithmetic is fp64.  Windows the reference answers with zeros (utils.py:68-69) come out as zeros. */
-size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap);
+size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap, int F, int T, int normalize);
 int ava_get_spec_batch(const void* audio, int audio_dtype, const int64_t* file_off, const int64_t* file_len,
                        const int32_t* file_idx, const double* t1, const double* t2, const double* target_times,
                        int n, int max_samples, double fs, int nperseg, int noverlap, const double* window,
                        double scale, const double* target_freqs, int F, int T, double spec_min, double spec_max,
-                       double fill_value, int remove_dc, float* out, float* out_max, void* ws, size_t ws_bytes,
-                       ava_stream_t s);
+                       double fill_value, int remove_dc, int normalize, int q_lo, double q_gamma, float* out,
+                       float* out_max, void* ws, size_t ws_bytes, ava_stream_t s);
 
 #ifdef __cplusplus
 }

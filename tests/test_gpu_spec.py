@@ -131,13 +131,36 @@ def test_get_spec_mirror_defaults_and_options():
     with pytest.raises(AssertionError):
         sp.get_spec(0.3, 0.3, audio, p, fs=fs)
     q = dict(p)
-    q['within_syll_normalize'] = True
-    with pytest.raises(NotImplementedError):
-        sp.get_spec(0.21, 0.39, audio, q, fs=fs)
-    q = dict(p)
     q['nperseg'] = 500
     with pytest.raises(NotImplementedError):
         sp.get_spec(0.21, 0.39, audio, q, fs=fs)
+
+
+@pytest.mark.parametrize("quantile", [0.0, 0.25, 0.5, 0.9, 0.99993, 1.0])
+def test_within_syll_normalize(quantile):
+    """utils.py:104-108: subtract np.quantile(spec, q) (numpy's default linear method), floor at zero, divide by the
+    maximum + 1e-12; a window the reference answers with zeros stays zeros"""
+    from ava_amd import spec as sp
+    p = dict(syn.FINCH_PARAMS)
+    p.update(within_syll_normalize=True, normalize_quantile=quantile, spec_min_val=1.0)
+    fs, T = p['fs'], p['num_time_bins']
+    audio, _ = syn.recordings(n_files=2, fs=fs, seconds=1.0)
+    on = np.array([0.1, 0.33, 0.5, 0.71, 5.0])
+    off = on + p['window_length']
+    fidx = [0, 1, 0, 1, 0]
+    t1, t2 = np.maximum(0.0, on - 0.05), off + 0.05
+    tts = np.linspace(on, off, T, axis=-1)
+    dev, mx = sp.get_spec_batch(sp.DeviceAudio(audio), fidx, t1, t2, p, fs, tts, return_max=True)
+    want = _oracle_batch(audio, fidx, t1, t2, p, fs, tts)
+    if quantile <= 0.9:                    # (at the saturated top quantiles everything is floored to zero)
+        assert want[:4].max() > 0.99 and (want[:4] > 0).mean() > 0.01
+    _check(dev, want)
+    assert not dev[4].any().item()
+    assert np.allclose(mx.cpu().numpy(), want.reshape(5, -1).max(axis=1).astype(np.float32), atol=ULP)
+    with pytest.raises(ValueError):
+        q = dict(p)
+        q['normalize_quantile'] = 1.5
+        sp.get_spec_batch(sp.DeviceAudio(audio), fidx, t1, t2, q, fs, tts)
 
 
 @pytest.mark.parametrize("name", ["finch", "mouse"])
@@ -208,9 +231,10 @@ def test_loader_feeds_the_train_step_on_the_device():
 def test_c_abi_argument_checks():
     from ava_amd import _lib
     lib = _lib.load()
-    assert lib.ava_spec_workspace_bytes(4, 8000, 500, 250) == 0
-    assert lib.ava_spec_workspace_bytes(4, 8000, 512, 512) == 0
-    nbytes = lib.ava_spec_workspace_bytes(4, 8000, 512, 256)
+    assert lib.ava_spec_workspace_bytes(4, 8000, 500, 250, 16, 16, 0) == 0
+    assert lib.ava_spec_workspace_bytes(4, 8000, 512, 512, 16, 16, 0) == 0
+    nbytes = lib.ava_spec_workspace_bytes(4, 8000, 512, 256, 16, 16, 0)
+    assert lib.ava_spec_workspace_bytes(4, 8000, 512, 256, 16, 16, 1) == nbytes + 4 * 256 * 8
     assert nbytes > 4 * 33 * 257 * 8
     dev = torch.device("cuda")
     audio = torch.zeros(16000, dtype=torch.int16, device=dev)
@@ -225,11 +249,11 @@ def test_c_abi_argument_checks():
     out = torch.empty(4, 16, 16, device=dev)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
-    def call(nperseg=512, noverlap=256, wsb=nbytes, smax=6.5, dtype=0, n=4):
+    def call(nperseg=512, noverlap=256, wsb=nbytes, smax=6.5, dtype=0, n=4, norm=0, q_lo=0, gamma=0.0):
         return lib.ava_get_spec_batch(audio.data_ptr(), dtype, off.data_ptr(), ln.data_ptr(), fidx.data_ptr(), t1.data_ptr(),
                                       t2.data_ptr(), tt.data_ptr(), n, 8000, 32000.0, nperseg, noverlap, win.data_ptr(),
-                                      1.0 / 512, tf.data_ptr(), 16, 16, 2.0, smax, -1e12, 1, out.data_ptr(), None,
-                                      ws.data_ptr(), wsb, _lib.stream())
+                                      1.0 / 512, tf.data_ptr(), 16, 16, 2.0, smax, -1e12, 1, norm, q_lo, gamma,
+                                      out.data_ptr(), None, ws.data_ptr(), wsb, _lib.stream())
     assert call() == 0
     torch.cuda.synchronize()
     assert not out.any().item()                # silence: log(1e-12) is far below spec_min_val
@@ -239,3 +263,6 @@ def test_c_abi_argument_checks():
     assert call(dtype=7) == -1
     assert call(n=0) == -1
     assert call(wsb=nbytes // 2) == -3
+    assert call(norm=1) == -3                  # the normalising variant needs the larger workspace
+    assert call(norm=1, q_lo=256) == -1
+    assert call(norm=1, gamma=1.5) == -1

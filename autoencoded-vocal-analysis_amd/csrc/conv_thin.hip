@@ -449,8 +449,16 @@ __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs 
     row[THIN_IC - 1] = 0.f;
   }
   float ca[4], cb[4];
+  if (a.fin.acc != nullptr) {               // BatchNorm of the input: sums accumulated by the producer (bn_acc.h), finalised here
+    __shared__ float coef[96];
+    __shared__ double accvals[64];
+    bn_coef_from_acc(coef, accvals, a.fin, 0);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) { ca[c] = a.pa[4 * h + c]; cb[c] = a.pb[4 * h + c]; }
+    for (int c = 0; c < 4; ++c) { ca[c] = coef[4 * h + c]; cb[c] = coef[32 + 4 * h + c]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ca[c] = a.pa[4 * h + c]; cb[c] = a.pb[4 * h + c]; }
+  }
   avaf2 w2[9][2];                                       // [tap][channel pair of this half], G is [9][8][1]
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -1117,8 +1125,16 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
     wt[(set * UP88_WSTRIDE + r) * 4 + co4] = exists ? a.G[((ky * 3 + kx) * 8 + ci) * 8 + 4 * sh + co4] : 0.f;
   }
   float sca[8], shf[8];
+  if (a.fin.acc != nullptr) {               // BatchNorm of the input: sums accumulated by the producer (bn_acc.h), finalised here
+    __shared__ float coef[96];
+    __shared__ double accvals[64];
+    bn_coef_from_acc(coef, accvals, a.fin, 0);
 #pragma unroll
-  for (int ci = 0; ci < 8; ++ci) { sca[ci] = ava_uniform(a.pa[ci]); shf[ci] = ava_uniform(a.pb[ci]); }   // scalar registers
+    for (int ci = 0; ci < 8; ++ci) { sca[ci] = ava_uniform(coef[ci]); shf[ci] = ava_uniform(coef[32 + ci]); }
+  } else {
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) { sca[ci] = ava_uniform(a.pa[ci]); shf[ci] = ava_uniform(a.pb[ci]); }   // scalar registers
+  }
   avaf2 bias2[2] = {avaf2{a.bias[4 * h], a.bias[4 * h + 1]}, avaf2{a.bias[4 * h + 2], a.bias[4 * h + 3]}};
   avaf2 s1[2] = {avaf2{0.f, 0.f}, avaf2{0.f, 0.f}}, s2[2] = {avaf2{0.f, 0.f}, avaf2{0.f, 0.f}};
   const float* wl = wt + ((px * 2 + h) * UP88_WSTRIDE) * 4;
@@ -1193,6 +1209,12 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
     if (lane < 2) red[wave][lane][i] = v;               // lane = h
   }
   __syncthreads();
+  if (t < 16 && a.acc_out != nullptr) {                    // sums accumulated for the consumer's prologue (bn_acc.h)
+    const int which = t >> 3, co = t & 7, hh = co >> 2, i = which * 4 + (co & 3);
+    bn_acc_add(a.acc_out, which * 32 + co, (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]));
+    return;
+  }
+  if (a.acc_out != nullptr) return;
   if (t < 16 && a.partials != nullptr) {
     const int which = t >> 3, co = t & 7, hh = co >> 2, i = which * 4 + (co & 3);
     a.partials[(size_t)blockIdx.x * 16 + t] = (red[0][hh][i] + red[1][hh][i]) + (red[2][hh][i] + red[3][hh][i]);

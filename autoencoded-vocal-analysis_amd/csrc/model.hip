@@ -540,7 +540,7 @@ static constexpr bool lab_skip_bn_fin() { return false; }
 // ---- BatchNorm sums accumulated in the producing kernel and finalised in the consumer's prologue (bn_acc.h) ----------
 // Forward: BatchNorm j (input of layer j) when layer j runs the wave-specialised / plain matrix-core forward kernel (the
 // consumer side) and its input comes from such a kernel, from conv1's packed-FMA kernel (j = 1) or from the
-// fc8 -> NHWC layout kernel (j = 7): j = 1..11.  Backward: BatchNorm j when the backward of layer j (fused kernel; j = 5:
+// fc8 -> NHWC layout kernel (j = 7), and the direct convt6 / convt7 kernels (j = 12, 13): j = 1..13.  Backward: BatchNorm j when the backward of layer j (fused kernel; j = 5:
 // the wave-specialised data-gradient kernel; j = 13: convt7's weight-gradient + sums kernel) hands over to the FUSED
 // backward of layer j-1: j = 13, 12, 11, 10, 5, 4, 3, 2.  The other 9 keep their finalisation launch (consumers:
 // convt6 / convt7 forward, the unfused 16x16 layers, bn8's layout kernel, conv1's backward, bn1's own gradient).
@@ -550,7 +550,8 @@ static bool acc_enabled(bool bwd) {
     const char* e = ava_env("AVA_BN_ACC");
     if (e != nullptr) return atoi(e);
     const char* f = ava_env("AVA_CONV_FUSED"); const char* w = ava_env("AVA_FUSED_WS"); const char* c = ava_env("AVA_CONV_IMPL");
-    return ((f && atoi(f) == 0) || (w && atoi(w) == 0) || c != nullptr) ? 0 : 1;     // kernel-selection switches: launches only
+    const char* td = ava_env("AVA_THIN_DIRECT"); const char* tw = ava_env("AVA_THIN_WS");
+    return ((f && atoi(f) == 0) || (w && atoi(w) == 0) || c != nullptr || td != nullptr || tw != nullptr) ? 0 : 1;     // kernel-selection switches: launches only
   }();
   (void)bwd;
   return on != 0;
@@ -561,7 +562,7 @@ static bool acc_enabled(bool bwd) {
 }
 static bool acc_pair_fwd(const ava_model* m, int j) {
   (void)m;
-  return acc_enabled(false) && ((j >= 1 && j <= 6) || (j >= 7 && j <= 11));
+  return acc_enabled(false) && ((j >= 1 && j <= 6) || (j >= 7 && j <= 13));
 }
 static bool acc_pair_bwd(const ava_model* m, int j) {
   (void)m;

@@ -541,9 +541,9 @@ static constexpr bool lab_skip_bn_fin() { return false; }
 // Forward: BatchNorm j (input of layer j) when layer j runs the wave-specialised / plain matrix-core forward kernel (the
 // consumer side) and its input comes from such a kernel, from conv1's packed-FMA kernel (j = 1) or from the
 // fc8 -> NHWC layout kernel (j = 7), and the direct convt6 / convt7 kernels (j = 12, 13): j = 1..13.  Backward: BatchNorm j when the backward of layer j (fused kernel; j = 5:
-// the wave-specialised data-gradient kernel; j = 13: convt7's weight-gradient + sums kernel) hands over to the FUSED
-// backward of layer j-1: j = 13, 12, 11, 10, 5, 4, 3, 2.  The other 9 keep their finalisation launch (consumers:
-// convt6 / convt7 forward, the unfused 16x16 layers, bn8's layout kernel, conv1's backward, bn1's own gradient).
+// the wave-specialised data-gradient kernel; j = 13: convt7's weight-gradient + sums kernel) hands over to the fused
+// backward, or to the data-gradient kernel, of layer j-1: j = 13 .. 8, 6 .. 2.  The other 4 keep their finalisation launch (forward bn1:
+// conv1's packed-FMA kernel; backward: bn8's layout kernel, conv1's backward, bn1's own gradient).
 static bool acc_enabled(bool bwd) {
 #ifdef AVA_LAB
   static const int on = [] {
@@ -566,7 +566,7 @@ static bool acc_pair_fwd(const ava_model* m, int j) {
 }
 static bool acc_pair_bwd(const ava_model* m, int j) {
   (void)m;
-  return acc_enabled(true) && (j == 13 || j == 12 || j == 11 || j == 10 || (j >= 2 && j <= 5));
+  return acc_enabled(true) && (j == 13 || j == 12 || j == 11 || j == 10 || j == 9 || j == 8 || (j >= 2 && j <= 6));
 }
 static long long* acc_slot(ava_model* m, int slot) { return m->bn_acc + (size_t)slot * AVA_ACC_SLOT_LL; }
 static BnFin fin_none() { BnFin f = {}; f.acc = nullptr; return f; }
@@ -821,20 +821,22 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
     if (a.acc_out != nullptr) return AVA_OK;                  // finalised by the next backward kernel
     return finalize_bwd(m, l, fgrid, (int64_t)B * D.hi * D.wi, st);
   }
-  // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
-  TRY(ava_conv3x3_wgrad_ex(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], B, D.hi, D.wi, L.cin,
-                           L.cout, L.mode, pro, m->act_bf16, st));
-  mark(m, CAT_CONV_WGRAD, st);
-  // data gradient w.r.t. the BatchNorm output, plus the BatchNorm-backward sums against X
+  // Layers without a fused kernel (the four at 16x16).  The data gradient w.r.t. the BatchNorm output (plus the
+  // BatchNorm-backward sums against X) goes FIRST: its prologue can finalise BatchNorm l+1's A, Bc, Cc from the
+  // accumulated sums (bn_acc.h) and workgroup 0 publishes them, so the weight-gradient kernel behind it reads the arrays.
   const int bmode = L.mode == MODE_S1 ? MODE_S1 : (L.mode == MODE_DOWN ? MODE_UP : MODE_DOWN);
   ConvAcc acc;
-  acc.fin = fin_none();                                      // unfused consumers read the A, Bc, Cc arrays
+  acc.fin = (pro == PRO_BWD && acc_pair_bwd(m, l + 1)) ? fin_bwd(m, l + 1, B) : fin_none();
   acc.acc_out = acc_pair_bwd(m, l) ? acc_slot(m, 14 + l) : nullptr;
   TRY(ava_conv3x3_ex(gin, gin2, ca, cb, cc, m->Gb[l], nullptr, gout, nullptr, X, bn_mean(m, l), bn_invstd(m, l),
                      m->bn_part, B, D.ho, D.wo, L.cout, L.cin, bmode, pro, EPI_BWD, 0, 0.f, m->act_bf16, &acc,
                      reinterpret_cast<ava_stream_t>(st)));
   mark(m, CAT_CONV_BWD_DATA, st);
   if (acc.acc_out == nullptr) TRY(finalize_bwd(m, l, ava_conv_grid(B, D.hi, D.wi, bmode), (int64_t)B * D.hi * D.wi, st));
+  // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
+  TRY(ava_conv3x3_wgrad_ex(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], B, D.hi, D.wi, L.cin,
+                           L.cout, L.mode, pro, m->act_bf16, st));
+  mark(m, CAT_CONV_WGRAD, st);
   return AVA_OK;
 }
 

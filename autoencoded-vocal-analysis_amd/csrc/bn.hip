@@ -263,8 +263,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* 
                                                                    const float* __restrict__ A,
                                                                    const float* __restrict__ Bc,
                                                                    const float* __restrict__ Cc,
-                                                                   float* __restrict__ out_nchw, int B, int P) {
+                                                                   float* __restrict__ out_nchw, int B, int P,
+                                                                   const BnFin fin) {
   __shared__ float tile[32][QPIX + 1];
+  __shared__ float coef[96];
+  __shared__ double accvals[64];
+  if (fin.acc != nullptr) {                 // bn8's A, Bc, Cc from the sums convt1's data-gradient kernel accumulated (bn_acc.h)
+    bn_coef_from_acc(coef, accvals, fin, 0);
+  } else {
+    if (threadIdx.x < 32) { coef[threadIdx.x] = A[threadIdx.x]; coef[32 + threadIdx.x] = Bc[threadIdx.x]; coef[64 + threadIdx.x] = Cc[threadIdx.x]; }
+    __syncthreads();
+  }
   const int nq = P / QPIX;
   for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
     const int b = w / nq, q = w - b * nq;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* 
       const int c = i / QPIX, p = i % QPIX;
       const size_t o = (size_t)b * 32 * P + (size_t)c * P + q * QPIX + p;
       const float f = ava_stored_bn<ACT>(f8_nchw[o]);
-      out_nchw[o] = f > 0.f ? fmaf(A[c], tile[c][p], fmaf(Bc[c], f, Cc[c])) : 0.f;
+      out_nchw[o] = f > 0.f ? fmaf(coef[c], tile[c][p], fmaf(coef[32 + c], f, coef[64 + c])) : 0.f;
     }
   }
 }
@@ -374,9 +383,11 @@ int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, 
   return AVA_OK;
 }
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
-                             float* out, int B, int P, int act_bf16, hipStream_t st) {
-  if (act_bf16) hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel<unsigned short>, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P);
-  else hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel<float>, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P);
+                             float* out, int B, int P, int act_bf16, const BnFin* fin, hipStream_t st) {
+  BnFin f = {};
+  if (fin != nullptr) f = *fin;
+  if (act_bf16) hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel<unsigned short>, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P, f);
+  else hipLaunchKernelGGL(bn_bwd_apply_to_nchw_kernel<float>, dim3(layout_grid(B, P)), dim3(256), 0, st, g, f8, A, Bc, Cc, out, B, P, f);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

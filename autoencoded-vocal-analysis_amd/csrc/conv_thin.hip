@@ -703,11 +703,19 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
 #pragma unroll
   for (int c = 0; c < 4; ++c) T[c] = Rt[c] = Rb[c] = Cc[c] = Kt[c] = Kb[c] = 0.f;
   float da[4], db[4], dc[4];
+  if (DYPRO == PRO_BWD && a.fin.acc != nullptr) {   // bn2's A, Bc, Cc from the sums conv2's backward accumulated (bn_acc.h)
+    __shared__ float coef[96];
+    __shared__ double accvals[64];
+    bn_coef_from_acc(coef, accvals, a.fin, 0);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    da[c] = DYPRO == PRO_BWD ? a.da[4 * h + c] : 0.f;
-    db[c] = DYPRO == PRO_BWD ? a.db[4 * h + c] : 0.f;
-    dc[c] = DYPRO == PRO_BWD ? a.dc[4 * h + c] : 0.f;
+    for (int c = 0; c < 4; ++c) { da[c] = coef[4 * h + c]; db[c] = coef[32 + 4 * h + c]; dc[c] = coef[64 + 4 * h + c]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      da[c] = DYPRO == PRO_BWD ? a.da[4 * h + c] : 0.f;
+      db[c] = DYPRO == PRO_BWD ? a.db[4 * h + c] : 0.f;
+      dc[c] = DYPRO == PRO_BWD ? a.dc[4 * h + c] : 0.f;
+    }
   }
   const bool edge_col = x == 0 || x == W - 1;
   const int tiles_y = a.Ho / THIN_TH;

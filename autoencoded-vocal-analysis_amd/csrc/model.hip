@@ -24,7 +24,7 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
 int ava_nhwc_to_nchw(const float* in, float* out, int B, int P, hipStream_t st);
 int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, int P, hipStream_t st);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
-                             float* out, int B, int P, int act_bf16, hipStream_t st);
+                             float* out, int B, int P, int act_bf16, const BnFin* fin, hipStream_t st);
 int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, float* A, float* Bc, float* Cc, int eval,
                            hipStream_t st);
@@ -542,8 +542,8 @@ static constexpr bool lab_skip_bn_fin() { return false; }
 // consumer side) and its input comes from such a kernel, from conv1's packed-FMA kernel (j = 1) or from the
 // fc8 -> NHWC layout kernel (j = 7), and the direct convt6 / convt7 kernels (j = 12, 13): j = 1..13.  Backward: BatchNorm j when the backward of layer j (fused kernel; j = 5:
 // the wave-specialised data-gradient kernel; j = 13: convt7's weight-gradient + sums kernel) hands over to the fused
-// backward, or to the data-gradient kernel, of layer j-1: j = 13 .. 8, 6 .. 2.  The other 4 keep their finalisation launch (forward bn1:
-// conv1's packed-FMA kernel; backward: bn8's layout kernel, conv1's backward, bn1's own gradient).
+// backward, or to the data-gradient kernel, of layer j-1 (j = 7: to bn8's layout kernel; j = 1: to conv1's packed-FMA backward): j = 13 .. 1.  The other 2 keep their finalisation launch (forward bn1:
+// conv1's packed-FMA kernel; backward: bn1's own gradient).
 static bool acc_enabled(bool bwd) {
 #ifdef AVA_LAB
   static const int on = [] {
@@ -566,7 +566,7 @@ static bool acc_pair_fwd(const ava_model* m, int j) {
 }
 static bool acc_pair_bwd(const ava_model* m, int j) {
   (void)m;
-  return acc_enabled(true) && (j == 13 || j == 12 || j == 11 || j == 10 || j == 9 || j == 8 || (j >= 2 && j <= 6));
+  return acc_enabled(true) && ((j >= 7 && j <= 13) || (j >= 1 && j <= 6));
 }
 static long long* acc_slot(ava_model* m, int slot) { return m->bn_acc + (size_t)slot * AVA_ACC_SLOT_LL; }
 static BnFin fin_none() { BnFin f = {}; f.acc = nullptr; return f; }
@@ -813,7 +813,7 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
     // BatchNorm l+1's A, Bc, Cc finalised in this kernel / BatchNorm l's sums accumulated by it (bn_acc.h); the thin
     // kernels of conv1 / convt7 (Cin or Cout = 1) keep arrays and partial rows
     const bool thin = L.cin == 1 || L.cout == 1;
-    a.fin = (!thin && pro == PRO_BWD && acc_pair_bwd(m, l + 1)) ? fin_bwd(m, l + 1, B) : fin_none();
+    a.fin = ((!thin || l == 0) && pro == PRO_BWD && acc_pair_bwd(m, l + 1)) ? fin_bwd(m, l + 1, B) : fin_none();   // l = 0: conv1's packed-FMA backward
     a.acc_out = ((!thin || l == 13) && acc_pair_bwd(m, l)) ? acc_slot(m, 14 + l) : nullptr;   // l = 13: convt7's sums kernel
     a.tiles_y = a.tiles_x = a.ntiles = 0;
     TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
@@ -922,7 +922,8 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
     float* t = gcur; gcur = gnext; gnext = t;
   }
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
-  TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, m->P8, m->act_bf16, st));
+  const BnFin fin8 = acc_pair_bwd(m, 7) ? fin_bwd(m, 7, B) : fin_none();      // bn8: finalised inside the layout kernel
+  TRY(ava_bn_bwd_apply_to_nchw(gcur, m->f8, bn_A(m, 7), bn_B(m, 7), bn_C(m, 7), m->dF8, B, m->P8, m->act_bf16, &fin8, st));
   mark(m, CAT_LAYOUT, st);
   if (!whole) TRY(reduce_wgrads(m, 7, NCONV, B, st));
   TRY(gemm(m, m->dF8, 0, m->h7, 0, nullptr, GG(m, FC8), 0, nullptr, GG(m, FC8 + 1), m->F, 1024, B, 0, 0, ACT_NONE, st));

@@ -283,5 +283,6 @@ struct WgradReduceEntry {
 struct WgradReduceTable {
   WgradReduceEntry e[14];
   int n;
-};
+  BnFin fin0;            // fin0.acc != null: block 0 also finalises bn1's own gradient (d gamma, d beta) from the sums
+};                       // conv1's backward accumulated (bn_acc.h) -- the last BatchNorm of the backward pass has no consumer kernel
 int ava_conv_wgrad_reduce_all(const WgradReduceTable& tab, int total_blocks, hipStream_t st);

@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradReduceTable tab) {
+  if (blockIdx.x == 0 && tab.fin0.acc != nullptr) {
+    __shared__ float coef[96];
+    __shared__ double accvals[64];
+    bn_coef_from_acc(coef, accvals, tab.fin0, 0);           // publishes d gamma, d beta of bn1 (and its unused A, Bc, Cc)
+  }
   int i = 0;
 #pragma unroll 1
   for (int k = 1; k < tab.n; ++k)

@@ -839,7 +839,8 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
   if (t < 2) {
     float s = 0.f;
     for (int i = 0; i < 72; ++i) s += scratch[72 * t + i];
-    a.bn_partials[(size_t)blockIdx.x * 2 + t] = s;
+    if (a.acc_out != nullptr) bn_acc_add(a.acc_out, 32 * t, s);       // one channel: values 0 (sum dx) and 32 (sum dx * xhat)
+    else a.bn_partials[(size_t)blockIdx.x * 2 + t] = s;
   }
 }
 

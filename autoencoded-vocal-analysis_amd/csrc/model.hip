@@ -542,8 +542,9 @@ static constexpr bool lab_skip_bn_fin() { return false; }
 // consumer side) and its input comes from such a kernel, from conv1's packed-FMA kernel (j = 1) or from the
 // fc8 -> NHWC layout kernel (j = 7), and the direct convt6 / convt7 kernels (j = 12, 13): j = 1..13.  Backward: BatchNorm j when the backward of layer j (fused kernel; j = 5:
 // the wave-specialised data-gradient kernel; j = 13: convt7's weight-gradient + sums kernel) hands over to the fused
-// backward, or to the data-gradient kernel, of layer j-1 (j = 7: to bn8's layout kernel; j = 1: to conv1's packed-FMA backward): j = 13 .. 1.  The other 2 keep their finalisation launch (forward bn1:
-// conv1's packed-FMA kernel; backward: bn1's own gradient).
+// backward, or to the data-gradient kernel, of layer j-1 (j = 7: to bn8's layout kernel; j = 1: to conv1's packed-FMA backward;
+// j = 0: to the weight-gradient reduction that ends the pass): j = 13 .. 0.  One keeps its finalisation launch: forward bn1 (the
+// input statistics come from the launch that also zeroes the accumulators).
 static bool acc_enabled(bool bwd) {
 #ifdef AVA_LAB
   static const int on = [] {
@@ -566,7 +567,7 @@ static bool acc_pair_fwd(const ava_model* m, int j) {
 }
 static bool acc_pair_bwd(const ava_model* m, int j) {
   (void)m;
-  return acc_enabled(true) && ((j >= 7 && j <= 13) || (j >= 1 && j <= 6));
+  return acc_enabled(true) && (j >= 0 && j <= 13);
 }
 static long long* acc_slot(ava_model* m, int slot) { return m->bn_acc + (size_t)slot * AVA_ACC_SLOT_LL; }
 static BnFin fin_none() { BnFin f = {}; f.acc = nullptr; return f; }
@@ -814,7 +815,7 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
     // kernels of conv1 / convt7 (Cin or Cout = 1) keep arrays and partial rows
     const bool thin = L.cin == 1 || L.cout == 1;
     a.fin = ((!thin || l == 0) && pro == PRO_BWD && acc_pair_bwd(m, l + 1)) ? fin_bwd(m, l + 1, B) : fin_none();   // l = 0: conv1's packed-FMA backward
-    a.acc_out = ((!thin || l == 13) && acc_pair_bwd(m, l)) ? acc_slot(m, 14 + l) : nullptr;   // l = 13: convt7's sums kernel
+    a.acc_out = ((!thin || l == 13 || l == 0) && acc_pair_bwd(m, l)) ? acc_slot(m, 14 + l) : nullptr;   // l = 13: convt7's sums kernel; l = 0: conv1's
     a.tiles_y = a.tiles_x = a.ntiles = 0;
     TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
     mark(m, CAT_CONV_BWD_DATA, st);
@@ -857,6 +858,7 @@ static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
     blocks += ceil_div(9 * L.cin * L.cout + L.cout, 32);
   }
   tab.n = n;
+  tab.fin0 = (l0 == 0 && acc_pair_bwd(m, 0)) ? fin_bwd(m, 0, B) : fin_none();     // bn1's own gradient: no consumer kernel, finalised here
   TRY(ava_conv_wgrad_reduce_all(tab, blocks, st));
   mark(m, CAT_CONV_WGRAD, st);
   return AVA_OK;

@@ -550,9 +550,13 @@ static bool acc_enabled(bool bwd) {
   static const int on = [] {
     const char* e = ava_env("AVA_BN_ACC");
     if (e != nullptr) return atoi(e);
-    const char* f = ava_env("AVA_CONV_FUSED"); const char* w = ava_env("AVA_FUSED_WS"); const char* c = ava_env("AVA_CONV_IMPL");
-    const char* td = ava_env("AVA_THIN_DIRECT"); const char* tw = ava_env("AVA_THIN_WS");
-    return ((f && atoi(f) == 0) || (w && atoi(w) == 0) || c != nullptr || td != nullptr || tw != nullptr) ? 0 : 1;     // kernel-selection switches: launches only
+    // any kernel-selection switch may route a layer to a kernel without the accumulator hooks: finalisation launches then
+    static const char* const sel[] = {"AVA_CONV_FUSED", "AVA_FUSED_WS", "AVA_CONV_IMPL", "AVA_CONV_WS", "AVA_CONV_WS_BWD",
+                                      "AVA_THIN_WS", "AVA_THIN_FWD_DIRECT", "AVA_THIN_STATS_DIRECT", "AVA_UP88_DIRECT",
+                                      "AVA_PACK_STATS"};
+    for (const char* n : sel)
+      if (ava_env(n) != nullptr) return 0;
+    return 1;
   }();
   (void)bwd;
   return on != 0;

@@ -228,6 +228,25 @@ def test_loader_feeds_the_train_step_on_the_device():
     assert lat.shape == (96, 32) and np.isfinite(lat).all()
 
 
+def test_windows_at_the_size_extension_feed_a_256x256_model():
+    """configs[4]'s geometry end to end: 256 x 256 windows made on the device (the grid is just num_freq_bins x
+    num_time_bins) through a VAE(x_shape=(256, 256)) train step"""
+    from ava_amd import spec as sp
+    from ava_amd.vae import VAE
+    p = dict(syn.FINCH_PARAMS)
+    p.update(num_freq_bins=256, num_time_bins=256)
+    audio, rois = _recordings("finch")
+    ds = sp.DeviceWindowDataset.from_arrays(audio, p['fs'], rois, p, dataset_length=16)
+    specs, fidx, on, off = ds.__getitem__(list(range(4)), seed=21, return_seg_info=True)
+    want, ofidx, oon, _ = so.FixedWindowOracle(audio, p['fs'], rois, p).getitem(list(range(4)), seed=21)
+    assert fidx == ofidx and on == oon
+    _check(specs, np.stack(want))
+    model = VAE(save_dir="", z_dim=16, device_name="cuda", x_shape=(256, 256))
+    loader = sp.DeviceWindowLoader(ds, batch_size=8)
+    losses = [model.train_epoch(loader) for _ in range(3)]
+    assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0]
+
+
 def test_c_abi_argument_checks():
     from ava_amd import _lib
     lib = _lib.load()

@@ -16,7 +16,8 @@
 #define AVA_ACC_SHARDS 8
 #define AVA_ACC_SHARD_LL 200            // per shard: [3 limbs][64 values] + flag word at 192 (+ padding)
 #define AVA_ACC_SLOT_LL (AVA_ACC_SHARDS * AVA_ACC_SHARD_LL)
-#define AVA_ACC_SLOTS 28                // BatchNorm l forward statistics: slot l; backward sums: slot 14 + l
+#define AVA_ACC_SLOTS 29                // BatchNorm l forward statistics: slot l; backward sums: slot 14 + l; slot 28: the
+                                        // second buffer of bn1's forward sums (their producer is the launch that zeroes the rest)
 #define AVA_BN_EPS_D 1e-5
 #define AVA_BN_MOM_D 0.1
 

@@ -129,7 +129,15 @@ __global__ __launch_bounds__(2 * W) void thin_1to8_kernel(const ConvArgs a) {
   __shared__ float tile[THIN_IR * THIN_IC];
   __shared__ float red[THIN_NW][2][8];
   const int t = threadIdx.x, h = t & 1, x = t >> 1, lane = t & 63, wave = t >> 6;
-  const float ca = a.pa ? a.pa[0] : 0.f, cb = a.pb ? a.pb[0] : 0.f, cc = a.pc ? a.pc[0] : 0.f;
+  float ca = a.pa ? a.pa[0] : 0.f, cb = a.pb ? a.pb[0] : 0.f;
+  const float cc = a.pc ? a.pc[0] : 0.f;
+  if (PRO == PRO_BN && a.fin.acc != nullptr) {        // bn1 (conv1's forward): the input sums of the pack launch, finalised here
+    __shared__ float coef[96];
+    __shared__ double accvals[64];
+    bn_coef_from_acc(coef, accvals, a.fin, 0);
+    ca = coef[0];
+    cb = coef[32];
+  }
   avaf2 w2[9][2];                                    // [tap][channel pair of this half]
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)

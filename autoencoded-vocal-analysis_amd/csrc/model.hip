@@ -142,7 +142,9 @@ struct ava_model {
   float* bn_part;           // [1024][64]
   float* bn_save;           // [14][4][32]: mean, invstd, scale, shift
   float* bn_bwd;            // [14][3][32]: A, Bc, Cc
-  long long* bn_acc;        // [28 slots][8 shards][200]: in-kernel BatchNorm sums (bn_acc.h), zeroed by the pack launch
+  long long* bn_acc;        // [29 slots][8 shards][200]: in-kernel BatchNorm sums (bn_acc.h), zeroed by the pack launch
+  int acc0_slot;            // slot (0 or 28) the NEXT statistics launch adds bn1's input sums to; -1: neither is known to be zero yet
+  int acc0_used;            // slot the last training forward used (conv1's kernel finalises from it)
   float* Gf[NCONV];
   float* Gb[NCONV];
   float *gA, *gB;           // gradient ping-pong, B*131072 floats each
@@ -312,6 +314,7 @@ extern "C" int ava_model_create_ex(ava_model** out, int z_dim, int H, int W, int
   if (need > workspace_bytes) { delete m; return AVA_EWORKSPACE; }
   m->lastB = 0;
   m->last_train = 1;
+  m->acc0_slot = -1; m->acc0_used = -1;
   m->status_last = nullptr;
   m->bwd_scale = nullptr;
   m->sse_parts = 0;
@@ -418,11 +421,13 @@ extern "C" int ava_profile_read(ava_model* m, float* ms, int* launches) {
 
 // ---- all 28 weight tables in one launch ---------------------------------------------------------------
 struct PackEntry { const float* w; float* g; int c0, c1, swap, flip; };
-struct PackTable { PackEntry e[2 * NCONV]; long long* acc; int nacc; };   // acc: BatchNorm accumulators to zero (bn_acc.h)
+struct PackTable { PackEntry e[2 * NCONV]; long long* acc; int nacc; int keep0, keep1; long long* in_acc; };
+// acc: BatchNorm accumulators to zero (bn_acc.h), except elements [keep0, keep1): the slot `in_acc` the statistics blocks of
+// this very launch add bn1's input sums to (zeroed by the previous launch: two slots alternate)
 __global__ void pack_all_kernel(const PackTable tab) {
   {
     const int gt = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, nt = gridDim.x * gridDim.y * blockDim.x;
-    for (int i = gt; i < tab.nacc; i += nt) tab.acc[i] = 0;
+    for (int i = gt; i < tab.nacc; i += nt) tab.acc[i] = 0;      // (no statistics in this launch: nothing to keep)
   }
   const PackEntry e = tab.e[blockIdx.y];
   const int n = e.c0 * e.c1 * 9;
@@ -440,7 +445,8 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const PackTable tab, co
                                                          float* __restrict__ partials, int nstats, float* __restrict__ eps,
                                                          int64_t neps, uint64_t seed, uint64_t offset) {
   constexpr int NPACK = 7 * 2 * NCONV;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < tab.nacc; i += gridDim.x * 256) tab.acc[i] = 0;   // every block first
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < tab.nacc; i += gridDim.x * 256)                 // every block first
+    if (i < tab.keep0 || i >= tab.keep1) tab.acc[i] = 0;
   if ((int)blockIdx.x >= nstats + NPACK) {              // third role: the step's rsample noise (ava_forward_noise)
     const int nb = gridDim.x - nstats - NPACK, bi = blockIdx.x - nstats - NPACK;
     for (int64_t i = (int64_t)bi * 256 + threadIdx.x; i < neps; i += (int64_t)nb * 256)
@@ -474,11 +480,15 @@ __global__ __launch_bounds__(256) void pack_stats_kernel(const PackTable tab, co
   const float r1 = wave_sum(s1), r2 = wave_sum(s2);
   if (l == 0) { red[w][0] = r1; red[w][1] = r2; }
   __syncthreads();
-  if (threadIdx.x < 2)
-    partials[(size_t)blockIdx.x * 2 + threadIdx.x] =
-        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 2) {
+    const float tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (tab.in_acc != nullptr) bn_acc_add(tab.in_acc, 32 * threadIdx.x, tot);     // one channel: values 0 (sum x) and 32 (sum x^2)
+    else partials[(size_t)blockIdx.x * 2 + threadIdx.x] = tot;
+  }
 }
 
+static bool acc_enabled(bool bwd);
+static long long* acc_slot(ava_model* m, int slot);
 // x_stats != nullptr: also the bn1 input statistics of x_stats[n] (training forward); *nstats_out = partial rows written
 struct NoiseGen { float* eps; int64_t n; uint64_t seed, offset; };   // eps == nullptr: no noise to generate
 
@@ -498,6 +508,8 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
   }
   tab.acc = m->bn_acc;
   tab.nacc = AVA_ACC_SLOTS * AVA_ACC_SLOT_LL;
+  tab.keep0 = tab.keep1 = 0; tab.in_acc = nullptr;
+  m->acc0_used = -1;
   mark(m, -1, st);
   static const bool fuse = [] { const char* e = ava_env("AVA_PACK_STATS"); return e == nullptr || atoi(e) != 0; }();
   if (x_stats != nullptr && nstats_out != nullptr && fuse && (reinterpret_cast<uintptr_t>(x_stats) & 15) == 0) {
@@ -507,6 +519,14 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
     if (nstats > 1024) nstats = 1024;
     int nnoise = ng.eps != nullptr ? (int)((ng.n + 255) / 256) : 0;
     if (nnoise > 64) nnoise = 64;
+    if (acc_enabled(false) && m->acc0_slot >= 0) {      // bn1's sums into the slot the previous pack launch zeroed
+      tab.in_acc = acc_slot(m, m->acc0_slot);
+      tab.keep0 = m->acc0_slot * AVA_ACC_SLOT_LL; tab.keep1 = tab.keep0 + AVA_ACC_SLOT_LL;
+      m->acc0_used = m->acc0_slot;
+      m->acc0_slot = m->acc0_slot == 0 ? 28 : 0;        // this launch zeroes the other one for the next step
+    } else {
+      m->acc0_slot = 0;                                 // this launch zeroes every slot: usable from the next step on
+    }
     hipLaunchKernelGGL(pack_stats_kernel, dim3(nstats + 7 * 2 * NCONV + nnoise), dim3(256), 0, st, tab, x_stats, n, m->bn_part,
                        nstats, ng.eps, ng.n, ng.seed, ng.offset);
     AVA_CHECK_LAUNCH();
@@ -521,6 +541,7 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
   }
   hipLaunchKernelGGL(pack_all_kernel, dim3(7, with_bwd ? 2 * NCONV : 2 * NCONV), dim3(256), 0, st, tab);
   AVA_CHECK_LAUNCH();
+  m->acc0_slot = 0;                                       // every slot zeroed
   mark(m, CAT_PACK, st);
   return AVA_OK;
 }
@@ -543,8 +564,8 @@ static constexpr bool lab_skip_bn_fin() { return false; }
 // fc8 -> NHWC layout kernel (j = 7), and the direct convt6 / convt7 kernels (j = 12, 13): j = 1..13.  Backward: BatchNorm j when the backward of layer j (fused kernel; j = 5:
 // the wave-specialised data-gradient kernel; j = 13: convt7's weight-gradient + sums kernel) hands over to the fused
 // backward, or to the data-gradient kernel, of layer j-1 (j = 7: to bn8's layout kernel; j = 1: to conv1's packed-FMA backward;
-// j = 0: to the weight-gradient reduction that ends the pass): j = 13 .. 0.  One keeps its finalisation launch: forward bn1 (the
-// input statistics come from the launch that also zeroes the accumulators).
+// j = 0: to the weight-gradient reduction that ends the pass): j = 13 .. 0.  Forward bn1's sums come from the pack launch,
+// which also zeroes the accumulators: two slots (0 and 28) alternate, the launch adds to the one its predecessor zeroed.
 static bool acc_enabled(bool bwd) {
 #ifdef AVA_LAB
   static const int on = [] {
@@ -665,7 +686,7 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
       TRY(ava_bn_stats(x, (int64_t)B * m->H * m->W, 1, m->bn_part, &nparts, reinterpret_cast<ava_stream_t>(st)));
       mark(m, CAT_BN, st);
     }
-    TRY(finalize_fwd(m, 0, nparts, (int64_t)B * m->H * m->W, st));
+    if (m->acc0_used < 0) TRY(finalize_fwd(m, 0, nparts, (int64_t)B * m->H * m->W, st));      // else: inside conv1's kernel
   } else {
     TRY(bn_eval_all(m, st));       // all 14 layers from the running statistics (also serves the decoder)
   }
@@ -678,6 +699,7 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
     float* nchw = (l == 6 && conv7_writes_nchw()) ? m->y7t : nullptr;
     ConvAcc acc;
     acc.fin = (train && acc_pair_fwd(m, l)) ? fin_fwd(m, l, B) : fin_none();                 // BatchNorm l: finalised in this kernel
+    if (train && l == 0 && m->acc0_used >= 0) { acc.fin = fin_fwd(m, 0, B); acc.fin.acc = acc_slot(m, m->acc0_used); }
     acc.acc_out = (train && l < 6 && acc_pair_fwd(m, l + 1)) ? acc_slot(m, l + 1) : nullptr;    // BatchNorm l+1: summed by this kernel
     TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nchw,
                        nullptr, nullptr, nullptr, m->bn_part, B, D.hi, D.wi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,

@@ -383,6 +383,10 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
 
   if (stager) {
     // ---------------- staging waves ----------------
+    // issue priority over the matrix-core waves of the same SIMD: their loads and LDS stores are the longer pipeline
+    // (DESIGN.md section 3, item 16); same-box A/B of the step: 1.9141 / 1.9131 ms without, 1.9087 / 1.8979 ms with (the
+    // reverse, matrix-core waves first, costs +26 us)
+    __builtin_amdgcn_s_setprio(3);
     if (walk.valid()) {
       sx.store(smem, cx);
       sd.store(smem + XF, cd);

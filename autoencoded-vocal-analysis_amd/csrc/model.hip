@@ -519,13 +519,18 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
     if (nstats > 1024) nstats = 1024;
     int nnoise = ng.eps != nullptr ? (int)((ng.n + 255) / 256) : 0;
     if (nnoise > 64) nnoise = 64;
+    // under stream capture the alternation would be frozen into the graph (every replay adding to the same slot): a
+    // captured step keeps bn1's finalisation launch, and the slot state is unknown afterwards
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (capturing) m->acc0_slot = -1;
     if (acc_enabled(false) && m->acc0_slot >= 0) {      // bn1's sums into the slot the previous pack launch zeroed
       tab.in_acc = acc_slot(m, m->acc0_slot);
       tab.keep0 = m->acc0_slot * AVA_ACC_SLOT_LL; tab.keep1 = tab.keep0 + AVA_ACC_SLOT_LL;
       m->acc0_used = m->acc0_slot;
       m->acc0_slot = m->acc0_slot == 0 ? 28 : 0;        // this launch zeroes the other one for the next step
     } else {
-      m->acc0_slot = 0;                                 // this launch zeroes every slot: usable from the next step on
+      m->acc0_slot = capturing ? -1 : 0;                // this launch zeroes every slot: usable from the next (eager) step on
     }
     hipLaunchKernelGGL(pack_stats_kernel, dim3(nstats + 7 * 2 * NCONV + nnoise), dim3(256), 0, st, tab, x_stats, n, m->bn_part,
                        nstats, ng.eps, ng.n, ng.seed, ng.offset);
@@ -541,7 +546,11 @@ static int pack_weights(ava_model* m, bool with_bwd, hipStream_t st, const float
   }
   hipLaunchKernelGGL(pack_all_kernel, dim3(7, with_bwd ? 2 * NCONV : 2 * NCONV), dim3(256), 0, st, tab);
   AVA_CHECK_LAUNCH();
-  m->acc0_slot = 0;                                       // every slot zeroed
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    m->acc0_slot = capturing ? -1 : 0;                    // every slot zeroed (when the launch really runs now)
+  }
   mark(m, CAT_PACK, st);
   return AVA_OK;
 }

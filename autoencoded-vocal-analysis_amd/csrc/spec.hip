@@ -305,61 +305,99 @@ __global__ __launch_bounds__(256) void spec_stft_kernel(const SpecArgs a) {
 
 #undef PD
 
-// utils.py:77-103 for one output pixel.  Linear B-spline evaluation in FITPACK's order (fpbspl: h0 = f (t[l+1] - x),
-// h1 = f (x - t[l]) with f = 1 / (t[l+1] - t[l]); fpbisp: sum over x then y of (c * hx) * hy), then interp2d's
-// out-of-bounds rule, then normalisation and clip.
+// utils.py:77-103.  Linear B-spline evaluation in FITPACK's order (fpbspl: h0 = f (t[l+1] - x), h1 = f (x - t[l]) with
+// f = 1 / (t[l+1] - t[l]); fpbisp: sum over x then y of (c * hx) * hy), then interp2d's out-of-bounds rule, then
+// normalisation and clip.  A workgroup owns AVA_SPEC_ROWS frequency rows of one window: the knot interval and the two
+// basis values of every target TIME are computed once per workgroup (LDS), those of a target FREQUENCY once per row
+// visit, so a pixel costs four loads, the 4-term sum and the normalising division.
+#define AVA_SPEC_ROWS 16
+#define AVA_SPEC_TMAX 512        // target times per window the column table holds (num_time_bins; larger: AVA_EINVAL)
 __global__ __launch_bounds__(256) void spec_interp_kernel(const SpecArgs a) {
-  const int w = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.F * a.T) return;
-  const int fi = p / a.T, ti = p - fi * a.T;
+  __shared__ double chx0[AVA_SPEC_TMAX], chx1[AVA_SPEC_TMAX];
+  __shared__ int cl[AVA_SPEC_TMAX];                                  // knot interval of column ti, -1: outside -> fill value
+  __shared__ double rhy0[AVA_SPEC_ROWS], rhy1[AVA_SPEC_ROWS];
+  __shared__ int rq[AVA_SPEC_ROWS];
+  const int w = blockIdx.y, f0 = blockIdx.x * AVA_SPEC_ROWS, t = threadIdx.x;
   const SpecMeta m = a.meta[w];
-  float* o = a.out + ((size_t)w * a.F + fi) * a.T + ti;
-  if (m.nframes == 0) { *o = 0.f; return; }                          // utils.py:68-69: np.zeros
-  if (m.nframes < 0) { *o = __builtin_nanf(""); return; }            // workspace too small for this window: loud
+  const int rows = a.F - f0 < AVA_SPEC_ROWS ? a.F - f0 : AVA_SPEC_ROWS;
+  float* obase = a.out + ((size_t)w * a.F + f0) * a.T;
+  if (m.nframes <= 0) {                                              // utils.py:68-69: np.zeros / the "scratch too small" marker
+    const float z = m.nframes == 0 ? 0.f : __builtin_nanf("");
+    for (int i = t; i < rows * a.T; i += 256) obase[i] = z;
+    return;
+  }
   const int K = a.nperseg / 2 + 1;
-  const double x = a.target_times[(size_t)w * a.T + ti], y = a.target_freqs[fi];
   const double* ft = a.ftimes + (size_t)w * a.maxframes;
   const double val = a.fbin;                       // bin frequencies: rfftfreq(n, d) = arange(n/2 + 1) * (1 / (n d)), d = 1 / fs
   const double xmin = ft[0], xmax = ft[m.nframes - 1];
-  const double ymin = 0.0, ymax = __dmul_rn((double)(K - 1), val);
-  double v;
-  if (x < xmin || x > xmax || y < ymin || y > ymax || !(x == x) || !(y == y)) {
-    v = a.fill_value;
-  } else {
-    int l = (int)floor((x - xmin) * a.fs / (double)a.nstep);
-    l = l < 0 ? 0 : (l > m.nframes - 2 ? m.nframes - 2 : l);
-    while (l > 0 && x < ft[l]) --l;
-    while (l < m.nframes - 2 && x >= ft[l + 1]) ++l;
-    int q = (int)floor(y / val);
-    q = q < 0 ? 0 : (q > K - 2 ? K - 2 : q);
-    while (q > 0 && y < __dmul_rn((double)q, val)) --q;
-    while (q < K - 2 && y >= __dmul_rn((double)(q + 1), val)) ++q;
-    const double tl = ft[l], tr = ft[l + 1];
-    const double fx = __ddiv_rn(1.0, __dsub_rn(tr, tl));
-    const double hx0 = __dmul_rn(fx, __dsub_rn(tr, x)), hx1 = __dmul_rn(fx, __dsub_rn(x, tl));
-    const double yl = __dmul_rn((double)q, val), yr = __dmul_rn((double)(q + 1), val);
-    const double fy = __ddiv_rn(1.0, __dsub_rn(yr, yl));
-    const double hy0 = __dmul_rn(fy, __dsub_rn(yr, y)), hy1 = __dmul_rn(fy, __dsub_rn(y, yl));
-    const double* c0 = a.logmag + ((size_t)w * a.maxframes + l) * K + q;       // coefficient c[time l][freq q]
-    const double* c1 = c0 + K;
-    double sp = 0.0;
-    sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c0[0], hx0), hy0));
-    sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c0[1], hx0), hy1));
-    sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c1[0], hx1), hy0));
-    sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c1[1], hx1), hy1));
-    v = sp;
+  for (int ti = t; ti < a.T; ti += 256) {
+    const double x = a.target_times[(size_t)w * a.T + ti];
+    int l = -1;
+    double hx0 = 0.0, hx1 = 0.0;
+    if (!(x < xmin || x > xmax || !(x == x))) {
+      l = (int)floor((x - xmin) * a.fs / (double)a.nstep);
+      l = l < 0 ? 0 : (l > m.nframes - 2 ? m.nframes - 2 : l);
+      while (l > 0 && x < ft[l]) --l;
+      while (l < m.nframes - 2 && x >= ft[l + 1]) ++l;
+      const double tl = ft[l], tr = ft[l + 1];
+      const double fx = __ddiv_rn(1.0, __dsub_rn(tr, tl));
+      hx0 = __dmul_rn(fx, __dsub_rn(tr, x));
+      hx1 = __dmul_rn(fx, __dsub_rn(x, tl));
+    }
+    cl[ti] = l; chx0[ti] = hx0; chx1[ti] = hx1;
   }
-  v = __dsub_rn(v, a.spec_min);
-  v = __ddiv_rn(v, a.range);                                         // utils.py:101-102
-  v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-  if (a.normalize) {                                                 // utils.py:104-108 follow in spec_normalize_kernel
-    a.vals[(size_t)w * a.F * a.T + p] = v;
-    return;
+  if (t < rows) {
+    const double y = a.target_freqs[f0 + t];
+    const double ymax = __dmul_rn((double)(K - 1), val);
+    int q = -1;
+    double hy0 = 0.0, hy1 = 0.0;
+    if (!(y < 0.0 || y > ymax || !(y == y))) {
+      q = (int)floor(y / val);
+      q = q < 0 ? 0 : (q > K - 2 ? K - 2 : q);
+      while (q > 0 && y < __dmul_rn((double)q, val)) --q;
+      while (q < K - 2 && y >= __dmul_rn((double)(q + 1), val)) ++q;
+      const double yl = __dmul_rn((double)q, val), yr = __dmul_rn((double)(q + 1), val);
+      const double fy = __ddiv_rn(1.0, __dsub_rn(yr, yl));
+      hy0 = __dmul_rn(fy, __dsub_rn(yr, y));
+      hy1 = __dmul_rn(fy, __dsub_rn(y, yl));
+    }
+    rq[t] = q; rhy0[t] = hy0; rhy1[t] = hy1;
   }
-  const float vf = (float)v;
-  *o = vf;
-  if (a.out_max != nullptr && vf > 0.f) atomicMax(reinterpret_cast<int*>(a.out_max + w), __float_as_int(vf));
+  __syncthreads();
+  float fmax = 0.f;
+  for (int i = t; i < rows * a.T; i += 256) {
+    const int r = i / a.T, ti = i - r * a.T;
+    const int l = cl[ti], q = rq[r];
+    double v;
+    if (l < 0 || q < 0) {
+      v = a.fill_value;
+    } else {
+      const double hx0 = chx0[ti], hx1 = chx1[ti], hy0 = rhy0[r], hy1 = rhy1[r];
+      const double* c0 = a.logmag + ((size_t)w * a.maxframes + l) * K + q;       // coefficient c[time l][freq q]
+      const double* c1 = c0 + K;
+      double sp = 0.0;
+      sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c0[0], hx0), hy0));
+      sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c0[1], hx0), hy1));
+      sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c1[0], hx1), hy0));
+      sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(c1[1], hx1), hy1));
+      v = sp;
+    }
+    v = __dsub_rn(v, a.spec_min);
+    v = __ddiv_rn(v, a.range);                                         // utils.py:101-102
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    if (a.normalize) {                                                 // utils.py:104-108 follow in spec_normalize_kernel
+      a.vals[((size_t)w * a.F + f0) * a.T + i] = v;
+    } else {
+      const float vf = (float)v;
+      obase[i] = vf;
+      fmax = vf > fmax ? vf : fmax;
+    }
+  }
+  if (a.out_max != nullptr && !a.normalize) {                          // one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(fmax, o, 64); fmax = y > fmax ? y : fmax; }
+    if ((t & 63) == 0 && fmax > 0.f) atomicMax(reinterpret_cast<int*>(a.out_max + w), __float_as_int(fmax));
+  }
 }
 
 // within_syll_normalize (utils.py:104-108): spec -= np.quantile(spec, q); spec[spec < 0] = 0; spec /= max(spec) + EPSILON.
@@ -467,7 +505,7 @@ extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int6
   if (audio == nullptr || file_off == nullptr || file_len == nullptr || file_idx == nullptr || t1 == nullptr ||
       t2 == nullptr || target_times == nullptr || window == nullptr || target_freqs == nullptr || out == nullptr)
     return AVA_EINVAL;
-  if (n <= 0 || F <= 0 || T <= 0 || max_samples <= 0 || !(fs > 0.0) || !spec_shape_ok(nperseg, noverlap)) return AVA_EINVAL;
+  if (n <= 0 || F <= 0 || T <= 0 || T > AVA_SPEC_TMAX || max_samples <= 0 || !(fs > 0.0) || !spec_shape_ok(nperseg, noverlap)) return AVA_EINVAL;
   if (audio_dtype < AVA_AUDIO_I16 || audio_dtype > AVA_AUDIO_F64) return AVA_EINVAL;
   if (!(spec_max != spec_min)) return AVA_EINVAL;
   if (normalize && (q_lo < 0 || q_lo >= F * T || !(q_gamma >= 0.0 && q_gamma <= 1.0))) return AVA_EINVAL;
@@ -504,7 +542,7 @@ extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int6
     default: hipLaunchKernelGGL(spec_stft_kernel<11>, fgrid, dim3(256), 0, st, a); break;
   }
   AVA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(spec_interp_kernel, dim3(ceil_div(F * T, 256), n), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(spec_interp_kernel, dim3(ceil_div(F, AVA_SPEC_ROWS), n), dim3(256), 0, st, a);
   AVA_CHECK_LAUNCH();
   if (normalize) {
     hipLaunchKernelGGL(spec_normalize_kernel, dim3(n), dim3(AVA_SPEC_NORM_T), 0, st, a);

@@ -13,7 +13,8 @@ order, so that a seeded call picks the very windows the reference picks), and th
 produced by three launches (``csrc/spec.hip``) straight into the fp32 ``[batch, freq, time]`` tensor the VAE step
 consumes: no CPU workers, no host-to-device copy of spectrograms.
 
-Not covered: ``nperseg`` must be a power of two in 64..2048 (``NotImplementedError`` otherwise).  There is no CPU
+Not covered: ``nperseg`` must be a power of two in 64..2048, at most 512 target times per window
+(``NotImplementedError`` otherwise).  There is no CPU
 fallback.
 """
 import warnings
@@ -153,6 +154,8 @@ def get_spec_batch(audio, file_idx, t1, t2, p, fs, target_times, target_freqs=No
     nperseg, noverlap = int(p['nperseg']), int(p['noverlap'])
     if nperseg < 64 or nperseg > 2048 or nperseg & (nperseg - 1) or not 0 <= noverlap < nperseg:
         raise NotImplementedError("device get_spec needs nperseg a power of two in 64..2048 and 0 <= noverlap < nperseg")
+    if T > 512:
+        raise NotImplementedError("device get_spec handles at most 512 target times per window")
     max_samples = int((s2 - s1).max())
     lib, dev = _lib.load(), audio.device
     window, scale = _stft_constants(nperseg, dev)

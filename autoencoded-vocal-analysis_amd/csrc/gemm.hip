@@ -13,32 +13,9 @@
 // one is multiplied.  Small-MN / large-K products are split along K into partial slabs that a
 // second kernel sums (fixed order: deterministic) and finishes with bias + activation.
 #include <stdlib.h>
-#include "common.h"
+#include "gemm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_EXP = 2 };
-
-struct GemmArgs {
-  const float* A;
-  const float* B;
-  const float* bias;
-  float* C;          // output, or partial slabs [splits][M][N]
-  float* colsum;
-  const float* mask; // optional: C = mask > 0 ? v : 0 (ReLU backward of the producing layer), leading dim ldc
-  int M, N, K;
-  int lda, ldb, ldc; // leading dimension (elements) of the stored matrices
-  int klen;          // K elements per split (multiple of 16)
-  int splits;
-  int act;
-  int vec_a, vec_b;  // 16-byte loads legal
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == ACT_RELU) return fmaxf(v, 0.f);
-  if (act == ACT_EXP) return expf(v);   // full-precision expf (vae.py:232)
-  return v;
-}
 
 #define AVA_OPAQUE4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 
@@ -484,6 +461,9 @@ static void plan(int M, int N, int K, int* bm, int* splits, int* klen) {
 extern "C" size_t ava_gemm_workspace_bytes(int M, int N, int K) {
   int bm, splits, klen;
   plan(M, N, K, &bm, &splits, &klen);
+  int lbn, lsplits, lklen;
+  ava_gemm_limb_plan(M, N, K, &lbn, &lsplits, &lklen);      // whichever kernel ava_gemm picks for the operands it is given
+  if (lsplits > splits) splits = lsplits;
   return splits > 1 ? ((size_t)splits * M * N + (size_t)splits * M) * sizeof(float) : 0;
 }
 
@@ -503,6 +483,7 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   plan(M, N, K, &bm, &splits, &klen);
   if (splits > 1 && (ws == nullptr || ws_bytes < ava_gemm_workspace_bytes(M, N, K))) return AVA_EWORKSPACE;
   GemmArgs g;
+  g.dbg = 0;
   g.A = A; g.B = B; g.bias = bias; g.colsum = colsum; g.mask = mask;
   g.C = splits > 1 ? reinterpret_cast<float*>(ws) : C;
   g.M = M; g.N = N; g.K = K;
@@ -516,6 +497,26 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   g.vec_b = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (b_kmajor ? K % 4 == 0 && K >= 4 : N % 4 == 0 && N >= 4);
   const bool vec = g.vec_a && g.vec_b;
   hipStream_t st = to_stream(s);
+  if (ava_gemm_limb_ok(g, a_kmajor, b_kmajor)) {
+    // the fc1 / fc8 products: three-limb bf16 matrix-core kernel (gemm_limb.hip), fp32-faithful
+    int lbn;
+    ava_gemm_limb_plan(M, N, K, &lbn, &splits, &klen);
+    if (splits > 1 && (ws == nullptr || ws_bytes < ((size_t)splits * M * N + (size_t)splits * M) * sizeof(float)))
+      return AVA_EWORKSPACE;
+    g.klen = klen; g.splits = splits;
+    g.C = splits > 1 ? reinterpret_cast<float*>(ws) : C;
+    const int rc = ava_gemm_limb_launch(g, a_kmajor, b_kmajor, lbn, st);
+    if (rc != AVA_OK) return rc;
+    if (splits > 1) {
+      const size_t mn = (size_t)M * N;
+      int blocks = (int)((mn + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(ws), bias,
+                         mask, C, colsum, M, N, g.ldc, splits, act);
+      AVA_CHECK_LAUNCH();
+    }
+    return AVA_OK;
+  }
   if (skinny_ok(g, a_kmajor, b_kmajor)) {
     g.C = C;
     const dim3 sgrid(ceil_div(N, 16), ceil_div(M, 16));
@@ -571,7 +572,7 @@ int ava_gemm_grouped(const AvaGemmProblem* p, int n, int a_kmajor, int b_kmajor,
     g.lda = p[i].lda > 0 ? p[i].lda : (a_kmajor ? g.K : g.M);
     g.ldb = p[i].ldb > 0 ? p[i].ldb : (b_kmajor ? g.K : g.N);
     g.ldc = p[i].ldc > 0 ? p[i].ldc : g.N;
-    g.klen = ceil_div(g.K, 16) * 16; g.splits = 1; g.act = p[i].act;
+    g.klen = ceil_div(g.K, 16) * 16; g.splits = 1; g.act = p[i].act; g.dbg = 0;
     g.vec_a = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
               (a_kmajor ? g.K % 4 == 0 && g.K >= 4 : g.M % 4 == 0 && g.M >= 4);
     g.vec_b = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&

@@ -1,0 +1,485 @@
+// fp32-faithful GEMM on the gfx950 bf16 matrix cores for the large products of the fully connected layers (fc1 / fc8
+// forward, dX, dW: ava/models/vae.py:142,153,225,261 and their autograd products).
+//
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md, Matrix cores).  An fp32 value is EXACTLY
+// the sum of three bf16 "limbs" (8 + 8 + 8 significand bits, round-to-nearest at each cut, so |a1| <= 2^-8 |a|,
+// |a2| <= 2^-17 |a|):  a = a0 + a1 + a2,  b = b0 + b1 + b2.  The product keeps the six limb pairs with i + j <= 2,
+//     a b  ~  a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0 ,
+// each on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the three dropped pairs are <= 2^-24 |a b| together, i.e.
+// below one fp32 rounding of the product.  Six bf16 MFMAs replace sixteen fp32 MFMAs' worth of matrix time.
+//
+// Tiling: BM x BN = 128 x (128 | 64) output tile, K step 32, 256 threads = 2 x 2 waves, wave tile 64 x (64 | 32) as
+// 16 x 16 MFMA tiles.  Operands are split while they are staged: global fp32 (16-byte loads, either storage order)
+// -> registers -> three limb planes in LDS, K contiguous ([limb][row][32 k] bf16, 64-byte rows), so that one
+// ds_read_b128 is one MFMA operand fragment and a wave reads 1 KB of contiguous LDS (conflict free).  Operands stored
+// with K strided (the dW products, W in the dX products) are transposed in registers (4 k x 4 columns per thread);
+// their rows sit in the image with bits 0 and 2 of the row index swapped, which makes those 8-byte writes conflict
+// free as well.  Double-buffered LDS, one barrier per K step, tile k+2 in flight in registers while tile k is
+// multiplied (same pipeline as gemm.hip).  Split-K writes fp32 slabs that gemm.hip's fixed-order reduce kernel sums.
+#include <type_traits>
+#include "gemm.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LBK 32
+
+// (x, y) -> three packed bf16 pairs; x = x0 + x1 + x2 exactly (the two subtractions are exact in fp32, the last
+// remainder has <= 8 significant bits)
+// The subtractions are written as single v_sub_f32: left to itself hipcc pairs them into v_pk_add_f32, which issues at
+// a third of the rate of two scalar ops beside MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+__device__ __forceinline__ float limb_sub(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void limb_split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x, y}, bf16x2));
+  float rx = limb_sub(x, __uint_as_float(p0 << 16)), ry = limb_sub(y, __uint_as_float(p0 & 0xffff0000u));
+  p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){rx, ry}, bf16x2));
+  rx = limb_sub(rx, __uint_as_float(p1 << 16));
+  ry = limb_sub(ry, __uint_as_float(p1 & 0xffff0000u));
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){rx, ry}, bf16x2));
+}
+
+// position of logical row r (0..15) inside its 16-row block of the LDS image
+template <bool PERM>
+__device__ __forceinline__ int pos16(int r) {
+  return PERM ? ((r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1)) : r;
+}
+// 16-byte chunk (0..3) of a row's 64 bytes that holds k octet `oct` of logical row r.  With 64-byte rows the rows r and
+// r + 4 start on the same bank, and ds_read_b128 serves lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... together
+// (MI355X_MICROARCH.md, LDS): each such group holds four rows of every bank class, two per k octet.  XOR-ing the chunk
+// index with a function of the row spreads them over the four chunks: conflict-free fragment reads (checked lane group
+// by lane group for both images), and the writes keep their contiguity (a row's four chunks are only permuted).
+template <bool PERM>
+__device__ __forceinline__ int chunk_of(int r, int oct) {
+  return PERM ? (oct ^ ((r & 1) << 1)) : (oct ^ ((4 - ((r >> 2) & 3)) & 3));
+}
+
+// The staging waves keep RING steps of operand tiles in registers: the loads of step s + RING - 1 are issued while step s
+// is being split into LDS, so a tile has RING - 2 whole K steps (plus the current one) to arrive from L2 / HBM.
+#define LIMB_RING 4
+
+// ---- K-contiguous source: element (row, k) at base[row * ld + k].  Unit = 8 consecutive k of one row. -------------
+template <int BT, int T>
+struct LimbLoaderK {
+  static constexpr int UNITS = BT * 4, NU = (UNITS + T - 1) / T;
+  float4 r[LIMB_RING][NU][2];
+  unsigned ok[LIMB_RING];      // bit i: unit i of that slot lies inside the matrix and inside its item's K range
+  size_t off[NU];              // load-side state of the item being loaded
+  unsigned okrow;
+  __device__ __forceinline__ void init(int t0, int extent, int ld) {
+    okrow = 0u;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int u = threadIdx.x + T * i, row = u >> 2, oct = u & 3, g = t0 + row;
+      if (u < UNITS && g < extent) okrow |= 1u << i;
+      off[i] = (size_t)min(g, extent - 1) * ld + oct * 8;
+    }
+  }
+  template <int SLOT>
+  __device__ __forceinline__ void load(const float* __restrict__ base, int /*ld*/, int k0, int kend, int K) {
+    unsigned okk = 0u;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int oct = (threadIdx.x + T * i) & 3, gk = k0 + oct * 8;
+      const float* p = base + off[i] + min(k0, K - 8 - oct * 8);        // K % 8 == 0: an octet is inside or outside as a whole
+      r[SLOT][i][0] = *reinterpret_cast<const float4*>(p);
+      r[SLOT][i][1] = *reinterpret_cast<const float4*>(p + 4);
+      if (gk < kend) okk |= 1u << i;
+    }
+    ok[SLOT] = okk & okrow;
+  }
+  template <int SLOT, bool COLSUM>
+  __device__ __forceinline__ void store(unsigned char* __restrict__ S) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int u = threadIdx.x + T * i, row = u >> 2, oct = u & 3;
+      if (UNITS % T != 0 && u >= UNITS) continue;
+      float4 a = r[SLOT][i][0], b = r[SLOT][i][1];
+      if (!((ok[SLOT] >> i) & 1u)) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+      u32x4 p0, p1, p2;
+      uint32_t x, y, z;
+      limb_split2(a.x, a.y, x, y, z); p0[0] = x; p1[0] = y; p2[0] = z;
+      limb_split2(a.z, a.w, x, y, z); p0[1] = x; p1[1] = y; p2[1] = z;
+      limb_split2(b.x, b.y, x, y, z); p0[2] = x; p1[2] = y; p2[2] = z;
+      limb_split2(b.z, b.w, x, y, z); p0[3] = x; p1[3] = y; p2[3] = z;
+      unsigned char* d = S + row * 64 + chunk_of<false>(row & 15, oct) * 16;
+      *reinterpret_cast<u32x4*>(d) = p0;
+      *reinterpret_cast<u32x4*>(d + BT * 64) = p1;
+      *reinterpret_cast<u32x4*>(d + 2 * BT * 64) = p2;
+    }
+  }
+};
+
+// ---- K-strided source: element (k, col) at base[k * ld + col].  Unit = 4 k x 4 columns, transposed in registers.
+// Thread -> (kq = u & 7, cq = u >> 3): a wave's load covers 8 rows x 128 contiguous bytes. ----------------------------
+template <int BT, int T>
+struct LimbLoaderN {
+  static constexpr int UNITS = 2 * BT, NU = (UNITS + T - 1) / T;
+  float4 r[LIMB_RING][NU][4];
+  unsigned ok[LIMB_RING];      // bit 4 i + j: row j of unit i of that slot is inside the matrix / the item's K range
+  int coff[NU];
+  unsigned okcol;
+  float cs[NU][4];             // running column sums of the item being stored (bias gradient of the dW products)
+  __device__ __forceinline__ LimbLoaderN() {
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cs[i][c] = 0.f;
+  }
+  __device__ __forceinline__ void init(int t0, int extent, int /*ld*/) {
+    okcol = 0u;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int u = threadIdx.x + T * i, cq = u >> 3, g = t0 + 4 * cq;
+      if (u < UNITS && g < extent) okcol |= 0xfu << (4 * i);   // extent % 4 == 0: a column quad is inside or outside as a whole
+      coff[i] = min(g, extent - 4);
+    }
+  }
+  template <int SLOT>
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int k0, int kend, int K) {
+    unsigned okk = 0u;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int kq = (threadIdx.x + T * i) & 7;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gk = k0 + 4 * kq + j;
+        r[SLOT][i][j] = *reinterpret_cast<const float4*>(base + (size_t)min(gk, K - 1) * ld + coff[i]);
+        if (gk < kend) okk |= 1u << (4 * i + j);
+      }
+    }
+    ok[SLOT] = okk & okcol;
+  }
+  template <int SLOT, bool COLSUM>
+  __device__ __forceinline__ void store(unsigned char* __restrict__ S) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int u = threadIdx.x + T * i, kq = u & 7, cq = u >> 3;
+      if (UNITS % T != 0 && u >= UNITS) continue;
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool okj = (ok[SLOT] >> (4 * i + j)) & 1u;
+        v[j][0] = okj ? r[SLOT][i][j].x : 0.f; v[j][1] = okj ? r[SLOT][i][j].y : 0.f;
+        v[j][2] = okj ? r[SLOT][i][j].z : 0.f; v[j][3] = okj ? r[SLOT][i][j].w : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (COLSUM) cs[i][c] += (v[0][c] + v[1][c]) + (v[2][c] + v[3][c]);
+        u32x2 p0, p1, p2;
+        uint32_t x, y, z;
+        limb_split2(v[0][c], v[1][c], x, y, z); p0[0] = x; p1[0] = y; p2[0] = z;
+        limb_split2(v[2][c], v[3][c], x, y, z); p0[1] = x; p1[1] = y; p2[1] = z;
+        const int row = 4 * cq + c;
+        unsigned char* d = S + ((row & ~15) + pos16<true>(row & 15)) * 64 + chunk_of<true>(row & 15, kq >> 1) * 16 + (kq & 1) * 8;
+        *reinterpret_cast<u32x2*>(d) = p0;
+        *reinterpret_cast<u32x2*>(d + BT * 64) = p1;
+        *reinterpret_cast<u32x2*>(d + 2 * BT * 64) = p2;
+      }
+    }
+  }
+};
+
+template <int BT, int T, bool KMAJ>
+struct LimbLoader;
+template <int BT, int T>
+struct LimbLoader<BT, T, true> : LimbLoaderK<BT, T> {};
+template <int BT, int T>
+struct LimbLoader<BT, T, false> : LimbLoaderN<BT, T> {};
+
+// One work item = (split, tile row, tile column).  A workgroup walks its items as ONE continuous sequence of K steps:
+// the staging waves run up to one step ahead across item boundaries, so the first loads of the next item are in flight
+// while the matrix-core waves finish the current one and write it out (no LDS in the epilogue: the MFMA operands are
+// swapped, D' = B^T A^T, so a lane's four accumulator registers are four consecutive columns of one output row).
+struct LimbItem { int m0, n0, split, kbeg, kend, bx; };
+
+template <int BN, bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const int tiles_m, const int tiles_n,
+                                                        const int nitems) {
+  constexpr int BM = 128, T = 256, WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int A_BYTES = 3 * BM * 64, B_BYTES = 3 * BN * 64, BUF = A_BYTES + B_BYTES;
+  __shared__ __align__(16) unsigned char smem[2 * BUF];
+
+  const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
+  const bool stager = wave8 < 4;
+  // item list: workgroups on one XCD (workgroup index mod 8) take a contiguous eighth of the list, so that items which
+  // share an operand panel share an L2 (speed only)
+  int it, it_end, it_step;
+  {
+    const int gsz = (int)gridDim.x, w = (int)blockIdx.x;
+    if (((gsz | nitems) & 7) == 0) { const int chunk = nitems >> 3, x = w & 7; it = x * chunk + (w >> 3); it_end = (x + 1) * chunk; it_step = gsz >> 3; }
+    else { it = w; it_end = nitems; it_step = gsz; }
+  }
+  auto decode = [&](int item) {
+    LimbItem r;
+    const int per = tiles_m * tiles_n;
+    r.split = item / per;
+    const int rem = item - r.split * per;
+    const int by = rem / tiles_n;
+    r.bx = rem - by * tiles_n;
+    r.m0 = by * BM; r.n0 = r.bx * BN;
+    r.kbeg = r.split * g.klen;
+    r.kend = min(g.K, r.kbeg + g.klen);
+    return r;
+  };
+  if (it >= it_end) return;
+
+  if (stager) {
+    // ------------------------------------------------ staging waves ------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    LimbLoader<BM, T, A_KMAJ> la;
+    LimbLoader<BN, T, B_KMAJ> lb;
+    // total K steps of this workgroup's item list: both roles pass exactly one barrier per step (plus the initial one)
+    int S = 0;
+    for (int i = it; i < it_end; i += it_step) { const LimbItem q = decode(i); S += (q.kend - q.kbeg + LBK - 1) / LBK; }
+    // load cursor: the next step to request;  store cursor (RING - 1 steps behind at most): the next step to split
+    int l_it = it, s_it = it;
+    LimbItem li = decode(l_it), si = li;
+    int l_k = li.kbeg, s_k = si.kbeg;
+    // The load-side state of the loaders (row offsets, bounds) is set right before the first load of an item; what a
+    // later store needs (the in-range masks) is captured per ring slot at load time.
+    auto load_step = [&](auto slot) {
+      constexpr int SLOT = decltype(slot)::value;
+      if (l_k == li.kbeg) { la.init(li.m0, g.M, g.lda); lb.init(li.n0, g.N, g.ldb); }
+      if (!AVA_DBG_BIT(g, 4)) {
+        la.template load<SLOT>(g.A, g.lda, l_k, li.kend, g.K);
+        lb.template load<SLOT>(g.B, g.ldb, l_k, li.kend, g.K);
+      }
+      l_k += LBK;
+      if (l_k >= li.kend) {
+        l_it += it_step;
+        if (l_it < it_end) { li = decode(l_it); l_k = li.kbeg; }
+      }
+    };
+    auto store_step = [&](auto slot, int buf) {
+      constexpr int SLOT = decltype(slot)::value;
+      unsigned char* S_ = smem + buf * BUF;
+      if (!AVA_DBG_BIT(g, 2)) {
+        la.template store<SLOT, !A_KMAJ>(S_);
+        lb.template store<SLOT, false>(S_ + A_BYTES);
+      }
+      s_k += LBK;
+      if (s_k >= si.kend) {             // last step of an item: its column sums (bias gradient) are complete
+        if constexpr (!A_KMAJ) {
+          if (g.colsum != nullptr && si.bx == 0) {
+            const bool fin = g.splits == 1;
+#pragma unroll
+            for (int i = 0; i < LimbLoaderN<BM, T>::NU; ++i) {
+              const int u = t + T * i, cq = u >> 3;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                float v = la.cs[i][c];     // the 8 threads (kq = lane & 7) that own the same 4 columns, fixed order
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                const int gm = si.m0 + 4 * cq + c;
+                if ((u & 7) == 0 && u < LimbLoaderN<BM, T>::UNITS && gm < g.M) {
+                  if (fin) g.colsum[gm] = v;
+                  else g.C[(size_t)g.splits * g.M * g.N + (size_t)si.split * g.M + gm] = v;   // partial, behind the slabs
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < LimbLoaderN<BM, T>::NU; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) la.cs[i][c] = 0.f;
+        }
+        s_it += it_step;
+        if (s_it < it_end) { si = decode(s_it); s_k = si.kbeg; }
+      }
+    };
+    // step j lives in ring slot j % RING.  Prologue: steps 0 .. RING-2 requested, step 0 split into buffer 0.
+    static_assert(LIMB_RING == 4, "the unrolled schedule below is written for a ring of four");
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    load_step(I0{});
+    if (S > 1) load_step(I1{});
+    if (S > 2) load_step(I2{});
+    store_step(I0{}, 0);
+    __syncthreads();                      // (A) step 0 ready
+    // stage s (the matrix-core waves multiply step s): request step s + 3 into the slot step s has left, split
+    // step s + 1 into the other LDS buffer
+    // Steady state WITHOUT conditionals around the loads: hipcc's waitcnt pass merges the two sides of an `if (more) load`
+    // conservatively (it must assume the loads were not issued), which turns the store's wait into vmcnt(0) -- i.e. into
+    // a wait for the loads issued a moment ago, and the ring into a one-deep pipeline.
+    int s0 = 0;
+#define LIMB_STAGE_FULL(SL_LOAD, SL_STORE, J)                             \
+      load_step(SL_LOAD{});                                               \
+      store_step(SL_STORE{}, (s0 + J + 1) & 1);                           \
+      __syncthreads();                    /* (B) step consumed, next ready */
+    for (; s0 + 6 < S; s0 += 4) {
+      LIMB_STAGE_FULL(I3, I1, 0)
+      LIMB_STAGE_FULL(I0, I2, 1)
+      LIMB_STAGE_FULL(I1, I3, 2)
+      LIMB_STAGE_FULL(I2, I0, 3)
+    }
+#undef LIMB_STAGE_FULL
+    for (; s0 < S; s0 += 4) {             // the last (up to 6) steps
+#define LIMB_STAGE(J, SL_LOAD, SL_STORE)                                  \
+      if (s0 + J < S) {                                                   \
+        if (s0 + J + 3 < S) load_step(SL_LOAD{});                         \
+        if (s0 + J + 1 < S) store_step(SL_STORE{}, (s0 + J + 1) & 1);     \
+        __syncthreads();                  /* (B) */                        \
+      }
+      LIMB_STAGE(0, I3, I1)
+      LIMB_STAGE(1, I0, I2)
+      LIMB_STAGE(2, I1, I3)
+      LIMB_STAGE(3, I2, I0)
+#undef LIMB_STAGE
+    }
+    return;
+  }
+
+  // -------------------------------------------------- matrix-core waves --------------------------------------------------
+  const int wave = wave8 & 3, wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, kg = lane >> 4;
+  const int a_lane = (wm * WM) * 64 + pos16<!A_KMAJ>(fr) * 64 + chunk_of<!A_KMAJ>(fr, kg) * 16;
+  const int b_lane = A_BYTES + (wn * WN) * 64 + pos16<!B_KMAJ>(fr) * 64 + chunk_of<!B_KMAJ>(fr, kg) * 16;
+  f32x4 acc[TM][TN];
+  __syncthreads();                       // (A)
+  int s = 0;
+  for (; it < it_end; it += it_step) {
+    const LimbItem ci = decode(it);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = ci.kbeg; k0 < ci.kend; k0 += LBK, ++s) {
+      const unsigned char* As = smem + (s & 1) * BUF + a_lane;
+      const unsigned char* Bs = smem + (s & 1) * BUF + b_lane;
+      bf16x8 af[TM][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) af[i][l] = *reinterpret_cast<const bf16x8*>(As + l * BM * 64 + i * 1024);
+      if (!AVA_DBG_BIT(g, 1))
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bf16x8 bf[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) bf[l] = *reinterpret_cast<const bf16x8*>(Bs + l * BN * 64 + j * 1024);
+        // D' = B^T A^T (rows = n, columns = m); smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i][2], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[2], af[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i][0], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();                   // (B)
+    }
+    // ---- epilogue, straight from the accumulators: lane (fr, kg) holds C[m0 + .. + fr][n0 + .. + 4 kg + 0..3] ----
+    const bool fin = g.splits == 1;
+    const int ldo = fin ? g.ldc : g.N;
+    float* __restrict__ obase = fin ? g.C : g.C + (size_t)ci.split * g.M * g.N;
+    if (!AVA_DBG_BIT(g, 8))
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
+      if (gn >= g.N) continue;           // N % 4 == 0: a quad is inside or outside as a whole
+      float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (fin && g.bias != nullptr) bq = *reinterpret_cast<const float4*>(g.bias + gn);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int gm = ci.m0 + wm * WM + i * 16 + fr;
+        if (gm >= g.M) continue;
+        float cv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (fin) {
+          cv[0] = apply_act(cv[0] + bq.x, g.act); cv[1] = apply_act(cv[1] + bq.y, g.act);
+          cv[2] = apply_act(cv[2] + bq.z, g.act); cv[3] = apply_act(cv[3] + bq.w, g.act);
+          if (g.mask != nullptr) {
+            const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)gm * g.ldc + gn);
+            if (!(mk.x > 0.f)) cv[0] = 0.f;
+            if (!(mk.y > 0.f)) cv[1] = 0.f;
+            if (!(mk.z > 0.f)) cv[2] = 0.f;
+            if (!(mk.w > 0.f)) cv[3] = 0.f;
+          }
+        }
+        *reinterpret_cast<float4*>(obase + (size_t)gm * ldo + gn) = make_float4(cv[0], cv[1], cv[2], cv[3]);
+      }
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+// Shapes the limb kernel takes: the products whose two long sides are those of fc1 / fc8 (1024 x F); the third is the
+// batch, of any size.  The rule looks at the shape only, so a layer runs the same arithmetic at every batch size.
+static bool limb_shape(int M, int N, int K) {
+  const int mn = M < N ? M : N, mnk = mn < K ? mn : K;
+  const size_t pair = (size_t)M * N * K / (size_t)mnk;
+  return pair >= ((size_t)1 << 22);
+}
+
+bool ava_gemm_limb_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
+  static const bool on = [] { const char* e = ava_env("AVA_GEMM_LIMB"); return e == nullptr || atoi(e) != 0; }();
+  if (!on || !limb_shape(g.M, g.N, g.K) || !g.vec_a || !g.vec_b) return false;
+  if ((a_kmajor || b_kmajor) && g.K % 8 != 0) return false;
+  if (!a_kmajor && g.M % 4 != 0) return false;
+  if (!b_kmajor && g.N % 4 != 0) return false;
+  if (g.colsum != nullptr && a_kmajor) return false;
+  // the epilogue stores (and reads bias / mask) as 16-byte quads of one output row
+  if (g.N % 4 != 0 || g.ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(g.C) & 15) != 0) return false;
+  if (g.bias != nullptr && (reinterpret_cast<uintptr_t>(g.bias) & 15) != 0) return false;
+  if (g.mask != nullptr && (reinterpret_cast<uintptr_t>(g.mask) & 15) != 0) return false;
+  return true;
+}
+
+void ava_gemm_limb_plan(int M, int N, int K, int* bn, int* splits, int* klen) {
+  // wide outputs against a short K (fc8 forward, fc1 dX: batch x 8192, K = 1024): 128 x 64 tiles fill the chip
+  // without split-K (no slabs, no reduce launch)
+  int b = 128;
+  if (ceil_div(M, 128) * ceil_div(N, 128) < 256 && ceil_div(M, 128) * ceil_div(N, 64) >= 192 && K <= 2048) b = 64;
+  { const char* e = ava_env("AVA_GEMM_LIMB_BN"); if (e) b = atoi(e) == 64 ? 64 : 128; }
+  const int tiles = ceil_div(M, 128) * ceil_div(N, b);
+  int s = 1;
+  if (tiles < 192) {
+    s = ceil_div(256, tiles);
+    const int max_s = K / 64 > 0 ? K / 64 : 1;        // at least 2 K steps per split
+    if (s > max_s) s = max_s;
+  }
+  { const char* e = ava_env("AVA_GEMM_LIMB_SPLITS"); if (e) { s = atoi(e); if (s < 1) s = 1; if (s > ceil_div(K, LBK)) s = ceil_div(K, LBK); } }
+  int kl = ceil_div(ceil_div(K, s), LBK) * LBK;
+  s = ceil_div(K, kl);
+  *bn = b; *splits = s; *klen = kl;
+}
+
+template <int BN>
+static void launch_limb(const GemmArgs& g, int a_k, int b_k, int tm, int tn, int nitems, int grid, hipStream_t st) {
+  if (a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, true>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  else if (a_k && !b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, false>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  else if (!a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, false, true>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  else hipLaunchKernelGGL((gemm_limb_kernel<BN, false, false>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+}
+
+int ava_gemm_limb_launch(const GemmArgs& g0, int a_kmajor, int b_kmajor, int bn, hipStream_t st) {
+  GemmArgs g = g0;
+  { const char* e = ava_env("AVA_GEMM_LIMB_DBG"); g.dbg = e ? atoi(e) : 0; }
+  const int tm = ceil_div(g.M, 128), tn = ceil_div(g.N, bn), nitems = tm * tn * g.splits;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  int grid = nitems < cus ? nitems : cus;          // one 512-thread workgroup per CU (96 KB of LDS), persistent over its items
+  { const char* e = ava_env("AVA_GEMM_LIMB_GRID"); if (e) { grid = atoi(e); if (grid > nitems) grid = nitems; if (grid < 1) grid = 1; } }
+  if (bn == 64) launch_limb<64>(g, a_kmajor, b_kmajor, tm, tn, nitems, grid, st);
+  else launch_limb<128>(g, a_kmajor, b_kmajor, tm, tn, nitems, grid, st);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}

@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
                                                         float one_minus_b1, float b2, float one_minus_b2,
                                                         float step_size, float sqrt_bc2, float eps,
                                                         const int* __restrict__ skip_if_set) {
-  if (skip_if_set != nullptr && *skip_if_set != 0) return;     // the forward flagged d <= 0 / NaN: no update (vae.py:312)
+  if (skip_if_set != nullptr && *skip_if_set != 0) {           // the forward flagged d <= 0 / NaN: no update (vae.py:312)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<int*>(skip_if_set) + 1, 1);    // word 1 counts the skipped steps
+    return;
+  }
   float4* p4 = reinterpret_cast<float4*>(p);
   const float4* g4 = reinterpret_cast<const float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);

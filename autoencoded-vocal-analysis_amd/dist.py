@@ -58,6 +58,13 @@ def allreduce_max_(t):
     return t
 
 
+def allreduce_max_async(t):
+    """MAX over ranks enqueued like a gradient bucket (status words); returns the work handle."""
+    if not active():
+        return None
+    return td.all_reduce(t, op=td.ReduceOp.MAX, async_op=True)
+
+
 def broadcast_parameters(model, src=0):
     """Identical weights / BatchNorm buffers / Adam state on every rank."""
     if active():

@@ -218,7 +218,7 @@ class VAE(nn.Module):
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         self._loss_buf = torch.zeros(4, dtype=torch.float32, device=dev)
         self._loss_acc = torch.zeros((), dtype=torch.float64, device=dev)
-        self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._status = torch.zeros(2, dtype=torch.int32, device=dev)   # [0] d <= 0 flag, [1] Adam steps skipped because of it
 
     def _grad_view(self, name):
         o, n, shape = self._arena_views[name]
@@ -356,7 +356,9 @@ class VAE(nn.Module):
             return
         # data parallel: backward runs in parts; the gradient bucket a part completes (fc8 + decoder, then fc1..fc7,
         # then the encoder) is all-reduced asynchronously while the next part is still running
-        pending = []
+        # the "d not positive" word first: MAX over ranks, so that ava_adam_step's device-side guard and the epoch loop's
+        # poll see the SAME word on every rank (one rank's NaN gradients reach every rank through the all-reduce below)
+        pending = [_dist.allreduce_max_async(self._status)]
         for part in range(lib.ava_backward_num_parts()):
             _lib.check(lib.ava_backward_part(self._handle, x.data_ptr(), x.shape[0], part, _lib.stream()),
                        "ava_backward_part")
@@ -377,37 +379,56 @@ class VAE(nn.Module):
 
     def _check_status(self):
         """Blocking check of the device status word (d not positive in some forward so far).  Under data parallelism
-        the word is OR-ed over the ranks first, so that every rank raises together."""
+        the word is MAX-ed over the ranks first, so that every rank raises together."""
         if _dist.active():
             _dist.allreduce_max_(self._status)
-        if int(self._status.item()) != 0:
+        if int(self._status[0].item()) != 0:
             self._raise_invalid_posterior()
 
     def _raise_invalid_posterior(self):
+        # Adam launches issued between the offending forward and this point were skipped on the device (the kernel
+        # counts them in word 1): take them back out of the host-side step count, so that ``state['step']`` and the
+        # bias correction equal the number of updates really applied (the reference stops inside the offending forward,
+        # vae.py:312, and never reaches ``optimizer.step()``).  What is NOT rolled back: the forwards that ran in the
+        # meantime (at most the polling lag, two steps) have moved the BatchNorm running statistics.
+        skipped = int(self._status[1].item())
+        opt = getattr(self, "optimizer", None)
+        if opt is not None and skipped > 0:
+            opt._step_count_flat = max(0, opt._step_count_flat - skipped)
         self._status.zero_()
-        self._status_poll = None
+        self._status_polls = []
         # LowRankMultivariateNormal's argument validation (vae.py:312) raises the same type
         raise ValueError("Expected parameter cov_diag to be positive (d = exp(.) under/overflowed)")
+
+    _POLL_LAG = 2       # steps between a status copy and the step that looks at it
 
     def _poll_status(self):
         """Non-blocking form for the epoch loops.  The reference raises inside the offending ``forward``
         (vae.py:312); the loops here never wait for the device, so after every step the status word is copied to
-        page-locked host memory asynchronously and looked at as soon as the copy has landed (typically one or two
-        steps later, at the latest at the end of the epoch).  Parameters stay those of before the offending step in
-        the meantime: ``ava_adam_step`` skips the update on the device while the word is set."""
-        poll = getattr(self, "_status_poll", None)
-        if poll is not None:
-            host, ev = poll
-            if not ev.query():
-                return                                   # previous copy still in flight: look again next step
+        page-locked host memory asynchronously and looked at ``_POLL_LAG`` steps later (by then the copy has long
+        landed: the wait is free), at the latest at the end of the epoch.  The lag is a fixed number of steps rather
+        than "as soon as the copy has landed" so that under data parallelism -- where the word every rank copies is
+        the MAX over ranks (``_backward_kernels``) -- all ranks raise at the SAME step and none is left waiting in a
+        collective.  Parameters stay those of before the offending step in the meantime: ``ava_adam_step`` skips
+        the update on the device while the word is set."""
+        polls = getattr(self, "_status_polls", None)
+        if polls is None:
+            polls = self._status_polls = []
+        if len(polls) >= self._POLL_LAG:
+            host, ev = polls.pop(0)
+            ev.synchronize()
             if int(host[0]) != 0:
                 self._raise_invalid_posterior()
-        if getattr(self, "_status_host", None) is None:
-            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._status_host.copy_(self._status, non_blocking=True)
+        ring = getattr(self, "_status_hosts", None)
+        if ring is None:
+            ring = self._status_hosts = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(self._POLL_LAG + 1)]
+            self._status_slot = 0
+        host = ring[self._status_slot]
+        self._status_slot = (self._status_slot + 1) % len(ring)
+        host.copy_(self._status, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self._status_poll = (self._status_host, ev)
+        polls.append((host, ev))
 
     # intermediates that are ACTIVATIONS between the convolutions: bfloat16 when act_dtype says so
     _ACT_BUFFERS = frozenset(["y%d" % i for i in range(1, 7)] + ["d%d" % i for i in range(1, 7)] + ["f8t"])

@@ -79,8 +79,9 @@ int ava_model_create_ex(ava_model** out, int z_dim, int H, int W, int act_dtype,
  *   loss_out (device, 4 floats): {-ELBO, sum z^2, SSE, sum entropy}.
  *   loss_accum (device double, may be NULL): -ELBO is also added to it (the epoch loops' running sum,
  *     vae.py:351,382, kept on the device so that no step needs a host sync).
- *   status_out (device int, may be NULL): OR-ed with 1 when some d is not > 0 (reference raises ValueError);
- *     sticky -- the caller clears it after reading.
+ *   status_out (device int[2], may be NULL): word 0 is OR-ed with 1 when some d is not > 0 (reference raises
+ *     ValueError); sticky -- the caller clears it after reading.  Word 1 is incremented by every ava_adam_step that
+ *     skipped its update because word 0 was set (so the caller can take those steps back out of its step count).
  * x, eps_w, eps_d must stay valid until ava_backward has run.
  * Leaves every intermediate needed by ava_backward in the workspace, together with the BatchNorm mode: the backward of
  * a bn_train = 0 forward differentiates the running-statistics form (dx = gamma*invstd*g), as autograd does for

@@ -42,6 +42,10 @@ def _worker(rank, world, port, q):
         norms = {s.name: float(flat[offs[s.name]:offs[s.name] + s.numel].double().norm()) for s in layout.param_specs(z)}
         gl = adist.global_loss(out["loss"].detach().double(), z, 10.0, 1)
         n = adist.global_dataset_len(B)
+        # the "d not positive" status word travels with the buckets: MAX over ranks, asynchronously
+        st = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
+        adist.wait_all([adist.allreduce_max_async(st)])
+        assert st.tolist() == [1, 0]
         q.put((rank, float(out["loss"]), norms, gl, n))
     finally:
         td.destroy_process_group()

@@ -79,6 +79,65 @@ def test_two_rank_step_on_gpu():
     assert res[0][2] == res[1][2] and res[0][5] == res[1][5]   # identical reduced gradients and updated parameters
 
 
+def _nan_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    from ava_amd import dist as adist, synthetic as syn
+    from gpu_util import build_model
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, B = 32, 4
+        model = build_model(z)
+        adist.broadcast_parameters(model)
+        if rank == 1:                                     # ONE rank's posterior goes invalid (d = exp(NaN))
+            with torch.no_grad():
+                model.fc43.bias.fill_(float("nan"))
+        before = model._params.clone()
+        loader = syn.get_synthetic_data_loaders(B * 6, batch_size=B, shuffle=(False, False))["train"]
+        steps = []
+        orig = model.optimizer.step
+        model.optimizer.step = lambda *a, **k: (steps.append(1), orig(*a, **k))[1]
+        raised = False
+        try:
+            model.train_epoch(loader)
+        except ValueError:
+            raised = True
+        torch.cuda.synchronize()
+        same = (model._params == before) | (torch.isnan(model._params) & torch.isnan(before))
+        # a collective after the raise: hangs (test time-out) unless BOTH ranks left the epoch at the same step
+        t = torch.ones(1)
+        td.all_reduce(t)
+        q.put((rank, raised, len(steps), bool(same.all()), int(model.optimizer._step_count_flat), float(t.item())))
+    finally:
+        td.destroy_process_group()
+
+
+def test_invalid_posterior_on_one_rank_stops_every_rank_at_the_same_step():
+    """Data parallel: d <= 0 / NaN on ONE rank.  The status word is MAX-reduced with the gradient buckets before Adam's
+    device-side guard reads it, so no rank applies the (NaN-contaminated) reduced gradient, and the epoch loops poll it
+    at a fixed lag, so both ranks raise ValueError at the same step instead of one of them hanging in a collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, raised0, steps0, same0, cnt0, t0), (r1, raised1, steps1, same1, cnt1, t1) = res
+    assert raised0 and raised1
+    assert steps0 == steps1 and 1 <= steps0 <= 3          # same step on both ranks, within the polling lag
+    assert same0 and same1                                # no rank applied an update
+    assert cnt0 == 0 and cnt1 == 0                        # skipped steps taken back out of Adam's step count
+    assert t0 == 2.0 and t1 == 2.0
+
+
 def test_bench_gpus_2_starts_two_ranks_itself():
     """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks (a child torch.distributed.run) and
     rank 0 prints ONE line with n_gpus = 2.  The box has one GPU, so the hidden `--backend gloo` lets both ranks share

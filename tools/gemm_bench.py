@@ -37,7 +37,14 @@ for name, fin, fout in fc:
         for _ in range(n): torch.mm(At, Bt, out=C)
         e1.record(); torch.cuda.synchronize()
         us_lib = e0.elapsed_time(e1) * 1e3 / n
+        # accuracy against an fp64 product of the same fp32 operands (ours / the vendor library's fp32)
+        ref = At.double() @ Bt.double()
+        lib.ava_gemm(p(A), 0, p(Bm), 0, None, p(C), 0, None, p(cs) if kind == "dW" else None, M, N, K, ak, bk, 0, p(ws), nbytes, stream())
+        torch.cuda.synchronize()
+        den = float((At.double().abs() @ Bt.double().abs()).max())
+        err = float((C.double() - ref).abs().max()) / den
+        err_lib = float((torch.mm(At, Bt).double() - ref).abs().max()) / den
         mult = 3 if name in ("fc4x",) else 1
         tot[kind] += us * mult
-        print("%-5s %-3s M=%5d N=%5d K=%5d  %7.1f us  %6.1f TFLOP/s  ws=%d MB   torch.mm %7.1f us" % (name, kind, M, N, K, us, 2.0 * M * N * K / us / 1e6, nbytes >> 20, us_lib))
+        print("%-5s %-3s M=%5d N=%5d K=%5d  %7.1f us  %6.1f TFLOP/s  ws=%d MB   torch.mm %7.1f us   err/sum|ab| %.2e (torch.mm %.2e)" % (name, kind, M, N, K, us, 2.0 * M * N * K / us / 1e6, nbytes >> 20, us_lib, err, err_lib))
 print(tot, sum(tot.values()))

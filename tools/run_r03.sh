@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-3 GPU passes, one gpurun call each:  tools/run_r03.sh <pass>   (output under gpurun_out/r03_<pass>/)
+set -u
+pass=${1:-gemm}
+out=gpurun_out/r03_$pass
+mkdir -p $out
+case $pass in
+  gemm)
+    timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k gemm > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
+    timeout 300 python tools/gemm_bench.py > $out/gemm_bench.log 2>&1
+    for cfg in 128_1 64_1 128_2 64_2 128_8 128_16 128_32 64_16; do
+      bn=${cfg%_*}; sp=${cfg#*_}
+      AVA_HIP_LIB_TAG=lab AVA_GEMM_LIMB_BN=$bn AVA_GEMM_LIMB_SPLITS=$sp timeout 300 python tools/gemm_bench.py 2>&1 | grep -E "fc1|fc8" > $out/gemm_bench_bn${bn}_s${sp}.log
+    done
+    AVA_HIP_LIB_TAG=lab AVA_GEMM_LIMB=0 timeout 300 python tools/gemm_bench.py 2>&1 | grep -E "fc1|fc8" > $out/gemm_bench_fp32.log
+    timeout 600 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
+    ;;
+  gemmabl)
+    timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k gemm > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
+    for d in 0 1 2 4 8 3 6 7 15; do
+      AVA_HIP_LIB_TAG=lab AVA_GEMM_LIMB_DBG=$d timeout 300 python tools/gemm_bench.py 2>&1 | grep -E "fc1|fc8" | cut -c1-75 > $out/abl_$d.log
+    done
+    ;;
+  gemmprof)
+    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+    rocprofv3 --kernel-trace --stats -d $out/prof -o gemm --output-format csv -- python3 tools/gemm_bench.py > $out/gemm_bench.log 2>&1
+    find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+    rm -rf $out/prof
+    ;;
+  *) echo "unknown pass $pass"; exit 2;;
+esac
+tail -n 5 $out/pytest.log

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ava_last_z": (_p, [_p]),
     "ava_last_xrec": (_p, [_p]),
     "ava_debug_buffer": (_p, [_p, C.c_char_p, C.POINTER(_i64)]),
+    "ava_debug_materialize": (_i, [_p, _p, _i, _p]),
     "ava_profile_enable": (_i, [_p, _i]),
     "ava_profile_read": (_i, [_p, C.POINTER(_f), C.POINTER(_i)]),
     "ava_fill_normal": (_i, [_p, _i64, C.c_uint64, C.c_uint64, _p]),

@@ -8,6 +8,15 @@ enum { MODE_S1 = 0, MODE_DOWN = 1, MODE_UP = 2 };
 enum { PRO_BN = 0, PRO_BWD = 1, PRO_ID = 2 };
 enum { EPI_FWD = 0, EPI_BWD = 1, EPI_SSE = 2, EPI_NONE = 3 };   // EPI_NONE: store only (internal)
 
+// conv1 recomputed inside the consumer of its output (conv_recomp.h): when G1 != null the launch's 8-channel input
+// tensor does not exist in memory; `in` / `x` is the raw 1-channel spectrogram batch instead
+struct RecompArgs {
+  const float* G1 = nullptr;       // conv1 weights, gather layout [9][1][8]; null: no recomputation
+  const float* bias1 = nullptr;    // [8]
+  const float* pa1 = nullptr;      // bn1 scale / shift (one channel)
+  const float* pb1 = nullptr;
+};
+
 struct ConvArgs {
   const float* in;
   const float* in2;
@@ -30,6 +39,7 @@ struct ConvArgs {
   int act_bf16;  // 1: activations (layer inputs / saved outputs) are stored as bfloat16 (see ava_bf16 below)
   long long* acc_out;  // != null: the per-channel sums of the epilogue are accumulated here (bn_acc.h) instead of partial rows
   BnFin fin;     // fin.acc != null: the prologue coefficients are derived from accumulated sums instead of pa / pb / pc
+  RecompArgs rc; // rc.G1 != null: `in` is the raw spectrogram batch x and the kernel recomputes y1 = relu(conv1(bn1 x)) from it
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };
 
@@ -255,6 +265,7 @@ struct TileWalk {
 struct ConvAcc {
   long long* acc_out;    // producer side (null: partial rows)
   BnFin fin;             // consumer side (fin.acc null: coefficient arrays)
+  RecompArgs rc;         // conv2's forward: y1 recomputed from x (conv_recomp.h)
 };
 
 struct WgradArgs {

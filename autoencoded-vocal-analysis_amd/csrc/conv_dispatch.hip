@@ -172,6 +172,7 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
                    int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, const ConvAcc* acc,
                    ava_stream_t s) {
   ConvArgs a;
+  a.rc = acc != nullptr ? acc->rc : RecompArgs{};
   a.act_bf16 = act_bf16;
   a.acc_out = acc != nullptr ? acc->acc_out : nullptr;
   if (acc != nullptr) a.fin = acc->fin;

@@ -22,6 +22,7 @@ struct FusedArgs {
   long long* acc_out;    // != null: sum dx, sum dx*xhat are accumulated here (bn_acc.h) instead of bn_partials rows
   BnFin fin;             // fin.acc != null: da / db / dc are derived from the accumulated sums of the layer above
   int act_bf16;          // x and dy2 (activations) are stored as bfloat16; dy and dx (gradients) are always fp32
+  RecompArgs rc;         // rc.G1 != null: `x` is the raw spectrogram batch; the layer input y1 is recomputed from it (conv_recomp.h)
   int sweep;             // thin kernels: workgroups sweep the tile list together instead of per-XCD chunks
 };
 

@@ -8,11 +8,14 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "conv_mfma.h"
+#include "conv_recomp.h"
 
 // ACT: storage type of the activations this launch touches -- the input of a forward layer (PRO_BN), the saved
 // activation in2 of the ReLU/BatchNorm-backward prologue (PRO_BWD), the raw x of the BatchNorm-backward sums (EPI_BWD)
 // and the output of a forward layer (EPI_FWD).  Gradients (PRO_BWD / PRO_ID inputs, EPI_BWD outputs) are always fp32.
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR, typename ACT>
+// RECOMP (conv2's forward): the 8-channel input y1 = relu(conv1(bn1 x)) is not in memory; the staging waves build its
+// window from the x window (conv_recomp.h), a.in is x.
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR, typename ACT, bool RECOMP = false>
 __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) {
   using G = Geom<MODE, TW, TH>;
   using TIN = typename std::conditional<PRO == PRO_BN, ACT, float>::type;
@@ -28,6 +31,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   float* tile0 = smem;                      // two tile buffers
   float* coef = smem + 2 * TILE_F;          // [3][32]
   float* red = coef + 96;                   // [4][2*16*MTA]
+  float* xs = red + 4 * 32 * MTA;           // RECOMP: the staging waves' private x windows
+  static_assert(!RECOMP || (CIN == 8 && PRO == PRO_BN), "conv1 is recomputed in front of conv2's forward only");
   __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
 
   const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
@@ -44,12 +49,15 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
   TileWalk walk(a.ntiles);
-  TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT> stg;       // staging waves only (threadIdx.x 0..255)
+  typename std::conditional<RECOMP, Y1Stager<IR, IC, ACT>, TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT>>::type stg;   // staging waves only (threadIdx.x 0..255)
+  auto stg_store = [&](float* tile) {
+    if constexpr (RECOMP) stg.store(tile, coef, xs); else stg.store(tile, coef);
+  };
   // stride-2 gathers hold the most staging registers: keeping their first tile in flight across the prologue raised
   // conv2's forward from 70 to 112 VGPRs (3 -> 2 resident workgroups per CU, 42 -> 50 us); they load after it instead
   constexpr bool HOIST = MODE != MODE_DOWN;
   if (stager) {
-    stg.init();
+    if constexpr (RECOMP) stg.init(a.rc); else stg.init();
     if (HOIST && walk.valid()) {                                // tile 0 goes in flight BEFORE the coefficient prologue
       int b, oy0, ox0, gy0, gx0;
       origin(walk.cur, b, oy0, ox0, gy0, gx0);
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         origin(walk.cur, b, oy0, ox0, gy0, gx0);
         stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
       }
-      stg.store(tile0, coef);                                   // tile 0 -> buffer 0
+      stg_store(tile0);                                         // tile 0 -> buffer 0
       if (walk.has_next()) {
         origin(walk.next(), b, oy0, ox0, gy0, gx0);
         stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);         // tile 1 in flight
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     for (; walk.valid(); walk.advance(), ++it) {
       // while the matrix-core waves multiply tile `it`, store tile it+1 and fetch tile it+2
       if (walk.has_next()) {
-        stg.store(tile0 + ((it + 1) & 1) * TILE_F, coef);
+        stg_store(tile0 + ((it + 1) & 1) * TILE_F);
         const int nn = walk.next() + walk.step;
         if (nn < walk.end) {
           origin(nn, b, oy0, ox0, gy0, gx0);
@@ -262,16 +270,17 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   __syncthreads();
 }
 
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, typename ACT>
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, typename ACT, bool RECOMP = false>
 int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   constexpr int MT = (COUT + 15) / 16;
   constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // same rules as launch_mfma
   constexpr bool PAIR = MODE == MODE_S1 && COUT == 8;
-  const size_t lds = (size_t)(2 * G::IR * G::IC * CIN + 96 + 4 * 32 * MT) * sizeof(float);
+  constexpr int XS_F = RECOMP ? Y1Stager<G::IR, G::IC, ACT>::LDS_FLOATS : 0;
+  const size_t lds = (size_t)(2 * G::IR * G::IC * CIN + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
@@ -283,20 +292,27 @@ int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   int per_cu = 1;
   static int resident = 0;
   if (resident == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     resident = per_cu * 256;
   }
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
   if (grid > resident) grid = resident;
   { const char* e = ava_env("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
-  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>), dim3(grid), dim3(512), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
 template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH>
 int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
+  if constexpr (CIN == 8 && COUT == 8 && MODE == MODE_DOWN && PRO == PRO_BN && EPI == EPI_FWD) {
+    if (a.rc.G1 != nullptr) {             // conv2's forward on a recomputed y1 (a.in = x)
+      if (a.act_bf16) return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, ava_bf16, true>(a, grid, st);
+      return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, float, true>(a, grid, st);
+    }
+  }
+  if (a.rc.G1 != nullptr) return AVA_EINVAL;
   if (a.act_bf16) return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, ava_bf16>(a, grid, st);
   return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, float>(a, grid, st);
 }

@@ -31,5 +31,5 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // gemm_limb.hip
 bool ava_gemm_limb_ok(const GemmArgs& g, int a_kmajor, int b_kmajor);
-void ava_gemm_limb_plan(int M, int N, int K, int* bn, int* splits, int* klen);
+void ava_gemm_limb_plan(int M, int N, int K, int a_kmajor, int* bn, int* splits, int* klen);
 int ava_gemm_limb_launch(const GemmArgs& g, int a_kmajor, int b_kmajor, int bn, hipStream_t st);

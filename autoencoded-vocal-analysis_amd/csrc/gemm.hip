@@ -462,8 +462,10 @@ extern "C" size_t ava_gemm_workspace_bytes(int M, int N, int K) {
   int bm, splits, klen;
   plan(M, N, K, &bm, &splits, &klen);
   int lbn, lsplits, lklen;
-  ava_gemm_limb_plan(M, N, K, &lbn, &lsplits, &lklen);      // whichever kernel ava_gemm picks for the operands it is given
-  if (lsplits > splits) splits = lsplits;
+  for (int ak = 0; ak < 2; ++ak) {                          // whichever kernel ava_gemm picks for the operands it is given
+    ava_gemm_limb_plan(M, N, K, ak, &lbn, &lsplits, &lklen);
+    if (lsplits > splits) splits = lsplits;
+  }
   return splits > 1 ? ((size_t)splits * M * N + (size_t)splits * M) * sizeof(float) : 0;
 }
 
@@ -500,7 +502,7 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
   if (ava_gemm_limb_ok(g, a_kmajor, b_kmajor)) {
     // the fc1 / fc8 products: three-limb bf16 matrix-core kernel (gemm_limb.hip), fp32-faithful
     int lbn;
-    ava_gemm_limb_plan(M, N, K, &lbn, &splits, &klen);
+    ava_gemm_limb_plan(M, N, K, a_kmajor, &lbn, &splits, &klen);
     if (splits > 1 && (ws == nullptr || ws_bytes < ((size_t)splits * M * N + (size_t)splits * M) * sizeof(float)))
       return AVA_EWORKSPACE;
     g.klen = klen; g.splits = splits;

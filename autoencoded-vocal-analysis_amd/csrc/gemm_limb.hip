@@ -63,10 +63,9 @@ __device__ __forceinline__ int chunk_of(int r, int oct) {
 
 // The staging waves keep RING steps of operand tiles in registers: the loads of step s + RING - 1 are issued while step s
 // is being split into LDS, so a tile has RING - 2 whole K steps (plus the current one) to arrive from L2 / HBM.
-#define LIMB_RING 4
 
 // ---- K-contiguous source: element (row, k) at base[row * ld + k].  Unit = 8 consecutive k of one row. -------------
-template <int BT, int T>
+template <int BT, int T, int LIMB_RING>
 struct LimbLoaderK {
   static constexpr int UNITS = BT * 4, NU = (UNITS + T - 1) / T;
   float4 r[LIMB_RING][NU][2];
@@ -117,13 +116,16 @@ struct LimbLoaderK {
   }
 };
 
-// ---- K-strided source: element (k, col) at base[k * ld + col].  Unit = 4 k x 4 columns, transposed in registers.
-// Thread -> (kq = u & 7, cq = u >> 3): a wave's load covers 8 rows x 128 contiguous bytes. ----------------------------
-template <int BT, int T>
+// ---- K-strided source: element (k, col) at base[k * ld + col].  Unit = KPU k x 4 columns, transposed in registers
+// (KPU = 4, or 2 where 4 would leave half of the staging threads without a unit: the 64-wide operand).
+// Thread -> (kq = u % KQ, cq = u / KQ), KQ = 32 / KPU: a wave's load covers KQ rows x (64 / KQ) x 16 contiguous bytes. ----
+template <int BT, int T, int LIMB_RING>
 struct LimbLoaderN {
-  static constexpr int UNITS = 2 * BT, NU = (UNITS + T - 1) / T;
-  float4 r[LIMB_RING][NU][4];
-  unsigned ok[LIMB_RING];      // bit 4 i + j: row j of unit i of that slot is inside the matrix / the item's K range
+  static constexpr int KPU = (2 * BT >= T) ? 4 : 2;
+  static constexpr int KQ = LBK / KPU;
+  static constexpr int UNITS = (BT / 4) * KQ, NU = (UNITS + T - 1) / T;
+  float4 r[LIMB_RING][NU][KPU];
+  unsigned ok[LIMB_RING];      // bit KPU i + j: row j of unit i of that slot is inside the matrix / the item's K range
   int coff[NU];
   unsigned okcol;
   float cs[NU][4];             // running column sums of the item being stored (bias gradient of the dW products)
@@ -137,8 +139,8 @@ struct LimbLoaderN {
     okcol = 0u;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      const int u = threadIdx.x + T * i, cq = u >> 3, g = t0 + 4 * cq;
-      if (u < UNITS && g < extent) okcol |= 0xfu << (4 * i);   // extent % 4 == 0: a column quad is inside or outside as a whole
+      const int u = threadIdx.x + T * i, cq = u / KQ, g = t0 + 4 * cq;
+      if (u < UNITS && g < extent) okcol |= ((1u << KPU) - 1u) << (KPU * i);   // extent % 4 == 0: a column quad is inside or outside as a whole
       coff[i] = min(g, extent - 4);
     }
   }
@@ -147,12 +149,12 @@ struct LimbLoaderN {
     unsigned okk = 0u;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      const int kq = (threadIdx.x + T * i) & 7;
+      const int kq = (threadIdx.x + T * i) % KQ;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int gk = k0 + 4 * kq + j;
+      for (int j = 0; j < KPU; ++j) {
+        const int gk = k0 + KPU * kq + j;
         r[SLOT][i][j] = *reinterpret_cast<const float4*>(base + (size_t)min(gk, K - 1) * ld + coff[i]);
-        if (gk < kend) okk |= 1u << (4 * i + j);
+        if (gk < kend) okk |= 1u << (KPU * i + j);
       }
     }
     ok[SLOT] = okk & okcol;
@@ -161,38 +163,55 @@ struct LimbLoaderN {
   __device__ __forceinline__ void store(unsigned char* __restrict__ S) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      const int u = threadIdx.x + T * i, kq = u & 7, cq = u >> 3;
+      const int u = threadIdx.x + T * i, kq = u % KQ, cq = u / KQ;
       if (UNITS % T != 0 && u >= UNITS) continue;
-      float v[4][4];
+      float v[KPU][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool okj = (ok[SLOT] >> (4 * i + j)) & 1u;
+      for (int j = 0; j < KPU; ++j) {
+        const bool okj = (ok[SLOT] >> (KPU * i + j)) & 1u;
         v[j][0] = okj ? r[SLOT][i][j].x : 0.f; v[j][1] = okj ? r[SLOT][i][j].y : 0.f;
         v[j][2] = okj ? r[SLOT][i][j].z : 0.f; v[j][3] = okj ? r[SLOT][i][j].w : 0.f;
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if (COLSUM) cs[i][c] += (v[0][c] + v[1][c]) + (v[2][c] + v[3][c]);
-        u32x2 p0, p1, p2;
-        uint32_t x, y, z;
-        limb_split2(v[0][c], v[1][c], x, y, z); p0[0] = x; p1[0] = y; p2[0] = z;
-        limb_split2(v[2][c], v[3][c], x, y, z); p0[1] = x; p1[1] = y; p2[1] = z;
         const int row = 4 * cq + c;
-        unsigned char* d = S + ((row & ~15) + pos16<true>(row & 15)) * 64 + chunk_of<true>(row & 15, kq >> 1) * 16 + (kq & 1) * 8;
-        *reinterpret_cast<u32x2*>(d) = p0;
-        *reinterpret_cast<u32x2*>(d + BT * 64) = p1;
-        *reinterpret_cast<u32x2*>(d + 2 * BT * 64) = p2;
+        unsigned char* d = S + ((row & ~15) + pos16<true>(row & 15)) * 64;
+        uint32_t x, y, z;
+        if constexpr (KPU == 4) {
+          if (COLSUM) cs[i][c] += (v[0][c] + v[1][c]) + (v[2][c] + v[3][c]);
+          u32x2 p0, p1, p2;
+          limb_split2(v[0][c], v[1][c], x, y, z); p0[0] = x; p1[0] = y; p2[0] = z;
+          limb_split2(v[2][c], v[3][c], x, y, z); p0[1] = x; p1[1] = y; p2[1] = z;
+          d += chunk_of<true>(row & 15, kq >> 1) * 16 + (kq & 1) * 8;
+          *reinterpret_cast<u32x2*>(d) = p0;
+          *reinterpret_cast<u32x2*>(d + BT * 64) = p1;
+          *reinterpret_cast<u32x2*>(d + 2 * BT * 64) = p2;
+        } else {
+          if (COLSUM) cs[i][c] += v[0][c] + v[1][c];
+          limb_split2(v[0][c], v[1][c], x, y, z);
+          d += chunk_of<true>(row & 15, kq >> 2) * 16 + (kq & 3) * 4;
+          *reinterpret_cast<uint32_t*>(d) = x;
+          *reinterpret_cast<uint32_t*>(d + BT * 64) = y;
+          *reinterpret_cast<uint32_t*>(d + 2 * BT * 64) = z;
+        }
       }
     }
   }
 };
 
-template <int BT, int T, bool KMAJ>
+template <int BT, int T, int RING, bool KMAJ>
 struct LimbLoader;
-template <int BT, int T>
-struct LimbLoader<BT, T, true> : LimbLoaderK<BT, T> {};
-template <int BT, int T>
-struct LimbLoader<BT, T, false> : LimbLoaderN<BT, T> {};
+template <int BT, int T, int RING>
+struct LimbLoader<BT, T, RING, true> : LimbLoaderK<BT, T, RING> {};
+template <int BT, int T, int RING>
+struct LimbLoader<BT, T, RING, false> : LimbLoaderN<BT, T, RING> {};
+
+// f(integral_constant<int, J>) for J = 0 .. R-1, unrolled at compile time (static ring-slot indices)
+template <int J, int R, class F>
+__device__ __forceinline__ void limb_for_stage(F&& f) {
+  f(std::integral_constant<int, J>{});
+  if constexpr (J + 1 < R) limb_for_stage<J + 1, R>(f);
+}
 
 // One work item = (split, tile row, tile column).  A workgroup walks its items as ONE continuous sequence of K steps:
 // the staging waves run up to one step ahead across item boundaries, so the first loads of the next item are in flight
@@ -200,9 +219,12 @@ struct LimbLoader<BT, T, false> : LimbLoaderN<BT, T> {};
 // swapped, D' = B^T A^T, so a lane's four accumulator registers are four consecutive columns of one output row).
 struct LimbItem { int m0, n0, split, kbeg, kend, bx; };
 
-template <int BN, bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const int tiles_m, const int tiles_n,
-                                                        const int nitems) {
+// RING: operand tiles the staging waves keep in registers (loads RING - 1 steps ahead).  MINW: waves per SIMD the
+// register allocation must allow (4 = two 512-thread workgroups per CU: the staging waves of one workgroup then run
+// beside the matrix-core waves of the other, which matters because a staging wave alone is stalled half of the time).
+template <int BN, bool A_KMAJ, bool B_KMAJ, int RING, int MINW>
+__global__ __launch_bounds__(512, MINW) void gemm_limb_kernel(const GemmArgs g, const int tiles_m, const int tiles_n,
+                                                              const int nitems) {
   constexpr int BM = 128, T = 256, WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int A_BYTES = 3 * BM * 64, B_BYTES = 3 * BN * 64, BUF = A_BYTES + B_BYTES;
   __shared__ __align__(16) unsigned char smem[2 * BUF];
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
     if (((gsz | nitems) & 7) == 0) { const int chunk = nitems >> 3, x = w & 7; it = x * chunk + (w >> 3); it_end = (x + 1) * chunk; it_step = gsz >> 3; }
     else { it = w; it_end = nitems; it_step = gsz; }
   }
-  auto decode = [&](int item) {
+  auto decode = [&](int item) __attribute__((always_inline)) {
     LimbItem r;
     const int per = tiles_m * tiles_n;
     r.split = item / per;
@@ -234,8 +256,8 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
   if (stager) {
     // ------------------------------------------------ staging waves ------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
-    LimbLoader<BM, T, A_KMAJ> la;
-    LimbLoader<BN, T, B_KMAJ> lb;
+    LimbLoader<BM, T, RING, A_KMAJ> la;
+    LimbLoader<BN, T, RING, B_KMAJ> lb;
     // total K steps of this workgroup's item list: both roles pass exactly one barrier per step (plus the initial one)
     int S = 0;
     for (int i = it; i < it_end; i += it_step) { const LimbItem q = decode(i); S += (q.kend - q.kbeg + LBK - 1) / LBK; }
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
     int l_k = li.kbeg, s_k = si.kbeg;
     // The load-side state of the loaders (row offsets, bounds) is set right before the first load of an item; what a
     // later store needs (the in-range masks) is captured per ring slot at load time.
-    auto load_step = [&](auto slot) {
+    auto load_step = [&](auto slot) __attribute__((always_inline)) {
       constexpr int SLOT = decltype(slot)::value;
       if (l_k == li.kbeg) { la.init(li.m0, g.M, g.lda); lb.init(li.n0, g.N, g.ldb); }
       if (!AVA_DBG_BIT(g, 4)) {
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
         if (l_it < it_end) { li = decode(l_it); l_k = li.kbeg; }
       }
     };
-    auto store_step = [&](auto slot, int buf) {
+    auto store_step = [&](auto slot, int buf) __attribute__((always_inline)) {
       constexpr int SLOT = decltype(slot)::value;
       unsigned char* S_ = smem + buf * BUF;
       if (!AVA_DBG_BIT(g, 2)) {
@@ -271,7 +293,8 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
           if (g.colsum != nullptr && si.bx == 0) {
             const bool fin = g.splits == 1;
 #pragma unroll
-            for (int i = 0; i < LimbLoaderN<BM, T>::NU; ++i) {
+            for (int i = 0; i < LimbLoaderN<BM, T, RING>::NU; ++i) {
+              static_assert(LimbLoaderN<BM, T, RING>::KQ == 8, "the shuffle tree below sums the 8 k-quads of a column quad");
               const int u = t + T * i, cq = u >> 3;
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
@@ -280,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
                 v += __shfl_xor(v, 2, 64);
                 v += __shfl_xor(v, 4, 64);
                 const int gm = si.m0 + 4 * cq + c;
-                if ((u & 7) == 0 && u < LimbLoaderN<BM, T>::UNITS && gm < g.M) {
+                if ((u & 7) == 0 && u < LimbLoaderN<BM, T, RING>::UNITS && gm < g.M) {
                   if (fin) g.colsum[gm] = v;
                   else g.C[(size_t)g.splits * g.M * g.N + (size_t)si.split * g.M + gm] = v;   // partial, behind the slabs
                 }
@@ -288,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
             }
           }
 #pragma unroll
-          for (int i = 0; i < LimbLoaderN<BM, T>::NU; ++i)
+          for (int i = 0; i < LimbLoaderN<BM, T, RING>::NU; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) la.cs[i][c] = 0.f;
         }
@@ -297,44 +320,31 @@ __global__ __launch_bounds__(512) void gemm_limb_kernel(const GemmArgs g, const 
       }
     };
     // step j lives in ring slot j % RING.  Prologue: steps 0 .. RING-2 requested, step 0 split into buffer 0.
-    static_assert(LIMB_RING == 4, "the unrolled schedule below is written for a ring of four");
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    load_step(I0{});
-    if (S > 1) load_step(I1{});
-    if (S > 2) load_step(I2{});
-    store_step(I0{}, 0);
+    limb_for_stage<0, RING - 1>([&](auto J) __attribute__((always_inline)) { if (decltype(J)::value < S) load_step(J); });
+    store_step(std::integral_constant<int, 0>{}, 0);
     __syncthreads();                      // (A) step 0 ready
-    // stage s (the matrix-core waves multiply step s): request step s + 3 into the slot step s has left, split
-    // step s + 1 into the other LDS buffer
+    // stage s (the matrix-core waves multiply step s): request step s + RING - 1 into the slot step s has left, split
+    // step s + 1 into the other LDS buffer.
     // Steady state WITHOUT conditionals around the loads: hipcc's waitcnt pass merges the two sides of an `if (more) load`
     // conservatively (it must assume the loads were not issued), which turns the store's wait into vmcnt(0) -- i.e. into
     // a wait for the loads issued a moment ago, and the ring into a one-deep pipeline.
     int s0 = 0;
-#define LIMB_STAGE_FULL(SL_LOAD, SL_STORE, J)                             \
-      load_step(SL_LOAD{});                                               \
-      store_step(SL_STORE{}, (s0 + J + 1) & 1);                           \
-      __syncthreads();                    /* (B) step consumed, next ready */
-    for (; s0 + 6 < S; s0 += 4) {
-      LIMB_STAGE_FULL(I3, I1, 0)
-      LIMB_STAGE_FULL(I0, I2, 1)
-      LIMB_STAGE_FULL(I1, I3, 2)
-      LIMB_STAGE_FULL(I2, I0, 3)
-    }
-#undef LIMB_STAGE_FULL
-    for (; s0 < S; s0 += 4) {             // the last (up to 6) steps
-#define LIMB_STAGE(J, SL_LOAD, SL_STORE)                                  \
-      if (s0 + J < S) {                                                   \
-        if (s0 + J + 3 < S) load_step(SL_LOAD{});                         \
-        if (s0 + J + 1 < S) store_step(SL_STORE{}, (s0 + J + 1) & 1);     \
-        __syncthreads();                  /* (B) */                        \
-      }
-      LIMB_STAGE(0, I3, I1)
-      LIMB_STAGE(1, I0, I2)
-      LIMB_STAGE(2, I1, I3)
-      LIMB_STAGE(3, I2, I0)
-#undef LIMB_STAGE
-    }
+    for (; s0 + 2 * RING - 2 < S; s0 += RING)
+      limb_for_stage<0, RING>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        load_step(std::integral_constant<int, (j + RING - 1) % RING>{});
+        store_step(std::integral_constant<int, (j + 1) % RING>{}, (s0 + j + 1) & 1);
+        __syncthreads();                  // (B) step consumed, next ready
+      });
+    for (; s0 < S; s0 += RING)            // the last (up to 2 RING - 2) steps
+      limb_for_stage<0, RING>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        if (s0 + j < S) {
+          if (s0 + j + RING - 1 < S) load_step(std::integral_constant<int, (j + RING - 1) % RING>{});
+          if (s0 + j + 1 < S) store_step(std::integral_constant<int, (j + 1) % RING>{}, (s0 + j + 1) & 1);
+          __syncthreads();                // (B)
+        }
+      });
     return;
   }
 
@@ -438,17 +448,19 @@ bool ava_gemm_limb_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
   return true;
 }
 
-void ava_gemm_limb_plan(int M, int N, int K, int* bn, int* splits, int* klen) {
-  // wide outputs against a short K (fc8 forward, fc1 dX: batch x 8192, K = 1024): 128 x 64 tiles fill the chip
-  // without split-K (no slabs, no reduce launch)
-  int b = 128;
-  if (ceil_div(M, 128) * ceil_div(N, 128) < 256 && ceil_div(M, 128) * ceil_div(N, 64) >= 192 && K <= 2048) b = 64;
-  { const char* e = ava_env("AVA_GEMM_LIMB_BN"); if (e) b = atoi(e) == 64 ? 64 : 128; }
+void ava_gemm_limb_plan(int M, int N, int K, int a_kmajor, int* bn, int* splits, int* klen) {
+  // Forward / dX products (A = the batch-sized activation, K contiguous): 128 x 64 tiles (74 KB of LDS, <= 128 VGPRs), two
+  // 512-thread workgroups per CU, so 512 work items fill the chip once.  dW products (both operands K-strided: their
+  // in-register transposition needs more registers than that occupancy leaves): 128 x 128 tiles, one workgroup per CU.
+  // K is split until the chip is full (fp32 slabs + fixed-order reduce kernel), at least two K steps per item.
+  int b = a_kmajor ? 64 : 128;
+  { const char* e = ava_env("AVA_GEMM_LIMB_BN"); if (e && a_kmajor) b = atoi(e) == 128 ? 128 : 64; }
   const int tiles = ceil_div(M, 128) * ceil_div(N, b);
+  const int want = b == 64 ? 512 : 256;
   int s = 1;
-  if (tiles < 192) {
-    s = ceil_div(256, tiles);
-    const int max_s = K / 64 > 0 ? K / 64 : 1;        // at least 2 K steps per split
+  if (tiles < want * 3 / 4) {
+    s = ceil_div(want, tiles);
+    const int max_s = K / 64 > 0 ? K / 64 : 1;
     if (s > max_s) s = max_s;
   }
   { const char* e = ava_env("AVA_GEMM_LIMB_SPLITS"); if (e) { s = atoi(e); if (s < 1) s = 1; if (s > ceil_div(K, LBK)) s = ceil_div(K, LBK); } }
@@ -457,12 +469,12 @@ void ava_gemm_limb_plan(int M, int N, int K, int* bn, int* splits, int* klen) {
   *bn = b; *splits = s; *klen = kl;
 }
 
-template <int BN>
+template <int BN, int RING, int MINW>
 static void launch_limb(const GemmArgs& g, int a_k, int b_k, int tm, int tn, int nitems, int grid, hipStream_t st) {
-  if (a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, true>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
-  else if (a_k && !b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, false>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
-  else if (!a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, false, true>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
-  else hipLaunchKernelGGL((gemm_limb_kernel<BN, false, false>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  if (a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, true, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  else if (a_k && !b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, false, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  else if (!a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, false, true, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  else hipLaunchKernelGGL((gemm_limb_kernel<BN, false, false, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
 }
 
 int ava_gemm_limb_launch(const GemmArgs& g0, int a_kmajor, int b_kmajor, int bn, hipStream_t st) {
@@ -476,10 +488,20 @@ int ava_gemm_limb_launch(const GemmArgs& g0, int a_kmajor, int b_kmajor, int bn,
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
               ? prop.multiProcessorCount : 256;
   }
-  int grid = nitems < cus ? nitems : cus;          // one 512-thread workgroup per CU (96 KB of LDS), persistent over its items
+  const int resident = (bn == 64 ? 2 : 1) * cus;     // persistent workgroups: one resident wave of them
+  int grid = nitems < resident ? nitems : resident;
   { const char* e = ava_env("AVA_GEMM_LIMB_GRID"); if (e) { grid = atoi(e); if (grid > nitems) grid = nitems; if (grid < 1) grid = 1; } }
-  if (bn == 64) launch_limb<64>(g, a_kmajor, b_kmajor, tm, tn, nitems, grid, st);
-  else launch_limb<128>(g, a_kmajor, b_kmajor, tm, tn, nitems, grid, st);
+  if (bn == 64 && a_kmajor) {
+    if (b_kmajor) hipLaunchKernelGGL((gemm_limb_kernel<64, true, true, 3, 4>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+    else hipLaunchKernelGGL((gemm_limb_kernel<64, true, false, 3, 4>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  } else if (bn == 128 && !a_kmajor) {
+    if (b_kmajor) hipLaunchKernelGGL((gemm_limb_kernel<128, false, true, 4, 2>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+    else hipLaunchKernelGGL((gemm_limb_kernel<128, false, false, 4, 2>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  }
+#ifdef AVA_LAB
+  else if (bn == 128) launch_limb<128, 4, 2>(g, a_kmajor, b_kmajor, tm, tn, nitems, grid, st);
+#endif
+  else return AVA_EINVAL;
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

@@ -686,6 +686,38 @@ static bool conv7_writes_nchw() {
   return on;
 }
 
+// y1 recomputed instead of stored (conv_recomp.h).  Measured (profiles/r03): correct (bit-identical y1, all step tests
+// green) but SLOWER in this VALU form -- conv2's forward 44 -> 67 us (the staging waves' 9-tap recomputation costs ~40 us of
+// vector issue chip-wide) and the store-free conv1 pass takes the 36 us of the storing one (that kernel is bound by its
+// LDS-staged compute chain, not by its 128 MiB of stores).  Lab switch only (AVA_RECOMP_Y1=1); the product stores y1.
+static bool recomp_y1() {
+  static const bool on = [] { const char* e = ava_env("AVA_RECOMP_Y1"); return e != nullptr && atoi(e) != 0; }();
+  return on;
+}
+static RecompArgs recomp_args(ava_model* m) {
+  RecompArgs rc;
+  rc.G1 = m->Gf[0]; rc.bias1 = PP(m, kLayers[0].pb); rc.pa1 = bn_scale(m, 0); rc.pb1 = bn_shift(m, 0);
+  return rc;
+}
+// Writes y1 into its workspace slot with the kernel (and therefore the arithmetic) whose store-free form took its
+// statistics: for debugging / the tests' mask read-back, and for backward kernels that still read the tensor.
+static int materialize_y1(ava_model* m, const float* x, int B, hipStream_t st) {
+  const ConvLayer& L = kLayers[0];
+  const LayerDims& D = m->lay[0];
+  ConvAcc acc;
+  acc.fin = fin_none(); acc.acc_out = nullptr;
+  TRY(ava_conv3x3_ex(x, nullptr, bn_scale(m, 0), bn_shift(m, 0), nullptr, m->Gf[0], PP(m, L.pb), m->X[1], nullptr, nullptr,
+                     nullptr, nullptr, m->bn_part, B, D.hi, D.wi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1, 0.f, m->act_bf16,
+                     &acc, reinterpret_cast<ava_stream_t>(st)));
+  mark(m, CAT_CONV_FWD, st);
+  return AVA_OK;
+}
+extern "C" int ava_debug_materialize(ava_model* m, const float* x, int B, ava_stream_t s) {
+  if (m == nullptr || x == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
+  if (!recomp_y1()) return AVA_OK;
+  return materialize_y1(m, x, B, to_stream(s));
+}
+
 static int encoder_forward(ava_model* m, const float* x, int B, int train, float* mu, float* u, float* logd_or_d,
                            int last_act, hipStream_t st, int pre_nparts = 0) {
   const int z = m->z;
@@ -699,17 +731,22 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
   } else {
     TRY(bn_eval_all(m, st));       // all 14 layers from the running statistics (also serves the decoder)
   }
+  const bool rc1 = recomp_y1();
   for (int l = 0; l < 7; ++l) {
     const ConvLayer& L = kLayers[l];
     const LayerDims& D = m->lay[l];
-    const float* in = l == 0 ? x : m->X[l];
-    float* out = l == 6 ? m->y7 : m->X[l + 1];
+    // y1 = relu(conv1(bn1 x)) is never stored (conv_recomp.h): conv1's launch only takes bn2's batch statistics
+    // (training; nothing at all on running statistics) and conv2's kernel recomputes its y1 window from x
+    if (rc1 && l == 0 && !train) continue;
+    const float* in = (l == 0 || (rc1 && l == 1)) ? x : m->X[l];
+    float* out = l == 6 ? m->y7 : ((rc1 && l == 0) ? nullptr : m->X[l + 1]);
     // conv7's matrix-core kernel also writes the NCHW-flatten copy fc1 reads (saves the transpose launch)
     float* nchw = (l == 6 && conv7_writes_nchw()) ? m->y7t : nullptr;
     ConvAcc acc;
     acc.fin = (train && acc_pair_fwd(m, l)) ? fin_fwd(m, l, B) : fin_none();                 // BatchNorm l: finalised in this kernel
     if (train && l == 0 && m->acc0_used >= 0) { acc.fin = fin_fwd(m, 0, B); acc.fin.acc = acc_slot(m, m->acc0_used); }
     acc.acc_out = (train && l < 6 && acc_pair_fwd(m, l + 1)) ? acc_slot(m, l + 1) : nullptr;    // BatchNorm l+1: summed by this kernel
+    if (rc1 && l == 1) acc.rc = recomp_args(m);
     TRY(ava_conv3x3_ex(in, nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out, nchw,
                        nullptr, nullptr, nullptr, m->bn_part, B, D.hi, D.wi, L.cin, L.cout, L.mode, PRO_BN, EPI_FWD, 1,
                        0.f, m->act_bf16, &acc, reinterpret_cast<ava_stream_t>(st)));
@@ -1009,6 +1046,7 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, b
   float* gcur = m->gA;
   float* gnext = m->gB;
   mark(m, -1, st);
+  if (recomp_y1()) TRY(materialize_y1(m, x, B, st));       // TEMPORARY: until conv2's / conv1's backward recompute y1 themselves
   TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, m->P8, st));             // dU_7 (ReLU of conv7)
   mark(m, CAT_LAYOUT, st);
   TRY(conv_layer_backward(m, 6, x, gcur, nullptr, nullptr, nullptr, nullptr, PRO_ID, gnext, B, st));

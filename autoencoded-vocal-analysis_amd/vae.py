@@ -433,7 +433,14 @@ class VAE(nn.Module):
     # intermediates that are ACTIVATIONS between the convolutions: bfloat16 when act_dtype says so
     _ACT_BUFFERS = frozenset(["y%d" % i for i in range(1, 7)] + ["d%d" % i for i in range(1, 7)] + ["f8t"])
 
+    # intermediates the step never stores (their consumers recompute them): written on demand by ava_debug_materialize
+    _RECOMPUTED = frozenset(["y1"])
+
     def _workspace_tensor(self, name, shape):
+        if name in self._RECOMPUTED:
+            x = self._last_x
+            _lib.check(_lib.load().ava_debug_materialize(self._handle, x.data_ptr(), x.shape[0], _lib.stream()),
+                       "ava_debug_materialize")
         n = ctypes.c_int64()
         p = _lib.load().ava_debug_buffer(self._handle, name.encode(), ctypes.byref(n))
         if not p:

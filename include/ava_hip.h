@@ -124,6 +124,10 @@ const float* ava_last_z(ava_model* m);
 const float* ava_last_xrec(ava_model* m);
 /* name -> workspace buffer of an intermediate (tests): "y1".."y7","d1".."d6","f8","mu","u","logd",... */
 const float* ava_debug_buffer(ava_model* m, const char* name, int64_t* floats);
+/* Intermediates the step does not keep in memory because their consumers recompute them (y1 = relu(conv1(bn1 x)),
+ * vae.py:217) are written into their ava_debug_buffer slots ("y1") by the kernel whose store-free form took their
+ * statistics: same arithmetic, bit for bit.  Call after the ava_forward whose intermediates are wanted, with its x. */
+int ava_debug_materialize(ava_model* m, const float* x, int B, ava_stream_t s);
 
 /* Optional timing of the driver's launches with HIP events recorded on the launch stream
  * (bench.py's roofline leg).  Categories, in order: conv forward, conv backward-data, conv weight-grad

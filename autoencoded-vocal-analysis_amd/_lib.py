@@ -68,6 +68,9 @@ SIGNATURES = {
     "ava_last_xrec": (_p, [_p]),
     "ava_debug_buffer": (_p, [_p, C.c_char_p, C.POINTER(_i64)]),
     "ava_debug_materialize": (_i, [_p, _p, _i, _p]),
+    "ava_set_cu_reserve": (_i, [_i]),
+    "ava_get_cu_reserve": (_i, []),
+    "ava_occupy_cus": (_i, [_i, _i, _f, _p]),
     "ava_profile_enable": (_i, [_p, _i]),
     "ava_profile_read": (_i, [_p, C.POINTER(_f), C.POINTER(_i)]),
     "ava_fill_normal": (_i, [_p, _i64, C.c_uint64, C.c_uint64, _p]),

@@ -39,6 +39,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// CUs every persistent ("one resident wave of workgroups") launch leaves free: ava_set_cu_reserve (model.hip).  Under data
+// parallelism RCCL's persistent workgroups hold wave slots for the length of an all-reduce; a conv grid sized for the
+// whole chip would then find fewer free slots than workgroups, and the surplus ones -- each owning a STATIC share of the
+// tiles -- would run as a second wave (up to 2x the kernel's time).  A grid sized for (CUs - reserve) fits beside them.
+// The tile partition is a function of the grid size only, so results are bit-reproducible for a given setting.
+int ava_cu_reserve(void);
+static inline int ava_scale_grid(int grid_for_all_cus) {
+  const int r = ava_cu_reserve();
+  if (r <= 0) return grid_for_all_cus;
+  const long g = (long)grid_for_all_cus * (256 - r) / 256;
+  return g < 1 ? 1 : (int)g;
+}
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Counter-based standard normal: splitmix64 finaliser + Box-Muller; matches ava_amd.synthetic.u01 / gauss (SURVEY

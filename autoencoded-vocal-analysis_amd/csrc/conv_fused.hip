@@ -752,7 +752,7 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
   const int nt = B * (hl / th) * (wl / tw);
   bool ws; int cap;
   fused_defaults(Cin, Cout, mode, &ws, &cap);   // 512 = two resident 256-thread workgroups per CU (384 / 768 / 1024 are slower)
-  return nt < cap ? nt : cap;
+  return nt < ava_scale_grid(cap) ? nt : ava_scale_grid(cap);
 }
 
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {

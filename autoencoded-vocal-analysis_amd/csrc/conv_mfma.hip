@@ -275,7 +275,7 @@ static int launch_mfma_t(const ConvArgs& a, int grid, hipStream_t st) {
   static const int resident = ava_resident_grid(&conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>, lds);
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
-  if (grid > resident) grid = resident;
+  if (grid > ava_scale_grid(resident)) grid = ava_scale_grid(resident);
   { const char* e = ava_env("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
   hipLaunchKernelGGL((conv3x3_mfma_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT>), dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
@@ -639,7 +639,7 @@ static int launch_wgrad_mfma_t(const WgradArgs& a, int grid, hipStream_t st) {
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid > b.ntiles) grid = b.ntiles;
   static const int resident = ava_resident_grid(kernel, lds);
-  if (grid > resident) grid = resident;          // one resident wave of workgroups = partial rows written
+  if (grid > ava_scale_grid(resident)) grid = ava_scale_grid(resident);          // one resident wave of workgroups = partial rows written
   { const char* e = ava_env("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (a.partials == nullptr) return grid;        // row-count query (ava_conv_wgrad_rows)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, b);

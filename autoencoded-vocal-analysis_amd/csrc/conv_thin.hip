@@ -1249,7 +1249,7 @@ int ava_conv3x3_up88_direct(const ConvArgs& a0, int grid, int Cin, int Cout, int
   a.ntiles = a.B * (a.Ho / 8);
   a.part_rows = grid;
   static const int resident = ava_resident_grid(&up88_direct_kernel<float>, 0);
-  int g = grid < resident ? grid : resident;
+  int g = grid < ava_scale_grid(resident) ? grid : ava_scale_grid(resident);
   { const char* e = ava_env("AVA_UP88_GRID"); if (e && atoi(e) >= 8 && atoi(e) < g) g = atoi(e); }
   if (g > a.ntiles) g = a.ntiles;
   if (a.act_bf16) hipLaunchKernelGGL(up88_direct_kernel<ava_bf16>, dim3(g), dim3(256), 0, st, a);
@@ -1284,7 +1284,7 @@ static int thin_fused_grid_w(int nt, int Cin) {
       if (W == 128) return 768;
       return thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD>, W, 0);
     }();
-    return nt < cap1 ? nt : cap1;
+    return nt < ava_scale_grid(cap1) ? nt : ava_scale_grid(cap1);
   }
   static const int cap8 = [] {
     const char* e = ava_env("AVA_THIN_GRID8");
@@ -1296,7 +1296,7 @@ static int thin_fused_grid_w(int nt, int Cin) {
     // direct form: one resident wave (3 per CU at 138 VGPRs; in-step A/B 512 / 768 / 1024 -> 48.0 / 42.4 / 55.7 us)
     return thin_resident(&thin_wgrad_stats_8to1_direct_kernel<W, PRO_ID>, W, 0);
   }();
-  return nt < cap8 ? nt : cap8;
+  return nt < ava_scale_grid(cap8) ? nt : ava_scale_grid(cap8);
 }
 
 int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode) {
@@ -1335,7 +1335,7 @@ static int thin_bwd_fused_launch_w(const FusedArgs& a0, int grid, int Cin, int d
     if (e && atoi(e) >= 8) return atoi(e);
     return thin_resident(&thin_1to8_kernel<W, PRO_ID, EPI_NONE>, W, 0);
   }();
-  const int dgrid = a.ntiles < dcap ? a.ntiles : dcap;
+  const int dgrid = a.ntiles < ava_scale_grid(dcap) ? a.ntiles : ava_scale_grid(dcap);
   if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BWD, EPI_NONE>), dim3(dgrid), block, 0, st, c);
   else hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_ID, EPI_NONE>), dim3(dgrid), block, 0, st, c);
   AVA_CHECK_LAUNCH();
@@ -1393,12 +1393,13 @@ static int conv3x3_thin_w(const ConvArgs& a0, int grid, int Cin, int Cout, int p
   ConvArgs a = a0;
   a.ntiles = a.B * (a.Ho / THIN_TH);                     // workgroups beyond ntiles still write their (zero) partial row
   a.part_rows = grid;                                    // rows the caller sized; one resident wave is launched
-  if (Cin == 8 && grid > 512) grid = 512;                // 8 -> 1: two workgroups per CU are resident (measured -3.5 us)
+  if (Cin == 8 && grid > ava_scale_grid(512)) grid = ava_scale_grid(512);                // 8 -> 1: two workgroups per CU are resident (measured -3.5 us)
   { const char* e = ava_env("AVA_THIN_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (Cin == 1 && Cout == 8) {
+    if (grid > ava_scale_grid(1024)) grid = ava_scale_grid(1024);      // W = 128: four 256-thread workgroups per CU
     if (W == 256) {                                      // 512-thread workgroups: at most one resident wave
       static const int res = thin_resident(&thin_1to8_kernel<W, PRO_BN, EPI_FWD>, W, 0);
-      if (grid > res) grid = res;
+      if (grid > ava_scale_grid(res)) grid = ava_scale_grid(res);
     }
     if (a.act_bf16 && !(pro == PRO_BN && epi == EPI_FWD)) return AVA_EINVAL;   // bf16 activations: only the model's launches
     if (pro == PRO_BN && epi == EPI_FWD && a.act_bf16) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BN, EPI_FWD, ava_bf16>), dim3(grid), block, 0, st, a);
@@ -1437,7 +1438,8 @@ static int conv3x3_thin_w(const ConvArgs& a0, int grid, int Cin, int Cout, int p
     if (pro == PRO_BN && epi == EPI_SSE) {
       static const int resident = thin_resident(&thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE>, W, 0);
       int g = a.part_rows < resident ? a.part_rows : resident;   // at most one resident wave; rows beyond the grid are zero-filled
-      if (g > 512) g = 512;                               // in-step A/B: 512 / 768 / 1023 workgroups -> 34.1 / 34.7 / 37.0 us
+      if (g > ava_scale_grid(resident)) g = ava_scale_grid(resident);
+      if (g > ava_scale_grid(512)) g = ava_scale_grid(512);                               // in-step A/B: 512 / 768 / 1023 workgroups -> 34.1 / 34.7 / 37.0 us
       { const char* e = ava_env("AVA_THIN_FWD_GRID"); if (e && atoi(e) >= 8 && atoi(e) < a.part_rows) g = atoi(e); }
       if (g > a.ntiles) g = a.ntiles;
       if (a.act_bf16) hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE, ava_bf16>), dim3(g), block, 0, st, a);

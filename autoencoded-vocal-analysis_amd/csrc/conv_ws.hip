@@ -297,7 +297,7 @@ int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   }
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
-  if (grid > resident) grid = resident;
+  if (grid > ava_scale_grid(resident)) grid = ava_scale_grid(resident);
   { const char* e = ava_env("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
   hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();

@@ -488,7 +488,7 @@ int ava_gemm_limb_launch(const GemmArgs& g0, int a_kmajor, int b_kmajor, int bn,
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
               ? prop.multiProcessorCount : 256;
   }
-  const int resident = (bn == 64 ? 2 : 1) * cus;     // persistent workgroups: one resident wave of them
+  const int resident = ava_scale_grid((bn == 64 ? 2 : 1) * cus);     // persistent workgroups: one resident wave of them
   int grid = nitems < resident ? nitems : resident;
   { const char* e = ava_env("AVA_GEMM_LIMB_GRID"); if (e) { grid = atoi(e); if (grid > nitems) grid = nitems; if (grid < 1) grid = 1; } }
   if (bn == 64 && a_kmajor) {

@@ -250,6 +250,42 @@ static void carve(ava_model* m, void* ws, size_t* total) {
 
 extern "C" int ava_version(void) { return 100; }
 
+// CUs left free by every persistent launch (common.h: ava_scale_grid).  Process-wide: the grids are sized deep inside the
+// launchers; set it before the first step of a run and leave it (the data-parallel binding does, dist.py).
+static int g_cu_reserve = 0;
+int ava_cu_reserve(void) { return g_cu_reserve; }
+extern "C" int ava_set_cu_reserve(int cus) {
+  if (cus < 0 || cus > 128) return AVA_EINVAL;
+  g_cu_reserve = cus;
+  return AVA_OK;
+}
+extern "C" int ava_get_cu_reserve(void) { return g_cu_reserve; }
+
+// Test / measurement helper: `workgroups` persistent 256-thread workgroups that hold their wave slots for `usec`
+// microseconds (s_memrealtime, 100 MHz) and do nothing else -- stands in for a collective's persistent kernel on a side
+// stream (tests/test_gpu_reserve.py, tools/reserve_bench.py).
+__global__ __launch_bounds__(256) void occupy_kernel(long long ticks, unsigned long long* sink) {
+  extern __shared__ unsigned char occupy_lds[];          // dynamic LDS only limits how many of these share a CU
+  if (ticks < 0) occupy_lds[threadIdx.x] = 0;
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  long long n = 0;
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); ++n; }
+  if (sink != nullptr && threadIdx.x == 0 && blockIdx.x == 0) *sink = (unsigned long long)n;
+}
+extern "C" int ava_occupy_cus(int workgroups, int lds_bytes, float usec, ava_stream_t s) {
+  if (workgroups < 1 || workgroups > 1024 || !(usec > 0.f) || usec > 20000.f || lds_bytes < 0 || lds_bytes > 160 * 1024)
+    return AVA_EINVAL;                                   // bounded: never a hang
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) return AVA_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, to_stream(s), (long long)(usec * 100.f), nullptr);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
 // spectrogram sizes the kernels cover: W = 128 or 256 (the full-resolution 1- and 8-channel layers run 2*W-thread
 // workgroups that own whole rows), H a multiple of 128 (16-row tiles of the layers at H/8 x W/8)
 static bool size_ok(int H, int W) { return (W == 128 || W == 256) && H >= 128 && H <= 1024 && H % 128 == 0; }

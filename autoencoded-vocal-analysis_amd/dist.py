@@ -28,6 +28,31 @@ def world_size():
     return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
 
 
+_reserve_applied = None
+
+
+def cu_reserve():
+    """CUs every persistent conv / GEMM grid leaves free while torch.distributed is active, so that the collective's own
+    persistent workgroups (RCCL: one per channel, resident for the length of an all-reduce) find wave slots instead of
+    pushing part of a statically partitioned conv grid into a second wave (``include/ava_hip.h: ava_set_cu_reserve``).
+    ``AVA_CU_RESERVE`` overrides the default of 32 (an eighth of the chip); 0 switches the reservation off."""
+    import os
+    try:
+        return max(0, min(128, int(os.environ.get("AVA_CU_RESERVE", "32"))))
+    except ValueError:
+        return 32
+
+
+def apply_cu_reserve(lib):
+    """Idempotent: size the library's persistent grids for data parallelism (no-op in a single-process run)."""
+    global _reserve_applied
+    want = cu_reserve() if active() else 0
+    if _reserve_applied != want and (active() or _reserve_applied is not None):
+        lib.ava_set_cu_reserve(want)
+        _reserve_applied = want
+    return want
+
+
 def allreduce_gradients(flat_grads):
     """In-place SUM over ranks of the flat gradient arena (backend 'nccl' is RCCL on ROCm)."""
     if active():

@@ -319,6 +319,7 @@ class VAE(nn.Module):
         B = x.shape[0]
         self._ensure(B)
         self._generation += 1
+        _dist.apply_cu_reserve(_lib.load())        # data parallel: leave wave slots for the collective's workgroups
         if self.noise_source is None:
             # device counter RNG: the noise is drawn inside the forward's first launch (same stream as ava_fill_normal)
             n = B * (self.z_dim + 1)

@@ -110,6 +110,15 @@ int ava_set_backward_scale(ava_model* m, const float* loss_scale);
 int ava_backward_num_parts(void);
 int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s);
 int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count);
+/* Data parallelism (the reference is single-device: vae.py:112-115).  Every convolution / large-GEMM launch is ONE
+ * resident wave of persistent workgroups over a static tile partition; a collective's own persistent workgroups (RCCL)
+ * need wave slots beside them.  ava_set_cu_reserve(r) sizes all those grids for (256 - r) CUs from now on (process-wide,
+ * 0 <= r <= 128; default 0).  Results are bit-reproducible for a given r.  ava_occupy_cus(w, lds, usec, stream) launches w
+ * 256-thread workgroups with `lds` bytes of LDS each (which bounds how many share a CU) that only hold their slots for
+ * usec microseconds (<= 20 ms): a stand-in for such a collective in tests. */
+int ava_set_cu_reserve(int cus);
+int ava_get_cu_reserve(void);
+int ava_occupy_cus(int workgroups, int lds_bytes, float usec, ava_stream_t s);
 /* torch.optim.Adam.step (torch/optim/adam.py:414-547), one fused pass over the four arenas.
  * `step` is the 1-based count after increment.  When the last ava_forward raised its status word (some d not > 0: the
  * reference raises ValueError inside forward and never reaches optimizer.step(), vae.py:312,353) the kernel leaves

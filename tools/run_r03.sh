@@ -31,6 +31,11 @@ case $pass in
     find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
     rm -rf $out/prof
     ;;
+  reserve)
+    timeout 600 python -m pytest tests/test_gpu_reserve.py -x -q > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
+    timeout 600 python tools/reserve_bench.py > $out/reserve_bench.log 2>&1
+    tail -n 5 $out/pytest.log; cat $out/reserve_bench.log
+    ;;
   gemmabl)
     timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k gemm > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
     for d in 0 1 2 4 8 3 6 7 15; do

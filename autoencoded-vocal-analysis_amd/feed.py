@@ -255,22 +255,34 @@ class PinnedBatchLoader:
         stop = threading.Event()
         end = object()
 
+        def put(item):
+            """stop-aware put (batches, the end marker and exceptions alike): never blocks past a consumer that left"""
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def produce():
             try:
                 for b in self._batches():
-                    while not stop.is_set():
-                        try:
-                            q.put(b, timeout=0.05)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
+                    if not put(b):
                         return
-                q.put(end)
+                put(end)
             except BaseException as e:                       # surface loader errors in the consumer
-                q.put(e)
+                put(e)
 
+        # one producer per loader at a time: a previous iteration's thread (consumer left early, e.g. on an exception in the
+        # step) may still be inside _fill(); it shares the ring slots, so it must have finished before a new one starts
+        prev = getattr(self, "_producer", None)
+        if prev is not None and prev.is_alive():
+            prev.join(timeout=30)
+            if prev.is_alive():
+                raise RuntimeError("PinnedBatchLoader: the producer thread of the previous iteration is still running")
         th = threading.Thread(target=produce, daemon=True)
+        self._producer = th
         th.start()
         try:
             while True:

@@ -30,10 +30,10 @@ def bottleneck_features(x_shape=X_SHAPE):
 
 
 def check_x_shape(x_shape):
-    """Spectrogram sizes the kernels cover (csrc/model.hip: size_ok): W in {128, 256}, H a multiple of 128."""
+    """Spectrogram sizes the kernels are validated for (csrc/model.hip: size_ok): H and W each 128 or 256."""
     h, w = int(x_shape[0]), int(x_shape[1])
-    if w not in (128, 256) or h % 128 != 0 or not 128 <= h <= 1024:
-        raise ValueError("unsupported spectrogram size %dx%d: width must be 128 or 256, height a multiple of 128" % (h, w))
+    if w not in (128, 256) or h not in (128, 256):
+        raise ValueError("unsupported spectrogram size %dx%d: height and width must each be 128 or 256" % (h, w))
     return (h, w)
 
 

@@ -60,9 +60,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two HIP-event passes")
     ap.add_argument("--no-loader-path", action="store_true", help="skip the PCIe-inclusive loader-path leg (N = 1 only)")
-    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
-                    help="bounded: 1 warm-up + 4 timed steps (best thread count) and 1 + 2 (all cores), ~40 s; "
-                         "full: BASELINE.md section 3's 3 warm-up + 10 timed steps for both")
+    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="full",
+                    help="full (default): BASELINE.md section 3's 3 warm-up + 10 timed steps at the best thread count and on "
+                         "all physical cores, for configs[1], plus configs[0] and configs[2] at the best thread count (~3 min); "
+                         "bounded: 1 warm-up + 4 timed steps (best thread count) and 1 + 2 (all cores), configs[1] only, ~40 s")
     ap.add_argument("--lr", type=float, default=1e-3, help=argparse.SUPPRESS)   # what-if probes of the lab build use 0
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)    # 'gloo': ranks share cuda:0 (tests on a 1-GPU box)
     ap.add_argument("--master-port", type=int, default=0, help=argparse.SUPPRESS)
@@ -93,6 +94,18 @@ def launch_ranks(args):
     if line is not None:
         print(line)
     raise SystemExit(res.returncode if res.returncode else (0 if line is not None else 1))
+
+
+def csrc_sha16():
+    """Hash of the kernel sources of the running tree (what a PMC summary must have been measured on to be quoted)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "autoencoded-vocal-analysis_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def one_step(model, x):
@@ -139,7 +152,10 @@ def loader_path(model, B, z_dim, shape):
     out["reference_handover_sync_to_device"] = run(Ref(), False)
     out["pinned_ring_float32"] = run(PinnedBatchLoader(base, batch_size=B, shuffle=True), True)
     out["pinned_ring_float64_device_cast"] = run(PinnedBatchLoader(base.astype(np.float64), batch_size=B, shuffle=True), True)
-    out["pinned_ring_uint8_device_cast"] = run(PinnedBatchLoader((base * 255).astype(np.uint8), batch_size=B, shuffle=True), True)
+    # uint8 items are 0 or 1 here (numpy_to_tensor casts, it does not rescale: 0..255-valued data would drive the loss to 1e9
+    # and time Adam on a model being wrecked); the bytes over PCIe and the device-side cast are the same
+    out["pinned_ring_uint8_device_cast"] = run(PinnedBatchLoader((base > 0.5).astype(np.uint8), batch_size=B, shuffle=True), True)
+    out["uint8_fixture"] = "binary {0,1} spectrograms (unnormalised 0..255 data is not what the cast would be fed in practice)"
     model.prefetch = True
     return out
 
@@ -224,7 +240,7 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(batch, z_dim, protocol, shape=(128, 128)):
+def cpu_baseline(batch, z_dim, protocol, shape=(128, 128), extra_configs=True):
     """CPU oracle (stock PyTorch-CPU ops = the ATen kernels the reference dispatches to, autograd backward, restated
     Adam) on the SAME batch shape; median of the timed steps.  Two thread settings: the fastest one found on this host
     class (tools/cpu_threads.py: 16 of 8/16/32/64/128 on the 2x64-core EPYC 9575F box) and all cores."""
@@ -263,11 +279,24 @@ def cpu_baseline(batch, z_dim, protocol, shape=(128, 128)):
     best = run(best_t, *plan[0])
     allc = run(phys, *plan[1]) if phys != best_t else best        # all PHYSICAL host cores
     top = best if best["value"] >= allc["value"] else allc
-    return {"value": top["value"], "unit": "spectrograms/s", "cores": top["threads"], "kind": "port",
-            "sample": "median of %d train steps of batch %d (z=%d) after %d warm-up, oracle/vae_oracle.py on torch-CPU"
-                      % (top["timed"], batch, z_dim, top["warmup"]),
-            "cpu_model": cpu_model_string(), "os_cpu_count": cores, "physical_cores": phys, "protocol": protocol,
-            "best_thread_count": best, "all_cores": allc}
+    out = {"value": top["value"], "unit": "spectrograms/s", "cores": top["threads"], "kind": "port",
+           "sample": "median of %d train steps of batch %d (z=%d) after %d warm-up, oracle/vae_oracle.py on torch-CPU"
+                     % (top["timed"], batch, z_dim, top["warmup"]),
+           "cpu_model": cpu_model_string(), "os_cpu_count": cores, "physical_cores": phys, "protocol": protocol,
+           "best_thread_count": best, "all_cores": allc}
+    if protocol == "full" and shape == (128, 128) and extra_configs:
+        # BASELINE.md section 3 asks for configs 1-3; configs[1] is the headline above
+        def cfg(b, zz):
+            nonlocal x, ew, ed, batch, z_dim
+            keep = (x, ew, ed, batch, z_dim)
+            batch, z_dim = b, zz
+            x = torch.from_numpy(syn.spectrograms(b, shape=shape))
+            ew, ed = [torch.from_numpy(a) for a in syn.noise(b, zz)]
+            r = run(best_t, 3, 10)
+            x, ew, ed, batch, z_dim = keep
+            return r
+        out["configs"] = {"configs[0]: batch 64, z=32": cfg(64, 32), "configs[2]: batch 256, z=64": cfg(256, 64)}
+    return out
 
 
 def main():
@@ -392,18 +421,26 @@ def main():
         # HBM bytes of the same kernels from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
         # passes of this command; tools/pmc_traffic.py) -- counters cannot be read from inside this process, so the
         # committed summary of the latest pass is quoted; null when there is none for this configuration
-        traffic, traffic_src = None, None
+        # The summary records the hash of the kernel sources it was measured on (tools/pmc_traffic.py); it is quoted
+        # only when that is the running tree's, otherwise `traffic` is null and `traffic_stale` says what exists.
+        traffic, traffic_src, traffic_stale = None, None, None
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[::-1]:
             try:
                 tj = json.load(open(path))
                 if B == 256 and world == 1 and args.z_dim == 32 and (H, W) == (128, 128):
-                    traffic, traffic_src = tj["conv_family_bytes_per_step"], os.path.relpath(path, ROOT)
+                    if tj.get("csrc_sha16") == csrc_sha16():
+                        traffic, traffic_src = tj["conv_family_bytes_per_step"], os.path.relpath(path, ROOT)
+                    else:
+                        traffic_stale = {"source": os.path.relpath(path, ROOT), "recorded_on_csrc_sha16": tj.get("csrc_sha16"),
+                                         "running_csrc_sha16": csrc_sha16(),
+                                         "conv_family_bytes_per_step": tj.get("conv_family_bytes_per_step")}
                 break
             except Exception:
                 pass
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_stale": traffic_stale,
                     "kernel": "conv+convT+BatchNorm kernels, forward+backward (SURVEY 8d aggregate)",
                     "algorithmic_bytes_per_step": B * a_conv, "conv_family_ms_per_step": round(conv_ms, 4),
                     # `achieved` uses the coarse pass (HIP events only at kernel-family boundaries); the fine pass
@@ -430,7 +467,9 @@ def main():
            "value": round(value, 1), "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if args.dtype == "f32" else "f32 arithmetic, bf16 activation storage", "data": "synthetic",
+           "dtype": ("f32" if args.dtype == "f32" else "f32 arithmetic, bf16 activation storage")
+                    + " (fc1/fc8 products: fp32 operands as three bf16 limbs on bf16 MFMA, six limb products, fp32 accumulate; "
+                      "convolutions and the small products on fp32 MFMA / packed fp32 FMA)", "data": "synthetic",
            "config": {"workload": "configs[%d]: mouse_sylls VAE, batch %d synthetic %dx%d fp32 spectrograms per GPU, z=%d, "
                                   "train step = zero_grad+forward+backward%s+Adam, device-resident batches"
                                   % (4 if (H, W) != (128, 128) else (3 if world > 1 else (2 if args.z_dim == 64 else 1)), B, H, W, args.z_dim,

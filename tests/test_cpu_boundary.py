@@ -170,7 +170,7 @@ def test_size_extension_layout_mirror_and_surface(shape):
 
 def test_unsupported_sizes_are_refused():
     lib = _lib.load()
-    for bad in [(128, 192), (96, 128), (64, 128), (128, 512), (2048, 128)]:
+    for bad in [(128, 192), (96, 128), (64, 128), (128, 512), (2048, 128), (384, 128), (512, 256)]:
         with pytest.raises(ValueError):
             VAE(device_name="cpu", x_shape=bad)
         assert lib.ava_arena_floats_hw(32, bad[0], bad[1]) == -1 and lib.ava_workspace_bytes_hw(32, bad[0], bad[1], 8) == 0

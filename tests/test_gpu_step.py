@@ -168,7 +168,13 @@ def test_train_step_matches_reference_golden(B, z):
         np.testing.assert_allclose(v[idx], G["s1.exp_avg_sq." + s.name], rtol=40 * tol,
                                    atol=tol * max(np.abs(v).max(), 1e-3 * gs * gs))
         pv = named[s.name].detach().cpu().numpy().ravel()
-        np.testing.assert_allclose(pv[idx], G["s1.val." + s.name], rtol=0, atol=2.2e-3)
+        # Adam's first step moves every entry by ~lr = 1e-3: most sampled entries must land on the reference's value
+        # (a model Adam never touched fails this), the rest (gradient entries near zero whose sign a ReLU-mask flip
+        # changes) within the step size.  The update itself is pinned entry by entry in
+        # test_adam_delta_matches_reference_golden.
+        dv = np.abs(pv[idx] - G["s1.val." + s.name])
+        assert np.mean(dv < 2e-5) >= (0.5 if sens else 0.8), s.name
+        assert dv.max() < 2.2e-3, s.name
         assert float(st[s.index]["step"]) == float(G["s1.adam_step"])
 
 
@@ -189,7 +195,7 @@ def test_three_steps_then_eval_matches_golden():
         assert rel(getattr(model, "bn%d" % i).running_var.cpu(), G["final.bn%d.running_var" % i]) < 1e-4
     model.eval()
     with torch.no_grad():
-        assert rel(float(model.forward(x).item()), G["eval.loss"]) < 2e-3
+        assert rel(float(model.forward(x).item()), G["eval.loss"]) < 1e-3
     fresh = build_model(z, train=False)
     fixed_noise(fresh, B, z)
     with torch.no_grad():

@@ -37,7 +37,10 @@ def main():
         w = 1024.0 * wd.get(k, [0, 0.0])[1] / steps
         kernels[k] = {"launches_per_step": calls // steps, "read_bytes_per_step": round(f), "write_bytes_per_step": round(w)}
     conv = {k: v for k, v in kernels.items() if k.startswith(CONV_PREFIX)}
-    out = {"steps": steps, "unit": "bytes per step (B=256 per GPU)",
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha16
+    out = {"steps": steps, "unit": "bytes per step (B=256 per GPU)", "csrc_sha16": csrc_sha16(),
            "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 halves wide streaming reads); WRITE_SIZE KiB x 1024",
            "conv_family_bytes_per_step": sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in conv.values()),
            "all_kernels_bytes_per_step": sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in kernels.values()),

@@ -36,6 +36,27 @@ case $pass in
     timeout 600 python tools/reserve_bench.py > $out/reserve_bench.log 2>&1
     tail -n 5 $out/pytest.log; cat $out/reserve_bench.log
     ;;
+  final)
+    # the round's evidence in one call: kernel stats, HBM traffic (two --pmc passes), SQ counters, the bench lines
+    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+    R=$PWD
+    rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loader-path > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+    find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/final_kernel_stats.csv \;
+    rm -rf $out/prof
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --global-batch 0 --no-loader-path --no-roofline > $out/pmc_fetch.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --global-batch 0 --no-loader-path --no-roofline > $out/pmc_write.log 2>&1
+    python3 tools/pmc_traffic.py $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $out/pmc_write -name "*counter_collection.csv" | head -1) > $out/pmc_traffic.json
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/pmc_sq -o sq -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --global-batch 0 --no-loader-path --no-roofline > $out/pmc_sq.log 2>&1
+    python3 tools/pmc_sq.py $(find $out/pmc_sq -name "*counter_collection.csv" | head -1) > $out/pmc_sq.json
+    rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq
+    mkdir -p profiles/r03 && cp $out/pmc_traffic.json profiles/r03/pmc_traffic.json      # so that the bench below quotes this build's traffic
+    python3 bench.py > $out/bench_final.json 2> $out/bench_final.err
+    python3 bench.py --z-dim 64 --no-cpu-baseline --no-loader-path > $out/bench_z64.json 2> $out/bench_z64.err
+    python3 bench.py --per-gpu-batch 128 --global-batch 0 --no-cpu-baseline --no-loader-path > $out/bench_B128.json 2> $out/bench_B128.err
+    python3 bench.py --height 256 --width 256 --z-dim 128 --per-gpu-batch 64 --global-batch 0 --steps 50 --no-cpu-baseline --no-loader-path > $out/bench_256x256_z128_B64_fp32.json 2> $out/bench_256_fp32.err
+    python3 bench.py --height 256 --width 256 --z-dim 128 --per-gpu-batch 64 --global-batch 0 --steps 50 --dtype bf16 --no-cpu-baseline --no-loader-path > $out/bench_256x256_z128_B64_bf16act.json 2> $out/bench_256_bf16.err
+    tail -c 400 $out/bench_final.json
+    ;;
   gemmabl)
     timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k gemm > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
     for d in 0 1 2 4 8 3 6 7 15; do

@@ -221,6 +221,64 @@ struct TileStager {
   }
 };
 
+// ---- fp32 values as three bf16 limbs (matrix-core kernels on v_mfma_f32_16x16x32_bf16) -----------------------------
+// x = x0 + x1 + x2 exactly (round-to-nearest at each cut; gemm_limb.hip has the error analysis): a product keeps the six
+// limb pairs with i + j <= 2 and is fp32-faithful at 6/16 of the fp32 MFMA's matrix time.
+typedef __bf16 ava_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ava_bf16x2v __attribute__((ext_vector_type(2)));
+typedef float ava_f32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t ava_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t ava_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ava_limb_sub(float a, float b) {      // one v_sub_f32 (never paired into v_pk_add_f32)
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void ava_limb_split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = __builtin_bit_cast(uint32_t, __builtin_convertvector((ava_f32x2v){x, y}, ava_bf16x2v));
+  float rx = ava_limb_sub(x, __uint_as_float(p0 << 16)), ry = ava_limb_sub(y, __uint_as_float(p0 & 0xffff0000u));
+  p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((ava_f32x2v){rx, ry}, ava_bf16x2v));
+  rx = ava_limb_sub(rx, __uint_as_float(p1 << 16));
+  ry = ava_limb_sub(ry, __uint_as_float(p1 & 0xffff0000u));
+  p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector((ava_f32x2v){rx, ry}, ava_bf16x2v));
+}
+
+// TileStager for the limb kernels: same loads, prologue and masks; the tile lands in LDS as three limb planes, each
+// [CIN / 8 channel octets][R * C pixels][8 channels] bf16 -- a pixel's octet is one 16-byte slot and the 16 pixels of a
+// matrix-core group are 256 contiguous bytes (conflict-free ds_read_b128 fragments).
+template <int CIN, int PRO, int R, int C, int NT = 256, typename TIN = float, typename TIN2 = float>
+struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2> {
+  using Base = TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2>;
+  static_assert(CIN % 8 == 0, "limb planes are made of channel octets");
+  static constexpr int NPIX = R * C, Q8 = CIN / 8;
+  static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
+  static constexpr int TILE_BYTES = 3 * PLANE_BYTES;
+  __device__ __forceinline__ void store(unsigned char* __restrict__ lds, const float* __restrict__ coef) {
+#pragma unroll
+    for (int i = 0; i < Base::NPF; ++i) {
+      const int idx = this->tid + NT * i;
+      const float* ca = coef + this->q4[i];
+      const avaf4 x = this->v[i];
+      const avaf4 y = PRO == PRO_BWD ? this->v2[i] : x;
+      const bool ok = (this->inb >> i) & 1u;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = ok ? prologue<PRO>(x[e], y[e], ca[e], ca[32 + e], ca[64 + e]) : 0.f;
+      ava_u32x2 p0, p1, p2;
+      uint32_t a, b, c;
+      ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
+      ava_limb_split2(o[2], o[3], a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
+      const int q = idx % Base::Q, pix = idx / Base::Q;
+      unsigned char* d = lds + ((q >> 1) * NPIX + pix) * 16 + (q & 1) * 8;
+      if ((this->live >> i) & 1u) {
+        *reinterpret_cast<ava_u32x2*>(d) = p0;
+        *reinterpret_cast<ava_u32x2*>(d + PLANE_BYTES) = p1;
+        *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
+      }
+    }
+  }
+};
+
 // Workgroups of one resident wave of a persistent kernel: occupancy (workgroups per CU) x CUs.  A persistent grid
 // larger than that runs in rounds whose last one is partly empty, and pays the per-workgroup set-up (weights into
 // registers, pipeline fill) once per round.

@@ -276,3 +276,139 @@ struct PairFrag {
     }
   }
 };
+
+// ---- the same fragments on the bf16 matrix cores with three-limb operands (conv_common.h) --------------------------
+// K = (tap, channel octet): lane (m / n, kg) of v_mfma_f32_16x16x32_bf16 holds 8 consecutive k = the 8 channels of one
+// octet at one tap; a chunk of 4 k-groups is one MFMA per limb pair.  Weights: three bf16x8 limbs per (chunk, cout tile)
+// in registers; activations: one 16-byte LDS read per limb and chunk (TileStagerL planes).
+template <int CIN, int COUT, int MODE, int CLS, int IC, int NPIX, int MTO = 0>
+struct ClassFragL {
+  static_assert(CIN % 8 == 0, "channel octets");
+  static constexpr int Q8 = CIN / 8;
+  static constexpr int KG = n_taps<MODE>(CLS) * Q8;
+  static constexpr int NCH = (KG + 3) / 4;
+  static constexpr int MT = MTO > 0 ? MTO : (COUT + 15) / 16;
+  static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
+  int off[NCH];                         // byte offset of this lane's 16-byte slot relative to the group's first pixel, plane 0
+  ava_bf16x8 w[NCH][3][MT];
+
+  // lane_pix: pixel offset of this lane's pixel inside a 16-pixel group (n * stride)
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_pix, int mtb = 0) {
+    const int m = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int g = 4 * c + kg;
+      const bool valid = g < KG;
+      const int t = valid ? g / Q8 : 0;
+      const int c8 = valid ? g - t * Q8 : 0;
+      int ky = 0, kx = 0;
+#pragma unroll
+      for (int tt = 0; tt < n_taps<MODE>(CLS); ++tt)
+        if (tt == t) { ky = tap_ky<MODE>(CLS, tt); kx = tap_kx<MODE>(CLS, tt); }
+      int dr, dc;
+      if (MODE == MODE_UP) { dr = ky == 0 ? 1 : 0; dc = kx == 0 ? 1 : 0; }
+      else { dr = ky; dc = kx; }
+      off[c] = (c8 * NPIX + lane_pix + dr * IC + dc) * 16;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = 16 * (mtb + mt) + m;
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          wv[j] = (valid && co < COUT) ? G[((ky * 3 + kx) * CIN + c8 * 8 + j) * COUT + co] : 0.f;
+        ava_u32x4 p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t a, b, d;
+          ava_limb_split2(wv[2 * j], wv[2 * j + 1], a, b, d);
+          p0[j] = a; p1[j] = b; p2[j] = d;
+        }
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));      // weights final before the tile loop (see ClassFrag::init)
+        w[c][0][mt] = __builtin_bit_cast(ava_bf16x8, p0);
+        w[c][1][mt] = __builtin_bit_cast(ava_bf16x8, p1);
+        w[c][2][mt] = __builtin_bit_cast(ava_bf16x8, p2);
+      }
+    }
+  }
+
+  // px: LDS byte address of the group's first pixel (channel octet 0, limb plane 0)
+  __device__ __forceinline__ void run(const unsigned char* __restrict__ px, f32x4 (&acc)[2][MT]) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const ava_bf16x8 b0 = *reinterpret_cast<const ava_bf16x8*>(px + off[c]);
+      const ava_bf16x8 b1 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + PLANE_BYTES);
+      const ava_bf16x8 b2 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + 2 * PLANE_BYTES);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 a = acc[c & 1][mt];                // smallest terms first
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][2][mt], b0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b2, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b1, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b1, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b0, a, 0, 0, 0);
+        acc[c & 1][mt] = a;
+      }
+    }
+  }
+};
+
+// two output rows in one tile (stride 1, 8 output channels), limb form: K walks 4 input rows x 3 taps x channel octets
+template <int CIN, int IC, int NPIX>
+struct PairFragL {
+  static_assert(CIN % 8 == 0, "channel octets");
+  static constexpr int Q8 = CIN / 8;
+  static constexpr int KG = 12 * Q8;
+  static constexpr int NCH = (KG + 3) / 4;
+  static constexpr int MT = 1;
+  static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
+  int off[NCH];
+  ava_bf16x8 w[NCH][3][1];
+
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_pix, int /*mtb*/ = 0) {
+    const int m = lane & 15, kg = lane >> 4;
+    const int half = m >> 3, co = m & 7;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int g = 4 * c + kg;
+      const bool valid = g < KG;
+      const int gg = valid ? g : 0;
+      const int dr = gg / (3 * Q8), rem = gg - dr * 3 * Q8;
+      const int kx = rem / Q8, c8 = rem - kx * Q8;
+      const int ky = dr - half;
+      off[c] = (c8 * NPIX + lane_pix + dr * IC + kx) * 16;
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        wv[j] = (valid && ky >= 0 && ky <= 2) ? G[((ky * 3 + kx) * CIN + c8 * 8 + j) * 8 + co] : 0.f;
+      ava_u32x4 p0, p1, p2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t a, b, d;
+        ava_limb_split2(wv[2 * j], wv[2 * j + 1], a, b, d);
+        p0[j] = a; p1[j] = b; p2[j] = d;
+      }
+      asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
+      w[c][0][0] = __builtin_bit_cast(ava_bf16x8, p0);
+      w[c][1][0] = __builtin_bit_cast(ava_bf16x8, p1);
+      w[c][2][0] = __builtin_bit_cast(ava_bf16x8, p2);
+    }
+  }
+
+  __device__ __forceinline__ void run(const unsigned char* __restrict__ px, f32x4 (&acc)[2][1]) const {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const ava_bf16x8 b0 = *reinterpret_cast<const ava_bf16x8*>(px + off[c]);
+      const ava_bf16x8 b1 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + PLANE_BYTES);
+      const ava_bf16x8 b2 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + 2 * PLANE_BYTES);
+      f32x4 a = acc[c & 1][0];
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][2][0], b0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b2, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b0, a, 0, 0, 0);
+      acc[c & 1][0] = a;
+    }
+  }
+};

@@ -10,12 +10,29 @@
 #include "conv_mfma.h"
 #include "conv_recomp.h"
 
+// Which shapes run the limb form: the stride-1 forward layers with 16 input channels (conv5 16 -> 24: 31.3 -> 24 us,
+// convt5 16 -> 8: 45.8 -> 32 us).  Measured on every shape (profiles/r03/limb_conv_forward.txt): the 8-channel layers are
+// HBM-bound and only pay the staging waves' split; the stride-2 layers read their fragments with a 32-byte lane stride
+// (two-way LDS conflicts: conv4 29 -> 35 us); the 24- and 32-channel layers need > 128 VGPRs for three limbs of weights and
+// lose their second workgroup per CU, and at one or two tiles per workgroup they are bound by launch / prologue latency,
+// not by the matrix pipe (+-1 us).  Lab build: AVA_CONV_LIMB=0 (off), 1 (this table), 2 (every shape with CIN % 8 == 0).
+static bool conv_limb_on(int Cin, int Cout, int mode, int pro) {
+  static const int sel = [] { const char* e = ava_env("AVA_CONV_LIMB"); return e ? atoi(e) : 1; }();
+  (void)Cout;
+  if (sel == 0) return false;
+  if (sel == 2) return true;
+  return Cin == 16 && mode == MODE_S1 && pro == PRO_BN;
+}
+
 // ACT: storage type of the activations this launch touches -- the input of a forward layer (PRO_BN), the saved
 // activation in2 of the ReLU/BatchNorm-backward prologue (PRO_BWD), the raw x of the BatchNorm-backward sums (EPI_BWD)
 // and the output of a forward layer (EPI_FWD).  Gradients (PRO_BWD / PRO_ID inputs, EPI_BWD outputs) are always fp32.
 // RECOMP (conv2's forward): the 8-channel input y1 = relu(conv1(bn1 x)) is not in memory; the staging waves build its
 // window from the x window (conv_recomp.h), a.in is x.
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR, typename ACT, bool RECOMP = false>
+// LIMB: the products run on v_mfma_f32_16x16x32_bf16 with fp32 operands split into three bf16 limbs (six limb products,
+// fp32-faithful; conv_common.h / conv_mfma.h): the staging waves write limb planes, the matrix-core waves hold limb weights.
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, bool MSPLIT, bool PAIR, typename ACT, bool RECOMP = false,
+          bool LIMB = false>
 __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) {
   using G = Geom<MODE, TW, TH>;
   using TIN = typename std::conditional<PRO == PRO_BN, ACT, float>::type;
@@ -26,7 +43,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   static_assert(!MSPLIT || MTA == 2, "MSPLIT deals exactly two cout tiles to the wave pairs");
   static_assert(!PAIR || (MODE == MODE_S1 && COUT == 8 && !MSPLIT && TH % 2 == 0), "PAIR: stride 1, 8 output channels");
   constexpr int NCLS = n_classes<MODE>();
-  constexpr int TILE_F = IR * IC * CIN;
+  static_assert(!LIMB || (!RECOMP && CIN % 8 == 0), "limb planes are made of channel octets");
+  constexpr int TILE_F = LIMB ? IR * IC * CIN * 3 / 2 : IR * IC * CIN;      // floats; LIMB: three bf16 planes
   extern __shared__ __align__(16) float smem[];
   float* tile0 = smem;                      // two tile buffers
   float* coef = smem + 2 * TILE_F;          // [3][32]
@@ -49,9 +67,13 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
   TileWalk walk(a.ntiles);
-  typename std::conditional<RECOMP, Y1Stager<IR, IC, ACT>, TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT>>::type stg;   // staging waves only (threadIdx.x 0..255)
-  auto stg_store = [&](float* tile) {
-    if constexpr (RECOMP) stg.store(tile, coef, xs); else stg.store(tile, coef);
+  typename std::conditional<RECOMP, Y1Stager<IR, IC, ACT>,
+                            typename std::conditional<LIMB, TileStagerL<CIN, PRO, IR, IC, 256, TIN, ACT>,
+                                                      TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT>>::type>::type stg;   // staging waves only (threadIdx.x 0..255)
+  auto stg_store = [&](float* tile) __attribute__((always_inline)) {
+    if constexpr (RECOMP) stg.store(tile, coef, xs);
+    else if constexpr (LIMB) stg.store(reinterpret_cast<unsigned char*>(tile), coef);
+    else stg.store(tile, coef);
   };
   // stride-2 gathers hold the most staging registers: keeping their first tile in flight across the prologue raised
   // conv2's forward from 70 to 112 VGPRs (3 -> 2 resident workgroups per CU, 42 -> 50 us); they load after it instead
@@ -116,13 +138,21 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   // ---------------- matrix-core waves ----------------
   const int mtb = MSPLIT ? (wave & 1) : 0;  // first cout tile of this wave
   const int wp = wave >> 1;                 // MSPLIT: which half of the pixel groups
-  typename std::conditional<PAIR, PairFrag<CIN, IC>, ClassFrag<CIN, COUT, MODE, 0, IC, MT>>::type f0;
-  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT> f1;
-  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT> f2;
-  ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT> f3;
+  constexpr int LCIN = LIMB ? CIN : 8;      // (the limb classes need CIN % 8 == 0 even where they are not used)
+  typename std::conditional<LIMB, typename std::conditional<PAIR, PairFragL<LCIN, IC, IR * IC>, ClassFragL<LCIN, COUT, MODE, 0, IC, IR * IC, MT>>::type,
+                            typename std::conditional<PAIR, PairFrag<CIN, IC>, ClassFrag<CIN, COUT, MODE, 0, IC, MT>>::type>::type f0;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, IR * IC, MT>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT>>::type f1;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, IR * IC, MT>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT>>::type f2;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, IR * IC, MT>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT>>::type f3;
   constexpr int SP = MODE == MODE_DOWN ? 2 : 1;
-  f0.init(a.G, lane, SP * n * CIN, mtb);
-  if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
+  constexpr int PIXU = LIMB ? 1 : CIN;      // what one pixel is worth in the fragments' offset unit (16-byte slots / floats)
+  f0.init(a.G, lane, SP * n * PIXU, mtb);
+  if (NCLS > 1) { f1.init(a.G, lane, n * PIXU, mtb); f2.init(a.G, lane, n * PIXU, mtb); f3.init(a.G, lane, n * PIXU, mtb); }
+  // LDS address of pixel `pix` of a tile, in the form the fragments' run() takes
+  auto pxp = [&](const float* tile, int pix) __attribute__((always_inline)) {
+    if constexpr (LIMB) return reinterpret_cast<const unsigned char*>(tile) + pix * 16;
+    else return tile + pix * CIN;
+  };
   const int lane_out = PAIR ? ((kg >> 1) * a.Wo + n) * COUT + 4 * (kg & 1) : (MODE == MODE_UP ? 2 * n : n) * COUT + 4 * kg;
   const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;
   float bias[MT][4], s1[MT][4], s2[MT][4];
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (MODE == MODE_UP) {
         const int cls = gi & 3, r = g >> 2;
-        const float* px = tile + r * IC * CIN;
+        const auto px = pxp(tile, r * IC);
         if (cls == 0) f0.run(px, acc);
         else if (cls == 1) f1.run(px, acc);
         else if (cls == 2) f2.run(px, acc);
@@ -198,7 +228,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         constexpr int GPR = TW / 16;
         constexpr int S = (MODE == MODE_S1 && !PAIR) ? 1 : 2;
         constexpr int SX = MODE == MODE_DOWN ? 2 : 1;
-        f0.run(tile + (S * (g / GPR) * IC + SX * 16 * (g % GPR)) * CIN, acc);
+        f0.run(pxp(tile, S * (g / GPR) * IC + SX * 16 * (g % GPR)), acc);
       }
       const int gout = group_out(g) + lane_out;
 #pragma unroll
@@ -270,17 +300,17 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   __syncthreads();
 }
 
-template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, typename ACT, bool RECOMP = false>
+template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, typename ACT, bool RECOMP = false, bool LIMB = false>
 int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   using G = Geom<MODE, TW, TH>;
   constexpr int MT = (COUT + 15) / 16;
   constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // same rules as launch_mfma
   constexpr bool PAIR = MODE == MODE_S1 && COUT == 8;
   constexpr int XS_F = RECOMP ? Y1Stager<G::IR, G::IC, ACT>::LDS_FLOATS : 0;
-  const size_t lds = (size_t)(2 * G::IR * G::IC * CIN + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
+  const size_t lds = (size_t)(2 * (LIMB ? G::IR * G::IC * CIN * 3 / 2 : G::IR * G::IC * CIN) + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP, LIMB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return AVA_ELAUNCH;
     attr_set = true;
@@ -292,14 +322,14 @@ int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   int per_cu = 1;
   static int resident = 0;
   if (resident == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP, LIMB>), 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     resident = per_cu * 256;
   }
   b.part_rows = grid;
   if (grid > b.ntiles) grid = b.ntiles;
   if (grid > ava_scale_grid(resident)) grid = ava_scale_grid(resident);
   { const char* e = ava_env("AVA_GRID"); if (e) grid = atoi(e); if (grid > b.ntiles) grid = b.ntiles; if (grid > b.part_rows) grid = b.part_rows; }
-  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP>), dim3(grid), dim3(512), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP, LIMB>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
@@ -313,6 +343,17 @@ int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
     }
   }
   if (a.rc.G1 != nullptr) return AVA_EINVAL;
+#ifdef AVA_LAB
+  constexpr bool kLimbBuilt = CIN % 8 == 0;
+#else
+  constexpr bool kLimbBuilt = CIN == 16 && MODE == MODE_S1 && PRO == PRO_BN;
+#endif
+  if constexpr (kLimbBuilt) {
+    if (conv_limb_on(CIN, COUT, MODE, PRO)) {
+      if (a.act_bf16) return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, ava_bf16, false, true>(a, grid, st);
+      return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, float, false, true>(a, grid, st);
+    }
+  }
   if (a.act_bf16) return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, ava_bf16>(a, grid, st);
   return launch_mfma_ws_t<CIN, COUT, MODE, PRO, EPI, TW, TH, float>(a, grid, st);
 }

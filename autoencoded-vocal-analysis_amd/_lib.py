@@ -62,6 +62,7 @@ SIGNATURES = {
     "ava_backward_part": (_i, [_p, _p, _i, _i, _p]),
     "ava_grad_bucket": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "ava_adam_step": (_i, [_p, _d, _d, _d, _d, _i, _p]),
+    "ava_adam_step_range": (_i, [_p, _i64, _i64, _d, _d, _d, _d, _i, _p]),
     "ava_encode": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
     "ava_decode": (_i, [_p, _p, _i, _i, _p, _p]),
     "ava_last_z": (_p, [_p]),

@@ -396,30 +396,38 @@ __global__ __launch_bounds__(512, MINW) void gemm_limb_kernel(const GemmArgs g, 
     const bool fin = g.splits == 1;
     const int ldo = fin ? g.ldc : g.N;
     float* __restrict__ obase = fin ? g.C : g.C + (size_t)ci.split * g.M * g.N;
-    if (!AVA_DBG_BIT(g, 8))
+    if (!AVA_DBG_BIT(g, 8)) {
+      // row tiles outermost: consecutive store instructions of a wave then write neighbouring 64-byte pieces of the SAME
+      // 16 output rows (4 kg quads x 16 bytes per row and instruction), which the L2 merges into full lines
+      float4 bq[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
-      if (gn >= g.N) continue;           // N % 4 == 0: a quad is inside or outside as a whole
-      float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (fin && g.bias != nullptr) bq = *reinterpret_cast<const float4*>(g.bias + gn);
+      for (int j = 0; j < TN; ++j) {
+        const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
+        bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fin && g.bias != nullptr && gn < g.N) bq[j] = *reinterpret_cast<const float4*>(g.bias + gn);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int gm = ci.m0 + wm * WM + i * 16 + fr;
         if (gm >= g.M) continue;
-        float cv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (fin) {
-          cv[0] = apply_act(cv[0] + bq.x, g.act); cv[1] = apply_act(cv[1] + bq.y, g.act);
-          cv[2] = apply_act(cv[2] + bq.z, g.act); cv[3] = apply_act(cv[3] + bq.w, g.act);
-          if (g.mask != nullptr) {
-            const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)gm * g.ldc + gn);
-            if (!(mk.x > 0.f)) cv[0] = 0.f;
-            if (!(mk.y > 0.f)) cv[1] = 0.f;
-            if (!(mk.z > 0.f)) cv[2] = 0.f;
-            if (!(mk.w > 0.f)) cv[3] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
+          if (gn >= g.N) continue;         // N % 4 == 0: a quad is inside or outside as a whole
+          float cv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (fin) {
+            cv[0] = apply_act(cv[0] + bq[j].x, g.act); cv[1] = apply_act(cv[1] + bq[j].y, g.act);
+            cv[2] = apply_act(cv[2] + bq[j].z, g.act); cv[3] = apply_act(cv[3] + bq[j].w, g.act);
+            if (g.mask != nullptr) {
+              const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)gm * g.ldc + gn);
+              if (!(mk.x > 0.f)) cv[0] = 0.f;
+              if (!(mk.y > 0.f)) cv[1] = 0.f;
+              if (!(mk.z > 0.f)) cv[2] = 0.f;
+              if (!(mk.w > 0.f)) cv[3] = 0.f;
+            }
           }
+          *reinterpret_cast<float4*>(obase + (size_t)gm * ldo + gn) = make_float4(cv[0], cv[1], cv[2], cv[3]);
         }
-        *reinterpret_cast<float4*>(obase + (size_t)gm * ldo + gn) = make_float4(cv[0], cv[1], cv[2], cv[3]);
       }
     }
   }

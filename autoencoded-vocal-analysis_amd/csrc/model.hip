@@ -1098,6 +1098,20 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, b
   return reduce_wgrads(m, whole ? 0 : 0, whole ? NCONV : 7, B, st);      // encoder (whole: all 14) weight/bias gradients
 }
 
+// the same update on the slice [offset, offset + count) of the arenas (data parallelism with a sharded optimizer:
+// every rank updates 1/N of each gradient bucket and the parameters are all-gathered; dist.py)
+extern "C" int ava_adam_step_range(ava_model* m, int64_t offset, int64_t count, double lr, double beta1, double beta2,
+                                   double eps, int step, ava_stream_t s) {
+  if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr || offset < 0 || count <= 0 ||
+      offset + count > m->arena || offset % 4 != 0 || count % 4 != 0)
+    return AVA_EINVAL;
+  mark(m, -1, to_stream(s));
+  const int rc = ava_adam_flat_guarded(m->P + offset, m->G + offset, m->M + offset, m->V + offset, count, lr, beta1, beta2,
+                                       eps, step, m->status_last, to_stream(s));
+  mark(m, CAT_ADAM, to_stream(s));
+  return rc;
+}
+
 extern "C" int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step,
                              ava_stream_t s) {
   if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr) return AVA_EINVAL;

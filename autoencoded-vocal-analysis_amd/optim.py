@@ -64,7 +64,17 @@ class FlatAdam(torch.optim.Adam):
         self._step_count_flat += 1
         b1, b2 = g['betas']
         lib = _lib.load()
-        if m._handle is not None:
+        if m._handle is not None and m._sharded_adam():
+            # data parallel, sharded optimizer: this rank's slice of every bucket, then the parameters to everyone
+            from . import dist as _dist
+            rc, handles = 0, []
+            for off, cnt in m._buckets():
+                so, sc = _dist.shard_of(off, cnt)
+                rc = rc or lib.ava_adam_step_range(m._handle, so, sc, float(g['lr']), float(b1), float(b2),
+                                                   float(g['eps']), self._step_count_flat, _lib.stream())
+                handles.append(_dist.all_gather_bucket_async(m._params, off, cnt))
+            _dist.wait_all(handles)
+        elif m._handle is not None:
             rc = lib.ava_adam_step(m._handle, float(g['lr']), float(b1), float(b2), float(g['eps']),
                                    self._step_count_flat, _lib.stream())
         else:

@@ -365,7 +365,10 @@ class VAE(nn.Module):
                        "ava_backward_part")
             off, cnt = ctypes.c_int64(), ctypes.c_int64()
             _lib.check(lib.ava_grad_bucket(self._handle, part, ctypes.byref(off), ctypes.byref(cnt)), "ava_grad_bucket")
-            pending.append(_dist.allreduce_gradients_async(self._grads[off.value:off.value + cnt.value]))
+            if self._sharded_adam():
+                pending.append(_dist.reduce_scatter_bucket_async(self._grads, off.value, cnt.value))
+            else:
+                pending.append(_dist.allreduce_gradients_async(self._grads[off.value:off.value + cnt.value]))
         # bench.py sets _comm_events to a list: the time the compute stream then spends blocked on the collectives
         # (end of the last backward kernel -> all buckets reduced) is the exposed communication of the step
         evs = getattr(self, "_comm_events", None)
@@ -377,6 +380,35 @@ class VAE(nn.Module):
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             evs.append((e0, e1))
+
+    def _buckets(self):
+        """(offset, count) of the gradient buckets, in the order the backward parts complete them"""
+        lib = _lib.load()
+        out = []
+        for part in range(lib.ava_backward_num_parts()):
+            off, cnt = ctypes.c_int64(), ctypes.c_int64()
+            _lib.check(lib.ava_grad_bucket(self._handle, part, ctypes.byref(off), ctypes.byref(cnt)), "ava_grad_bucket")
+            out.append((off.value, cnt.value))
+        return out
+
+    def _sharded_adam(self):
+        """Data parallel with the optimizer sharded over the ranks (dist.sharded_adam): only when every bucket splits."""
+        if not _dist.sharded_adam() or self._handle is None:
+            return False
+        ok = getattr(self, "_sharded_ok", None)
+        if ok is None:
+            ok = self._sharded_ok = all(_dist.shard_of(o, c) is not None for o, c in self._buckets())
+        return ok
+
+    def gather_adam_state(self):
+        """Sharded optimizer: make exp_avg / exp_avg_sq complete on every rank (collective; before a checkpoint)."""
+        if not self._sharded_adam():
+            return
+        hs = []
+        for o, c in self._buckets():
+            hs.append(_dist.all_gather_bucket_async(self._exp_avg, o, c))
+            hs.append(_dist.all_gather_bucket_async(self._exp_avg_sq, o, c))
+        _dist.wait_all(hs)
 
     def _check_status(self):
         """Blocking check of the device status word (d not positive in some forward so far).  Under data parallelism
@@ -393,6 +425,8 @@ class VAE(nn.Module):
         # vae.py:312, and never reaches ``optimizer.step()``).  What is NOT rolled back: the forwards that ran in the
         # meantime (at most the polling lag, two steps) have moved the BatchNorm running statistics.
         skipped = int(self._status[1].item())
+        if self._sharded_adam():
+            skipped //= len(self._buckets())         # one guarded launch per bucket slice and step
         opt = getattr(self, "optimizer", None)
         if opt is not None and skipped > 0:
             opt._step_count_flat = max(0, opt._step_count_flat - skipped)
@@ -546,6 +580,7 @@ class VAE(nn.Module):
                 self.loss['test'][epoch] = loss
             if (save_freq is not None) and (epoch % save_freq == 0) and (epoch > 0):
                 filename = "checkpoint_" + str(epoch).zfill(3) + '.tar'
+                self.gather_adam_state()                # sharded optimizer: collective, every rank
                 if _dist.rank() == 0:
                     self.save_state(filename)
             if (vis_freq is not None) and (epoch % vis_freq == 0):

@@ -124,6 +124,11 @@ int ava_occupy_cus(int workgroups, int lds_bytes, float usec, ava_stream_t s);
  * reference raises ValueError inside forward and never reaches optimizer.step(), vae.py:312,353) the kernel leaves
  * parameters and moments untouched. */
 int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step, ava_stream_t s);
+/* The same update restricted to the floats [offset, offset + count) of the four arenas (offset, count multiples of 4):
+ * a data-parallel caller that reduce-scatters the gradient buckets lets every rank update its 1/N slice of each bucket
+ * and all-gathers the parameters (same bytes on the wire as an all-reduce, Adam's HBM traffic divided by N). */
+int ava_adam_step_range(ava_model* m, int64_t offset, int64_t count, double lr, double beta1, double beta2, double eps,
+                        int step, ava_stream_t s);
 /* VAE.encode (vae.py:216-233): mu,u,d [B,z] (d = exp(.)); bn_train as above. */
 int ava_encode(ava_model* m, const float* x, int B, int bn_train, float* mu, float* u, float* d, ava_stream_t s);
 /* VAE.decode (vae.py:258-270): z [B,z] -> x_rec [B,16384]. */

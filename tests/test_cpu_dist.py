@@ -43,6 +43,13 @@ def _worker(rank, world, port, q):
         gl = adist.global_loss(out["loss"].detach().double(), z, 10.0, 1)
         n = adist.global_dataset_len(B)
         # the "d not positive" status word travels with the buckets: MAX over ranks, asynchronously
+        # sharded-optimizer helpers: this rank's slice of a bucket, and the in-place all-gather of the slices
+        assert adist.shard_of(64, 128) == (64 + rank * 64, 64) and adist.shard_of(0, 6) is None
+        buf = torch.zeros(8 + 128)
+        o, c = adist.shard_of(8, 128)
+        buf[o:o + c] = float(rank + 1)
+        adist.wait_all([adist.all_gather_bucket_async(buf, 8, 128)])
+        assert buf[:8].abs().sum() == 0 and bool((buf[8:72] == 1).all()) and bool((buf[72:] == 2).all())
         st = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
         adist.wait_all([adist.allreduce_max_async(st)])
         assert st.tolist() == [1, 0]

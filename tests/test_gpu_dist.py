@@ -138,6 +138,60 @@ def test_invalid_posterior_on_one_rank_stops_every_rank_at_the_same_step():
     assert t0 == 2.0 and t1 == 2.0
 
 
+def _sharded_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    from ava_amd import dist as adist, synthetic as syn
+    from gpu_util import build_model
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, B = 32, 8
+        x = torch.from_numpy(syn.spectrograms(B * world)[B * rank:B * rank + B]).cuda()
+        ew, ed = syn.noise(B * world, z)
+        sl = slice(B * rank, B * rank + B)
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["AVA_DP_SHARDED_ADAM"] = mode
+            model = build_model(z)
+            adist.broadcast_parameters(model)
+            model.noise_source = lambda b, zz: (ew[sl], ed[sl])
+            assert model._sharded_adam() == (mode == "1") or model._handle is None
+            for _ in range(2):
+                model.optimizer.zero_grad()
+                model.forward(x).backward()
+                model.optimizer.step()
+            assert model._sharded_adam() == (mode == "1")
+            model.gather_adam_state()
+            torch.cuda.synchronize()
+            res[mode] = (model._params.clone(), model._exp_avg.clone(), model._exp_avg_sq.clone())
+        same = all(torch.equal(a, b) for a, b in zip(res["0"], res["1"]))
+        q.put((rank, same, float(res["1"][0].double().sum().item())))
+    finally:
+        os.environ.pop("AVA_DP_SHARDED_ADAM", None)
+        td.destroy_process_group()
+
+
+def test_sharded_adam_equals_allreduce_adam():
+    """reduce-scatter -> Adam on 1/N of every bucket -> all-gather (AVA_DP_SHARDED_ADAM=1) gives bit-identical parameters
+    and, once gathered, optimizer state as the all-reduce form, on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == res[1][2]
+
+
 def test_bench_gpus_2_starts_two_ranks_itself():
     """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks (a child torch.distributed.run) and
     rank 0 prints ONE line with n_gpus = 2.  The box has one GPU, so the hidden `--backend gloo` lets both ranks share

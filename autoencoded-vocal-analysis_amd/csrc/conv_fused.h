@@ -22,6 +22,9 @@ struct FusedArgs {
   long long* acc_out;    // != null: sum dx, sum dx*xhat are accumulated here (bn_acc.h) instead of bn_partials rows
   BnFin fin;             // fin.acc != null: da / db / dc are derived from the accumulated sums of the layer above
   int act_bf16;          // x and dy2 (activations) are stored as bfloat16; dy and dx (gradients) are always fp32
+  RecompArgs rcd;        // rcd.G1 != null: `dy` is a 1-channel tensor and the 8-channel upstream gradient is its 3x3 gather with the
+                         // weights G1 [9][1][8], formed in the staging waves (conv_recomp.h: convt7's data gradient inside convt6's backward)
+  int skip_dx;           // thin 8 -> 1 backward: only the weight gradient + BatchNorm sums (its data gradient is formed by the consumer)
   RecompArgs rc;         // rc.G1 != null: `x` is the raw spectrogram batch; the layer input y1 is recomputed from it (conv_recomp.h)
   int sweep;             // thin kernels: workgroups sweep the tile list together instead of per-XCD chunks
 };

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "conv_mfma.h"
 #include "conv_fused.h"
+#include "conv_recomp.h"
 
 template <int LMODE, int TW, int TH>
 struct FGeom {
@@ -305,7 +306,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
   for (int e = t; e < NW + CO; e += 256) prow[e] = wacc[e];
 }
 
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW, typename ACT>
+// DUREC (convt6's backward): the upstream gradient dy (8 channels, full resolution) does not exist in memory -- it is
+// convt7's data gradient, a 3x3 gather of the 1-channel seed a.dy, formed on the matrix cores by the staging waves as
+// they build the dU tile (conv_recomp.h: DU1to8Stager).
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW, typename ACT, bool DUREC = false>
 __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMODE == MODE_DOWN)) ? 2 : 4) void conv3x3_bwd_fused_ws_kernel(const FusedArgs a) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
@@ -322,6 +326,8 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   float* cx = smem + 2 * BUF_F;              // [3][32]
   float* cd = cx + 96;                       // [3][32]
   float* red = cd + 96;                      // [4][32*MT]
+  float* xs = red + 4 * 32 * MT;             // DUREC: the staging waves' private seed windows
+  static_assert(!DUREC || (CO == 8 && DYPRO == PRO_BWD && DR == 9), "the 1 -> 8 gather feeds a 9-row dU window of 8 channels");
 
   const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
   const bool stager = wave8 < 4;             // waves 0-3 stage tiles, waves 4-7 run the two matrix-core phases
@@ -348,7 +354,10 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   };
   TileWalk walk(a.ntiles);
   TileStager<CI, PRO_BN, XR, XC, false, 256, ACT, ACT> sx;      // staging waves only (threadIdx.x 0..255)
-  TileStager<CO, DYPRO, DR, DC, false, 256, float, ACT> sd;
+  typename std::conditional<DUREC, DU1to8Stager<DC, ACT>, TileStager<CO, DYPRO, DR, DC, false, 256, float, ACT>>::type sd;
+  auto sd_store = [&](float* dst) __attribute__((always_inline)) {
+    if constexpr (DUREC) sd.store(dst, cd, xs); else sd.store(dst, cd);
+  };
   auto prefetch = [&](int tl) {
     int b, y0, x0, gy, gx;
     origin(tl, b, y0, x0);
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   };
   if (stager) {
     sx.init();
-    sd.init();
+    if constexpr (DUREC) sd.init(a.rcd, xs); else sd.init();
     if (walk.valid()) prefetch(walk.cur);    // tile 0 goes in flight BEFORE the coefficient prologue
   }
   __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
     __builtin_amdgcn_s_setprio(3);
     if (walk.valid()) {
       sx.store(smem, cx);
-      sd.store(smem + XF, cd);
+      sd_store(smem + XF);
       if (walk.has_next()) prefetch(walk.next());
     }
     __syncthreads();                                            // (A) tile 0 ready
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
       if (walk.has_next()) {                                    // tile it+1 -> the other buffer, tile it+2 in flight
         float* nb = smem + ((it + 1) & 1) * BUF_F;
         sx.store(nb, cx);
-        sd.store(nb + XF, cd);
+        sd_store(nb + XF);
         const int nn = walk.next() + walk.step;
         if (nn < walk.end) prefetch(nn);
       }
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
 // ------------------------------------------------------------------------------------------------
 static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap);
 
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW, typename ACT>
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW, typename ACT, bool DUREC = false>
 static int launch_fused_t(const FusedArgs& a, int grid, hipStream_t st) {
   using FG = FGeom<LMODE, TW, TH>;
   constexpr int MT = (CI + 15) / 16;
@@ -641,14 +650,14 @@ static int launch_fused_t(const FusedArgs& a, int grid, hipStream_t st) {
   if (!ws) return AVA_EINVAL;           // every shape of the library runs the wave-specialised kernel
 #endif
   const size_t buf_f = (size_t)FG::XR * FG::XC * CI + FG::DR * FG::DC * CO + 16;
-  const size_t tiles_f = (ws ? 2 : 1) * buf_f + 192 + 4 * 32 * MT;
+  const size_t tiles_f = (ws ? 2 : 1) * buf_f + 192 + 4 * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0);
   const size_t red_f = (size_t)9 * CI * CO + CO;
   const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
 #ifdef AVA_LAB
-  const void* kfn = ws ? reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>)
+  const void* kfn = ws ? reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT, DUREC>)
                        : reinterpret_cast<const void*>(&conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>);
 #else
-  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>);
+  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT, DUREC>);
 #endif
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
@@ -666,13 +675,20 @@ static int launch_fused_t(const FusedArgs& a, int grid, hipStream_t st) {
   if (!ws) hipLaunchKernelGGL((conv3x3_bwd_fused_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>), dim3(grid), dim3(256), lds, st, b);
   else
 #endif
-  hipLaunchKernelGGL((conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT>), dim3(grid), dim3(512), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_bwd_fused_ws_kernel<CI, CO, LMODE, DYPRO, TW, TH, MINW, ACT, DUREC>), dim3(grid), dim3(512), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
 template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int MINW>
 static int launch_fused(const FusedArgs& a, int grid, hipStream_t st) {
+  if constexpr (CI == 8 && CO == 8 && LMODE == MODE_UP && DYPRO == PRO_BWD && TH == 4) {
+    if (a.rcd.G1 != nullptr) {            // convt6's backward with convt7's data gradient formed in the staging waves
+      if (a.act_bf16) return launch_fused_t<CI, CO, LMODE, DYPRO, TW, TH, MINW, ava_bf16, true>(a, grid, st);
+      return launch_fused_t<CI, CO, LMODE, DYPRO, TW, TH, MINW, float, true>(a, grid, st);
+    }
+  }
+  if (a.rcd.G1 != nullptr) return AVA_EINVAL;
   if (a.act_bf16) return launch_fused_t<CI, CO, LMODE, DYPRO, TW, TH, MINW, ava_bf16>(a, grid, st);
   return launch_fused_t<CI, CO, LMODE, DYPRO, TW, TH, MINW, float>(a, grid, st);
 }

@@ -13,6 +13,7 @@
 // needed between writing it and reading it back (LDS operations of one wave execute in order).
 #pragma once
 #include "conv_common.h"
+#include "conv_mfma.h"
 
 // RAWI: also keep the raw (un-normalised) y1 of the window's interior [RI x CI at (ROFF, COFF)] in a second LDS tile
 // (the fused backward's BatchNorm sums need raw x at the dx pixels)
@@ -117,6 +118,153 @@ struct Y1Stager {
           if (ri >= 0 && ri < RI && ci >= 0 && ci < CI) *reinterpret_cast<avaf4*>(raw + (ri * CI + ci) * 8 + q4) = y;
         }
       }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same idea on the MATRIX cores, for a 1 -> 8-channel 3x3 gather whose 8-channel result is only an intermediate:
+// convt7's data gradient dd6 = gather(seed r, W7) (vae.py:269 backward), consumed by convt6's fused backward as the `dy`
+// operand of its ReLU / BatchNorm-backward prologue.  The VALU form above costs ~16 vector instructions per output
+// value; here two output rows of 16 pixels x 8 channels are ONE 16 x 16 tile of v_mfma_f32_16x16x4_f32 (M = 2 rows x 8
+// channels, N = 16 pixels, K = 3 taps kx x 4 input rows: 3 MFMAs, the PairFrag arrangement of conv_mfma.h), and a lane ends
+// up with four channels of one pixel -- exactly the quad it writes to the LDS tile.  ~30 vector instructions per 256 values.
+// The k order is (kx outer, input row inner), i.e. the fma chain of thin_1to8_kernel with a zero term per kx.
+//
+// Window [9 x C] (the stride-2 kernels' 2 TH + 1 rows at TH = 4).  Wave w of the four staging waves produces row pair
+// (2w, 2w + 1) for every 16-column group, and the groups g = w, w + 4, .. of the last row (8).  It reads only input rows
+// it loaded itself: a private LDS window of 8 rows x (16 NG + 2) columns -- rows 0-3: input rows of its pair, rows 4-6:
+// input rows of row 8, row 7 and the pad columns: zeros (written once), so that a zero weight never meets a non-finite
+// pad value.
+template <int C>
+struct Conv1to8Core {
+  static constexpr int NG = (C + 15) / 16;
+  static constexpr int XCP = 16 * NG + 2;
+  static constexpr int XS_F = 8 * XCP;                          // floats of one wave's private window
+  static constexpr int XE = 7 * (C + 2);                        // elements loaded per tile and wave
+  static constexpr int NLX = (XE + 63) / 64;
+  static constexpr int NUW = NG + (NG + 3) / 4;                 // units per wave (upper bound)
+  static constexpr int LDS_FLOATS = 4 * XS_F;
+  static_assert(NLX <= 16 && NUW <= 16, "masks are 16 bits wide");
+  float xr[NLX];
+  float wA[3];
+  unsigned xin;
+  int lane, wave;
+
+  __device__ __forceinline__ void init(const float* __restrict__ G1, float* __restrict__ xs_all, int tid) {
+    lane = tid & 63; wave = tid >> 6;
+    const int m = lane & 15, kgA = lane >> 4, half = m >> 3, co = m & 7, ky = kgA - half;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = (ky >= 0 && ky <= 2) ? G1[(ky * 3 + c) * 8 + co] : 0.f;
+      asm volatile("" : "+v"(v));
+      wA[c] = v;
+    }
+    float* xs = xs_all + wave * XS_F;
+    for (int e = lane; e < XS_F; e += 64) xs[e] = 0.f;          // pad columns and row 7 stay zero for the whole kernel
+    xin = 0u;
+  }
+  // window row (0..10, relative to image row gy0 - 1) of private row pr
+  __device__ __forceinline__ int win_row(int pr) const { return pr < 4 ? 2 * wave + pr : 4 + pr; }
+
+  __device__ __forceinline__ void load(const float* __restrict__ src, int b, int H, int W, int gy0, int gx0) {
+    const float* __restrict__ base = src + (size_t)b * H * W;
+    xin = 0u;
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int e = lane + 64 * i, pr = e / (C + 2), pc = e - pr * (C + 2);
+      const int gy = gy0 - 1 + win_row(pr), gx = gx0 - 1 + pc;
+      const bool ok = e < XE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      xr[i] = base[cy * W + cx];
+      xin |= ok ? (1u << i) : 0u;
+    }
+  }
+  // private window <- the loaded values through v -> pro(v) (zero outside the image)
+  template <class PRO>
+  __device__ __forceinline__ void stage(float* __restrict__ xs_all, PRO pro) {
+    float* __restrict__ xs = xs_all + wave * XS_F;
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int e = lane + 64 * i, pr = e / (C + 2), pc = e - pr * (C + 2);
+      if (e < XE) xs[pr * XCP + pc] = ((xin >> i) & 1u) ? pro(xr[i]) : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // unit u of this wave -> (valid, first window row of the tile's M rows 0-7, column group); lane's output pixel / quad
+  __device__ __forceinline__ bool unit(int u, int& row, int& col, int& quad, int& pb, int& g) const {
+    const int n = lane & 15, kg = lane >> 4;
+    const bool own = u < NG;
+    g = own ? u : wave + 4 * (u - NG);
+    pb = own ? 0 : 4;
+    row = (own ? 2 * wave : 8) + (kg >> 1);
+    col = 16 * g + n;
+    quad = kg & 1;
+    return g < NG && col < C && (own || (kg >> 1) == 0);
+  }
+  __device__ __forceinline__ f32x4 mma(const float* __restrict__ xs_all, int pb, int g) const {
+    const float* __restrict__ xs = xs_all + wave * XS_F;
+    const int n = lane & 15, kg = lane >> 4;
+    const float* p = xs + (pb + kg) * XCP + 16 * g + n;
+    const float b0 = p[0], b1 = p[1], b2 = p[2];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[0], b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[1], b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[2], b2, acc, 0, 0, 0);
+    return acc;
+  }
+};
+
+// dU tile [9 x C x 8] of convt6's fused backward, with dy = convt7's data gradient formed on the fly from the 1-channel
+// seed:  dU = y > 0 ? A * dy + Bc * y + Cc : 0  (prologue<PRO_BWD>), y = the saved activation d6 (a.dy2), zero outside
+// the image.  Interface of TileStager (init / load / store).
+template <int C, typename ACT>
+struct DU1to8Stager {
+  using Core = Conv1to8Core<C>;
+  static constexpr int LDS_FLOATS = Core::LDS_FLOATS;
+  Core core;
+  avaf4 y2[Core::NUW];
+  unsigned yin;                      // bit u: unit u's pixel exists in the window and lies inside the image
+  __device__ __forceinline__ void init(const RecompArgs& rc, float* xs_all, int tid = (int)threadIdx.x) {
+    core.init(rc.G1, xs_all, tid);
+    yin = 0u;
+  }
+  // in: the 1-channel seed [B,H,W]; in2: the saved 8-channel activation [B,H,W,8]; (gy0, gx0): window origin
+  __device__ __forceinline__ void load(const float* __restrict__ in, const float* __restrict__ in2, int b, int H, int W,
+                                       int gy0, int gx0) {
+    core.load(in, b, H, W, gy0, gx0);
+    const ACT* __restrict__ base2 = ava_as<ACT>(in2) + (size_t)b * H * W * 8;
+    yin = 0u;
+#pragma unroll
+    for (int u = 0; u < Core::NUW; ++u) {
+      int row, col, quad, pb, g;
+      const bool v = core.unit(u, row, col, quad, pb, g);
+      const int gy = gy0 + row, gx = gx0 + col;
+      const bool ok = v && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      y2[u] = ava_ld4<ACT>(base2 + (cy * W + cx) * 8 + 4 * quad);
+      yin |= ok ? (1u << u) : 0u;
+    }
+  }
+  // lds: the [9 x C x 8] fp32 tile; coef: A [0..7], Bc [32..39], Cc [64..71]
+  __device__ __forceinline__ void store(float* __restrict__ lds, const float* __restrict__ coef, float* __restrict__ xs_all) {
+    core.stage(xs_all, [](float v) { return v; });               // PRO_ID on the seed
+#pragma unroll
+    for (int u = 0; u < Core::NUW; ++u) {
+      int row, col, quad, pb, g;
+      const bool v = core.unit(u, row, col, quad, pb, g);
+      if (u >= Core::NG && core.wave + 4 * (u - Core::NG) >= Core::NG) continue;      // wave-uniform: no such group
+      const f32x4 acc = core.mma(xs_all, pb, g);
+      const float* ca = coef + 4 * quad;
+      const bool in = (yin >> u) & 1u;
+      avaf4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = y2[u][r];
+        o[r] = (in && y > 0.f) ? fmaf(ca[r], acc[r], fmaf(ca[32 + r], y, ca[64 + r])) : 0.f;
+      }
+      if (v) *reinterpret_cast<avaf4*>(lds + (row * C + col) * 8 + 4 * quad) = o;
     }
   }
 };

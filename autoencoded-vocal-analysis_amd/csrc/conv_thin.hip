@@ -1324,7 +1324,7 @@ static int thin_bwd_fused_launch_w(const FusedArgs& a0, int grid, int Cin, int d
     return AVA_OK;
   }
   // 8 -> 1: dx by the 1 -> 8 gather kernel (store only), then weight gradient + BatchNorm sums in one pass over x
-  if (a.dx == nullptr) return AVA_EINVAL;
+  if (a.dx == nullptr && !a.skip_dx) return AVA_EINVAL;
   ConvArgs c = {};
   c.in = a.dy; c.in2 = a.dy2; c.pa = a.da; c.pb = a.db; c.pc = a.dc; c.G = a.Gb; c.out = a.dx;
   c.B = a.B; c.Hi = a.Ho; c.Wi = a.Wo; c.Ho = a.Hi; c.Wo = a.Wi; c.ntiles = a.ntiles;
@@ -1336,9 +1336,11 @@ static int thin_bwd_fused_launch_w(const FusedArgs& a0, int grid, int Cin, int d
     return thin_resident(&thin_1to8_kernel<W, PRO_ID, EPI_NONE>, W, 0);
   }();
   const int dgrid = a.ntiles < ava_scale_grid(dcap) ? a.ntiles : ava_scale_grid(dcap);
-  if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BWD, EPI_NONE>), dim3(dgrid), block, 0, st, c);
-  else hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_ID, EPI_NONE>), dim3(dgrid), block, 0, st, c);
-  AVA_CHECK_LAUNCH();
+  if (!a.skip_dx) {                       // (skipped when the consumer forms this gradient itself: conv_recomp.h)
+    if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_BWD, EPI_NONE>), dim3(dgrid), block, 0, st, c);
+    else hipLaunchKernelGGL((thin_1to8_kernel<W, PRO_ID, EPI_NONE>), dim3(dgrid), block, 0, st, c);
+    AVA_CHECK_LAUNCH();
+  }
 #ifdef AVA_LAB
   if constexpr (W == 128) {
     static const int direct = [] { const char* e = ava_env("AVA_THIN_STATS_DIRECT"); return e ? atoi(e) : 1; }();

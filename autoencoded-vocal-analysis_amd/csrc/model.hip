@@ -905,6 +905,13 @@ static int fused_grid(const ava_model* m, int l, int B) {
   return ava_conv_fused_grid_for(B, m->lay[l].hi, m->lay[l].wi, L.cin, L.cout, L.mode);
 }
 
+// convt7's data gradient formed inside convt6's fused backward (the shape that kernel is instantiated for: W = 128 tiles of
+// 32 x 4 low-resolution pixels).  Lab build: AVA_DD6_FUSED=0 restores the separate data-gradient launch.
+static bool dd6_fused(const ava_model* m) {
+  static const bool on = [] { const char* e = ava_env("AVA_DD6_FUSED"); return e == nullptr || atoi(e) != 0; }();
+  return on && fused_grid(m, 12, m->lastB > 0 ? m->lastB : 1) > 0 && m->lay[12].wi % 32 == 0 && m->lay[12].hi % 4 == 0;
+}
+
 static int conv_layer_backward(ava_model* m, int l, const float* x0, const float* gin, const float* gin2,
                                const float* ca, const float* cb, const float* cc, int pro, float* gout, int B,
                                hipStream_t st) {
@@ -927,6 +934,13 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
     a.fin = ((!thin || l == 0) && pro == PRO_BWD && acc_pair_bwd(m, l + 1)) ? fin_bwd(m, l + 1, B) : fin_none();   // l = 0: conv1's packed-FMA backward
     a.acc_out = ((!thin || l == 13 || l == 0) && acc_pair_bwd(m, l)) ? acc_slot(m, 14 + l) : nullptr;   // l = 13: convt7's sums kernel; l = 0: conv1's
     a.tiles_y = a.tiles_x = a.ntiles = 0;
+    if (dd6_fused(m)) {
+      // convt7's data gradient dd6 (8 channels at full resolution: 128 MiB written and read back at batch 256) is never
+      // stored: convt7's launch only forms its weight gradient and BatchNorm sums, and convt6's fused backward gathers its
+      // dy window from the 1-channel seed in the staging waves (conv_recomp.h)
+      if (l == 13) a.skip_dx = 1;
+      if (l == 12) { a.dy = m->seed; a.rcd.G1 = m->Gb[13]; }
+    }
     TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
     mark(m, CAT_CONV_BWD_DATA, st);
     if (a.acc_out != nullptr) return AVA_OK;                  // finalised by the next backward kernel

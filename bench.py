@@ -366,7 +366,9 @@ def main():
     # ---- exposed communication: time the compute stream spends waiting for the gradient all-reduces --------------
     dist_info = {"backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world,
                  "ranks_seen": world, "grad_allreduce_bytes_per_step": int(model._grads.numel()) * 4 if world > 1 else 0,
-                 "buckets": _lib.load().ava_backward_num_parts() if world > 1 else 0}
+                 "buckets": _lib.load().ava_backward_num_parts() if world > 1 else 0,
+                 # CUs every persistent grid leaves free for the collective's workgroups (dist.cu_reserve); sharded optimizer?
+                 "cu_reserve": _lib.load().ava_get_cu_reserve(), "sharded_adam": bool(model._sharded_adam()) if world > 1 else False}
     if world > 1:
         t = torch.ones(1, device="cuda")
         torch.distributed.all_reduce(t)

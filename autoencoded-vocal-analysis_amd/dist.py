@@ -111,9 +111,15 @@ def allreduce_gradients_async(flat_slice):
 
 def wait_all(handles):
     """Make the current stream (and, for CPU backends, the host) wait for the given all-reduces."""
+    waited = False
     for h in handles:
         if h is not None:
             h.wait()
+            waited = True
+    # gloo stages device tensors through the host on streams of its own; RCCL's collectives are ordered on the compute
+    # stream by wait().  For the CPU-backed test backend make the hand-back explicit.
+    if waited and td.get_backend() != "nccl" and torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 def allreduce_max_(t):

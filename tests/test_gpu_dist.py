@@ -168,8 +168,9 @@ def _sharded_worker(rank, world, port, q):
             model.gather_adam_state()
             torch.cuda.synchronize()
             res[mode] = (model._params.clone(), model._exp_avg.clone(), model._exp_avg_sq.clone())
+        diffs = [float((a.double() - b.double()).abs().max()) for a, b in zip(res["0"], res["1"])]
         same = all(torch.equal(a, b) for a, b in zip(res["0"], res["1"]))
-        q.put((rank, same, float(res["1"][0].double().sum().item())))
+        q.put((rank, same, float(res["1"][0].double().sum().item()), diffs))
     finally:
         os.environ.pop("AVA_DP_SHARDED_ADAM", None)
         td.destroy_process_group()
@@ -188,7 +189,7 @@ def test_sharded_adam_equals_allreduce_adam():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res[0][1] and res[1][1]
+    assert res[0][1] and res[1][1], (res[0][3], res[1][3])
     assert res[0][2] == res[1][2]
 
 

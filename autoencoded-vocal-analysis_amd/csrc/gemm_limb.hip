@@ -396,16 +396,10 @@ __global__ __launch_bounds__(512, MINW) void gemm_limb_kernel(const GemmArgs g, 
     const bool fin = g.splits == 1;
     const int ldo = fin ? g.ldc : g.N;
     float* __restrict__ obase = fin ? g.C : g.C + (size_t)ci.split * g.M * g.N;
-    if (!AVA_DBG_BIT(g, 8)) {
-      // row tiles outermost: consecutive store instructions of a wave then write neighbouring 64-byte pieces of the SAME
-      // 16 output rows (4 kg quads x 16 bytes per row and instruction), which the L2 merges into full lines
-      float4 bq[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
-        bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fin && g.bias != nullptr && gn < g.N) bq[j] = *reinterpret_cast<const float4*>(g.bias + gn);
-      }
+    // dW products and split-K slabs: nothing to add or mask -- keep the per-element activation switch out of the store loop
+    const bool plain = !fin || (g.bias == nullptr && g.mask == nullptr && g.act == ACT_NONE);
+    const bool relu = g.act == ACT_RELU;         // (ava_gemm_limb_ok admits ACT_NONE and ACT_RELU only)
+    if (!AVA_DBG_BIT(g, 8) && plain) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int gm = ci.m0 + wm * WM + i * 16 + fr;
@@ -414,17 +408,36 @@ __global__ __launch_bounds__(512, MINW) void gemm_limb_kernel(const GemmArgs g, 
         for (int j = 0; j < TN; ++j) {
           const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
           if (gn >= g.N) continue;         // N % 4 == 0: a quad is inside or outside as a whole
+          *reinterpret_cast<f32x4*>(obase + (size_t)gm * ldo + gn) = acc[i][j];
+        }
+      }
+    } else if (!AVA_DBG_BIT(g, 8)) {
+      // row tiles outermost: consecutive store instructions of a wave then write neighbouring 64-byte pieces of the SAME
+      // 16 output rows (4 kg quads x 16 bytes per row and instruction), which the L2 merges into full lines
+      float4 bq[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
+        bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias != nullptr && gn < g.N) bq[j] = *reinterpret_cast<const float4*>(g.bias + gn);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int gm = ci.m0 + wm * WM + i * 16 + fr;
+        if (gm >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int gn = ci.n0 + wn * WN + j * 16 + 4 * kg;
+          if (gn >= g.N) continue;
           float cv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          if (fin) {
-            cv[0] = apply_act(cv[0] + bq[j].x, g.act); cv[1] = apply_act(cv[1] + bq[j].y, g.act);
-            cv[2] = apply_act(cv[2] + bq[j].z, g.act); cv[3] = apply_act(cv[3] + bq[j].w, g.act);
-            if (g.mask != nullptr) {
-              const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)gm * g.ldc + gn);
-              if (!(mk.x > 0.f)) cv[0] = 0.f;
-              if (!(mk.y > 0.f)) cv[1] = 0.f;
-              if (!(mk.z > 0.f)) cv[2] = 0.f;
-              if (!(mk.w > 0.f)) cv[3] = 0.f;
-            }
+          cv[0] += bq[j].x; cv[1] += bq[j].y; cv[2] += bq[j].z; cv[3] += bq[j].w;
+          if (relu) { cv[0] = fmaxf(cv[0], 0.f); cv[1] = fmaxf(cv[1], 0.f); cv[2] = fmaxf(cv[2], 0.f); cv[3] = fmaxf(cv[3], 0.f); }
+          if (g.mask != nullptr) {
+            const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)gm * g.ldc + gn);
+            if (!(mk.x > 0.f)) cv[0] = 0.f;
+            if (!(mk.y > 0.f)) cv[1] = 0.f;
+            if (!(mk.z > 0.f)) cv[2] = 0.f;
+            if (!(mk.w > 0.f)) cv[3] = 0.f;
           }
           *reinterpret_cast<float4*>(obase + (size_t)gm * ldo + gn) = make_float4(cv[0], cv[1], cv[2], cv[3]);
         }
@@ -449,6 +462,7 @@ bool ava_gemm_limb_ok(const GemmArgs& g, int a_kmajor, int b_kmajor) {
   if (!a_kmajor && g.M % 4 != 0) return false;
   if (!b_kmajor && g.N % 4 != 0) return false;
   if (g.colsum != nullptr && a_kmajor) return false;
+  if (g.act != ACT_NONE && g.act != ACT_RELU) return false;
   // the epilogue stores (and reads bias / mask) as 16-byte quads of one output row
   if (g.N % 4 != 0 || g.ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(g.C) & 15) != 0) return false;
   if (g.bias != nullptr && (reinterpret_cast<uintptr_t>(g.bias) & 15) != 0) return false;

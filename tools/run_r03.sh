@@ -27,7 +27,7 @@ case $pass in
     ;;
   prof)
     cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-    rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_prof.json 2> $out/bench_prof.err
+    rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loader-path --global-batch 0 > $out/bench_prof.json 2> $out/bench_prof.err
     find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
     rm -rf $out/prof
     ;;
@@ -40,7 +40,7 @@ case $pass in
     # the round's evidence in one call: kernel stats, HBM traffic (two --pmc passes), SQ counters, the bench lines
     cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
     R=$PWD
-    rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loader-path > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
+    rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loader-path --global-batch 0 > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err
     find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/final_kernel_stats.csv \;
     rm -rf $out/prof
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --global-batch 0 --no-loader-path --no-roofline > $out/pmc_fetch.log 2>&1

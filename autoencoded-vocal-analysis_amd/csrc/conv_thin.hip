@@ -113,6 +113,38 @@ __device__ __forceinline__ void thin_stage1(float* __restrict__ lds, const float
   }
 }
 
+// The same window, register staged: `load` issues the global loads of a tile's window (clamped addresses, in-image bits
+// remembered), `store` applies the prologue and writes LDS.  The kernels below load tile k+1's window while tile k is
+// being multiplied, so the window's HBM latency is no longer paid between the two barriers of every tile (the direct
+// thin_stage1 waits for its loads right where it issues them).
+template <int W, int PRO>
+struct ThinWindow {
+  static constexpr int NV = (THIN_IR * THIN_IC + THIN_NT - 1) / THIN_NT;
+  float v[NV], v2[PRO == PRO_BWD ? NV : 1];
+  unsigned inb;
+  __device__ __forceinline__ void load(const float* __restrict__ in, const float* __restrict__ in2, int b, int H, int gy0) {
+    inb = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + THIN_NT * i, r = e / THIN_IC, c = e - r * THIN_IC;
+      const int gy = gy0 + r, gx = c - 1;
+      const bool ok = e < THIN_IR * THIN_IC && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const size_t off = ((size_t)b * H + min(max(gy, 0), H - 1)) * W + min(max(gx, 0), W - 1);
+      v[i] = in[off];
+      if (PRO == PRO_BWD) v2[i] = in2[off];
+      inb |= ok ? (1u << i) : 0u;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds, float ca, float cb, float cc) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + THIN_NT * i;
+      const float o = ((inb >> i) & 1u) ? prologue<PRO>(v[i], PRO == PRO_BWD ? v2[i] : 0.f, ca, cb, cc) : 0.f;
+      if (e < THIN_IR * THIN_IC) lds[e] = o;
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // 1 -> 8 channels: conv1 forward (PRO_BN, EPI_FWD), convt7 backward-data (PRO_ID, EPI_BWD)
 // ---------------------------------------------------------------------------------------------------------
@@ -124,7 +156,7 @@ __device__ __forceinline__ void thin_stage1(float* __restrict__ lds, const float
 // ACT: storage type of the 8-channel ACTIVATION this launch touches (EPI_FWD: the output; EPI_BWD: epi_x); the
 // 8-channel output of the data-gradient forms (EPI_BWD / EPI_NONE) is an fp32 gradient.
 template <int W, int PRO, int EPI, typename ACT = float>
-__global__ __launch_bounds__(2 * W) void thin_1to8_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(2 * W, W == 128 ? 4 : 2) void thin_1to8_kernel(const ConvArgs a) {
   using TOUT = typename std::conditional<EPI == EPI_FWD, ACT, float>::type;
   __shared__ float tile[THIN_IR * THIN_IC];
   __shared__ float red[THIN_NW][2][8];
@@ -163,12 +195,16 @@ __global__ __launch_bounds__(2 * W) void thin_1to8_kernel(const ConvArgs a) {
   const int tiles_y = a.Ho / THIN_TH;
   // sweeping walk: store-heavy, the only shared input is a 1-channel halo row (in-step A/B: conv1 forward 32.2 -> 29.3 us,
   // convt7 data gradient 35.4 -> 33.1 us against the per-XCD chunked walk)
-  for (TileWalk walk(a.ntiles, false); walk.valid(); walk.advance()) {
+  ThinWindow<W, PRO> win;
+  TileWalk walk(a.ntiles, false);
+  if (walk.valid()) { const int tl = walk.cur, b0 = tl / tiles_y; win.load(a.in, a.in2, b0, a.Hi, (tl - b0 * tiles_y) * THIN_TH - 1); }
+  for (; walk.valid(); walk.advance()) {
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
-    thin_stage1<W, PRO>(tile, a.in, a.in2, ca, cb, cc, b, a.Hi, oy0 - 1);
+    win.store(tile, ca, cb, cc);
     __syncthreads();
+    if (walk.has_next()) { const int tn = walk.next(), bn = tn / tiles_y; win.load(a.in, a.in2, bn, a.Hi, (tn - bn * tiles_y) * THIN_TH - 1); }
     avaf2 acc[THIN_TH][2];
 #pragma unroll
     for (int p = 0; p < THIN_TH; ++p) acc[p][0] = acc[p][1] = avaf2{0.f, 0.f};
@@ -727,11 +763,14 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
   }
   const bool edge_col = x == 0 || x == W - 1;
   const int tiles_y = a.Ho / THIN_TH;
-  for (TileWalk walk(a.ntiles, a.sweep == 0); walk.valid(); walk.advance()) {
+  ThinWindow<W, PRO_BN> win;
+  TileWalk walk(a.ntiles, a.sweep == 0);
+  if (walk.valid()) { const int tl = walk.cur, b0 = tl / tiles_y; win.load(a.x, nullptr, b0, a.Hi, (tl - b0 * tiles_y) * THIN_TH - 1); }
+  for (; walk.valid(); walk.advance()) {
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
-    thin_stage1<W, PRO_BN>(tile, a.x, nullptr, ha, hb, 0.f, b, a.Hi, oy0 - 1);
+    win.store(tile, ha, hb, 0.f);
     const size_t o0 = (((size_t)b * a.Ho + oy0) * W + x) * 8 + 4 * h;
     float du[THIN_TH][4];
 #pragma unroll
@@ -768,6 +807,7 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
       }
     }
     __syncthreads();
+    if (walk.has_next()) { const int tn = walk.next(), bn = tn / tiles_y; win.load(a.x, nullptr, bn, a.Hi, (tn - bn * tiles_y) * THIN_TH - 1); }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       float in[THIN_IR];
@@ -1014,11 +1054,14 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(con
   float T = 0.f, Rt = 0.f, Rb = 0.f, Cl = 0.f, Cr = 0.f, Ktl = 0.f, Ktr = 0.f, Kbl = 0.f, Kbr = 0.f;
   const float own = h == 0 ? 1.f : 0.f;                 // the scalar sums of dU are taken by one lane of each pair
   const int tiles_y = a.Hi / THIN_TH;
-  for (TileWalk walk(a.ntiles, a.sweep == 0); walk.valid(); walk.advance()) {
+  ThinWindow<W, DYPRO> win;
+  TileWalk walk(a.ntiles, a.sweep == 0);
+  if (walk.valid()) { const int tl = walk.cur, b0 = tl / tiles_y; win.load(a.dy, a.dy2, b0, a.Ho, (tl - b0 * tiles_y) * THIN_TH - 1); }
+  for (; walk.valid(); walk.advance()) {
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
-    thin_stage1<W, DYPRO>(tile, a.dy, a.dy2, da, db, dc, b, a.Ho, oy0 - 1);
+    win.store(tile, da, db, dc);
     const size_t o0 = (((size_t)b * a.Hi + oy0) * W + x) * 8 + 4 * h;
     avaf2 xh[THIN_TH][2];
 #pragma unroll
@@ -1028,6 +1071,7 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(con
       xh[r][1] = avaf2{fmaf(ha[2], v[2], hb[2]), fmaf(ha[3], v[3], hb[3])};
     }
     __syncthreads();
+    if (walk.has_next()) { const int tn = walk.next(), bn = tn / tiles_y; win.load(a.dy, a.dy2, bn, a.Ho, (tn - bn * tiles_y) * THIN_TH - 1); }
     // sums of dU over this thread's column of the tile and the image-border rows / columns / corners
     {
       float col = 0.f;

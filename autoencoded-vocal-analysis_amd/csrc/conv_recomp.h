@@ -268,3 +268,56 @@ struct DU1to8Stager {
     }
   }
 };
+
+// y1 = relu(conv1(bn1 x)) windows on the matrix cores (Conv1to8Core): the form of Y1Stager that costs a third of the vector
+// work.  [9 x C x 8] tile of bn2(y1) (zero outside the image) for conv2's forward / backward; RAWI: also the raw y1 of the
+// interior [RI x CI at (ROFF, COFF)] (the fused backward's BatchNorm sums need raw x at its dx pixels).
+template <int C, typename ACT, bool RAWI = false, int RI = 0, int CI = 0, int ROFF = 0, int COFF = 0>
+struct Y1MfmaStager {
+  using Core = Conv1to8Core<C>;
+  static constexpr int LDS_FLOATS = Core::LDS_FLOATS;
+  Core core;
+  float ca1, cb1;
+  float bias[4];                     // conv1's bias for this lane's channel quad (lane >> 4 & 1)
+  int gy0s, gx0s, Hs, Ws;            // origin / image size of the tile whose x window is in the registers
+  __device__ __forceinline__ void init(const RecompArgs& rc, float* xs_all, int tid = (int)threadIdx.x) {
+    core.init(rc.G1, xs_all, tid);
+    const int quad = ((tid & 63) >> 4) & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float v = rc.bias1[4 * quad + j]; asm volatile("" : "+v"(v)); bias[j] = v; }
+    ca1 = rc.pa1[0]; cb1 = rc.pb1[0];
+    gy0s = gx0s = 0; Hs = Ws = 1;
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ x, const float* /*in2*/, int b, int H, int W, int gy0, int gx0) {
+    core.load(x, b, H, W, gy0, gx0);
+    gy0s = gy0; gx0s = gx0; Hs = H; Ws = W;
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds, const float* __restrict__ coef, float* __restrict__ xs_all,
+                                        float* __restrict__ raw = nullptr) {
+    const float a1 = ca1, b1 = cb1;
+    core.stage(xs_all, [a1, b1](float v) { return fmaf(v, a1, b1); });        // prologue<PRO_BN> of bn1
+#pragma unroll
+    for (int u = 0; u < Core::NUW; ++u) {
+      int row, col, quad, pb, g;
+      const bool v = core.unit(u, row, col, quad, pb, g);
+      if (u >= Core::NG && core.wave + 4 * (u - Core::NG) >= Core::NG) continue;      // wave-uniform: no such group
+      const f32x4 acc = core.mma(xs_all, pb, g);
+      const float* ca = coef + 4 * quad;
+      const int gy = gy0s + row, gx = gx0s + col;
+      const bool in = gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+      avaf4 y, o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        y[r] = ava_stored<ACT>(fmaxf(acc[r] + bias[r], 0.f));
+        o[r] = in ? fmaf(y[r], ca[r], ca[32 + r]) : 0.f;
+      }
+      if (v) {
+        *reinterpret_cast<avaf4*>(lds + (row * C + col) * 8 + 4 * quad) = o;
+        if constexpr (RAWI) {
+          const int ri = row - ROFF, ci = col - COFF;
+          if (ri >= 0 && ri < RI && ci >= 0 && ci < CI) *reinterpret_cast<avaf4*>(raw + (ri * CI + ci) * 8 + 4 * quad) = y;
+        }
+      }
+    }
+  }
+};

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   float* coef = smem + 2 * TILE_F;          // [3][32]
   float* red = coef + 96;                   // [4][2*16*MTA]
   float* xs = red + 4 * 32 * MTA;           // RECOMP: the staging waves' private x windows
-  static_assert(!RECOMP || (CIN == 8 && PRO == PRO_BN), "conv1 is recomputed in front of conv2's forward only");
+  static_assert(!RECOMP || (CIN == 8 && PRO == PRO_BN && IR == 9), "conv1 is recomputed in front of conv2's forward only (9-row windows)");
   __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
 
   const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     else { gy0 = oy0 / 2; gx0 = ox0 / 2; }
   };
   TileWalk walk(a.ntiles);
-  typename std::conditional<RECOMP, Y1Stager<IR, IC, ACT>,
+  typename std::conditional<RECOMP, Y1MfmaStager<IC, ACT>,
                             typename std::conditional<LIMB, TileStagerL<CIN, PRO, IR, IC, 256, TIN, ACT>,
                                                       TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT>>::type>::type stg;   // staging waves only (threadIdx.x 0..255)
   auto stg_store = [&](float* tile) __attribute__((always_inline)) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   // conv2's forward from 70 to 112 VGPRs (3 -> 2 resident workgroups per CU, 42 -> 50 us); they load after it instead
   constexpr bool HOIST = MODE != MODE_DOWN;
   if (stager) {
-    if constexpr (RECOMP) stg.init(a.rc); else stg.init();
+    if constexpr (RECOMP) stg.init(a.rc, xs); else stg.init();
     if (HOIST && walk.valid()) {                                // tile 0 goes in flight BEFORE the coefficient prologue
       int b, oy0, ox0, gy0, gx0;
       origin(walk.cur, b, oy0, ox0, gy0, gx0);
@@ -319,7 +319,7 @@ int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   constexpr int MT = (COUT + 15) / 16;
   constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // same rules as launch_mfma
   constexpr bool PAIR = MODE == MODE_S1 && COUT == 8;
-  constexpr int XS_F = RECOMP ? Y1Stager<G::IR, G::IC, ACT>::LDS_FLOATS : 0;
+  constexpr int XS_F = RECOMP ? Y1MfmaStager<G::IC, ACT>::LDS_FLOATS : 0;
   const size_t lds = (size_t)(2 * (LIMB ? G::IR * G::IC * CIN * 3 / 2 : G::IR * G::IC * CIN) + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {

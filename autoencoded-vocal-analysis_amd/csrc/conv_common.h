@@ -302,8 +302,9 @@ struct TileWalk {
   int cur, end, step;
   // chunked: each XCD (workgroup index mod 8) walks its own contiguous eighth of the tile list, so that tiles sharing
   // halo rows share an L2; otherwise the workgroups sweep the list together (better for halo-free, store-heavy kernels)
-  __device__ __forceinline__ explicit TileWalk(int ntiles, bool chunked = true) {
-    const int g = (int)gridDim.x, w = (int)blockIdx.x;
+  // (w, g): this workgroup's index and the number of workgroups that share the tile list; default: the launch grid
+  __device__ __forceinline__ explicit TileWalk(int ntiles, bool chunked = true, int w_ = -1, int g_ = 0) {
+    const int g = w_ >= 0 ? g_ : (int)gridDim.x, w = w_ >= 0 ? w_ : (int)blockIdx.x;
     if (chunked && ((g | ntiles) & 7) == 0) {
       const int chunk = ntiles >> 3, xcd = w & 7;
       cur = xcd * chunk + (w >> 3);
@@ -339,6 +340,13 @@ struct WgradArgs {
   int B, Hi, Wi, Ho, Wo;
   int tiles_y, tiles_x, ntiles;
   int act_bf16;        // x and dy2 (activations) are stored as bfloat16
+};
+
+// one weight-gradient launch as data (model.hip defers the 16 x 16 layers' calls and issues them in pairs)
+struct WgradCall {
+  const float *x, *xa, *xb, *dy, *dy2, *da, *db, *dc;
+  float* partials;
+  int Hi, Wi, Cin, Cout, mode, dy_pro;
 };
 
 // all 14 weight-gradient reductions in one launch (model.hip)

@@ -244,6 +244,43 @@ int ava_conv3x3_wgrad_ex(const float* x, const float* xa, const float* xb, const
 #endif
 }
 
+// Two layers' weight gradients in one launch where a pair kernel exists (conv_mfma.hip: the 16 x 16 layers), otherwise
+// one after the other.  Same partial rows either way.
+int ava_conv3x3_wgrad_mfma_pair(const WgradArgs& a, int grid_a, const WgradCall& ca, const WgradArgs& b, int grid_b,
+                                const WgradCall& cb, hipStream_t st);
+int ava_conv3x3_wgrad_pair(const WgradCall& p, const WgradCall& q, int B, int act_bf16, ava_stream_t s) {
+  static const bool on = [] { const char* e = ava_env("AVA_WGRAD_PAIR"); return e == nullptr || atoi(e) != 0; }();
+  if (on && use_mfma()) {
+    WgradArgs w[2];
+    int grid[2];
+    const WgradCall* c[2] = {&p, &q};
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i) {
+      WgradArgs& a = w[i];
+      a.act_bf16 = act_bf16;
+      a.x = c[i]->x; a.xa = c[i]->xa; a.xb = c[i]->xb; a.dy = c[i]->dy; a.dy2 = c[i]->dy2;
+      a.da = c[i]->da; a.db = c[i]->db; a.dc = c[i]->dc; a.partials = c[i]->partials;
+      a.B = B; a.Hi = c[i]->Hi; a.Wi = c[i]->Wi;
+      const int mode = c[i]->mode;
+      a.Ho = mode == MODE_S1 ? a.Hi : (mode == MODE_DOWN ? a.Hi / 2 : a.Hi * 2);
+      a.Wo = mode == MODE_S1 ? a.Wi : (mode == MODE_DOWN ? a.Wi / 2 : a.Wi * 2);
+      a.ntiles = conv_geometry(B, a.Ho, a.Wo, &a.tiles_y, &a.tiles_x);
+      ok = a.ntiles > 0 && a.x != nullptr && a.dy != nullptr && a.partials != nullptr &&
+           !(c[i]->dy_pro == PRO_BWD && a.dy2 == nullptr);
+      grid[i] = 2 * a.ntiles < 512 ? 2 * a.ntiles : 512;
+    }
+    if (ok) {
+      const int rc = ava_conv3x3_wgrad_mfma_pair(w[0], grid[0], p, w[1], grid[1], q, to_stream(s));
+      if (rc != AVA_EINVAL) return rc;
+    }
+  }
+  int rc = ava_conv3x3_wgrad_ex(p.x, p.xa, p.xb, p.dy, p.dy2, p.da, p.db, p.dc, p.partials, B, p.Hi, p.Wi, p.Cin, p.Cout,
+                                p.mode, p.dy_pro, act_bf16, s);
+  if (rc != AVA_OK) return rc;
+  return ava_conv3x3_wgrad_ex(q.x, q.xa, q.xb, q.dy, q.dy2, q.da, q.db, q.dc, q.partials, B, q.Hi, q.Wi, q.Cin, q.Cout,
+                              q.mode, q.dy_pro, act_bf16, s);
+}
+
 
 // partial rows ava_conv3x3_wgrad writes for this shape (<= ava_conv_wgrad_grid): the matrix-core kernels launch one
 // resident wave of workgroups, which depends on the kernel's occupancy

@@ -487,8 +487,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(const WgradArgs
   for (int e = t; e < NW + COUT; e += 256) prow[e] = wacc[e];
 }
 
+// the kernel's body as a device function of (workgroup index, workgroups of this layer): conv3x3_wgrad_split_kernel runs it
+// for its whole grid, conv3x3_wgrad_pair_kernel runs two layers' bodies in one launch
 template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH, typename ACT>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int wg, const int nwg) {
   using G = Geom<MODE, TW, TH>;
   constexpr int IR = G::IR, IC = G::IC;
   constexpr int NT = (COUT + 15) / 16;
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArg
   TileStager<COUT, DYPRO, TH, TW, false, 256, float, ACT> sd;      // dy: fp32 gradient, dy2: saved activation
   sx.init();
   sd.init();
-  TileWalk walk(a.ntiles);
+  TileWalk walk(a.ntiles, true, wg, nwg);
   if (walk.valid()) {
     int b, oy0, ox0, gy0, gx0;
     origin(walk.cur, b, oy0, ox0, gy0, gx0);
@@ -611,13 +613,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArg
     }
   }
   __syncthreads();
-  float* prow = a.partials + (size_t)blockIdx.x * (NW + COUT);
+  float* prow = a.partials + (size_t)wg * (NW + COUT);
   for (int e = t; e < NW; e += 256) prow[e] = wacc[e];
   if (t < COUT) prow[NW + t] = (wacc[NW + t] + wacc[NW + COUT + t]) + (wacc[NW + 2 * COUT + t] + wacc[NW + 3 * COUT + t]);
 }
 
 template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH, typename ACT>
-static int launch_wgrad_mfma_t(const WgradArgs& a, int grid, hipStream_t st) {
+__global__ __launch_bounds__(256) void conv3x3_wgrad_split_kernel(const WgradArgs a) {
+  wgrad_split_body<CIN, COUT, MODE, DYPRO, TW, TH, ACT>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two layers' weight-gradient kernels in ONE launch: workgroups [0, grid_a) run layer A's body, the rest layer B's.  The
+// four 16 x 16 layers' weight gradients are independent of the data-gradient chain once their dU exists, and each is a
+// latency-bound launch of one or two tiles per workgroup; issued as pairs (conv7 + conv6, convt2 + convt1) behind both
+// data-gradient kernels they overlap each other.  Every workgroup computes exactly what it computed in its own launch
+// (same tiles, same partial row), so the gradients are bit-identical.
+template <int CA, int OA, int MA, int PA, int TWA, int THA, int CB, int OB, int MB, int PB, int TWB, int THB, typename ACT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_pair_kernel(const WgradArgs a, const WgradArgs b, const int grid_a) {
+  if ((int)blockIdx.x < grid_a) wgrad_split_body<CA, OA, MA, PA, TWA, THA, ACT>(a, (int)blockIdx.x, grid_a);
+  else wgrad_split_body<CB, OB, MB, PB, TWB, THB, ACT>(b, (int)blockIdx.x - grid_a, (int)gridDim.x - grid_a);
+}
+
+// tile geometry, workgroups (= partial rows written) and LDS bytes of one layer's weight-gradient kernel
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH, typename ACT>
+static int wgrad_plan(const WgradArgs& a, int grid, WgradArgs* b, size_t* lds_out) {
   using G = Geom<MODE, TW, TH>;
   // layers with many (tap, cin) rows deal the M tiles out to the waves (fewer registers, no cross-wave reduction)
   constexpr bool SPLIT = CIN >= 24 && COUT > 16;   // measured: 24->24, 24->32, 32->24 gain 10-55 %, 16-channel sides lose
@@ -626,6 +645,26 @@ static int launch_wgrad_mfma_t(const WgradArgs& a, int grid, hipStream_t st) {
   const size_t tiles_f = (size_t)G::IR * G::IC * CIN + TH * TW * COUT + 16 + 192;
   const size_t red_f = (size_t)9 * CIN * COUT + 4 * COUT;
   const size_t lds = (tiles_f > red_f ? tiles_f : red_f) * sizeof(float);
+  *lds_out = lds;
+  *b = a;
+  b->tiles_y = a.Ho / TH;
+  b->tiles_x = a.Wo / TW;
+  b->ntiles = a.B * b->tiles_y * b->tiles_x;
+  if (grid > b->ntiles) grid = b->ntiles;
+  static const int resident = ava_resident_grid(kernel, lds);
+  if (grid > ava_scale_grid(resident)) grid = ava_scale_grid(resident);          // one resident wave of workgroups = partial rows written
+  { const char* e = ava_env("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
+  return grid;
+}
+
+template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH, typename ACT>
+static int launch_wgrad_mfma_t(const WgradArgs& a, int grid, hipStream_t st) {
+  constexpr bool SPLIT = CIN >= 24 && COUT > 16;
+  const auto kernel = SPLIT ? &conv3x3_wgrad_split_kernel<CIN, COUT, MODE, DYPRO, TW, TH, ACT>
+                            : &conv3x3_wgrad_mfma_kernel<CIN, COUT, MODE, DYPRO, TW, TH, ACT>;
+  WgradArgs b;
+  size_t lds;
+  grid = wgrad_plan<CIN, COUT, MODE, DYPRO, TW, TH, ACT>(a, grid, &b, &lds);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -633,18 +672,50 @@ static int launch_wgrad_mfma_t(const WgradArgs& a, int grid, hipStream_t st) {
       return AVA_ELAUNCH;
     attr_set = true;
   }
-  WgradArgs b = a;
-  b.tiles_y = a.Ho / TH;
-  b.tiles_x = a.Wo / TW;
-  b.ntiles = a.B * b.tiles_y * b.tiles_x;
-  if (grid > b.ntiles) grid = b.ntiles;
-  static const int resident = ava_resident_grid(kernel, lds);
-  if (grid > ava_scale_grid(resident)) grid = ava_scale_grid(resident);          // one resident wave of workgroups = partial rows written
-  { const char* e = ava_env("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   if (a.partials == nullptr) return grid;        // row-count query (ava_conv_wgrad_rows)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
+}
+
+// the pair launch: each layer keeps the grid (tile partition, partial rows) of its own launch
+template <int CA, int OA, int MA, int PA, int TWA, int THA, int CB, int OB, int MB, int PB, int TWB, int THB, typename ACT>
+static int launch_wgrad_pair_t(const WgradArgs& a, int grid_a, const WgradArgs& b, int grid_b, hipStream_t st) {
+  static_assert(CA >= 24 && OA > 16 && CB >= 24 && OB > 16, "pairs of split kernels only");
+  const auto kernel = &conv3x3_wgrad_pair_kernel<CA, OA, MA, PA, TWA, THA, CB, OB, MB, PB, TWB, THB, ACT>;
+  WgradArgs pa, pb;
+  size_t lds_a, lds_b;
+  grid_a = wgrad_plan<CA, OA, MA, PA, TWA, THA, ACT>(a, grid_a, &pa, &lds_a);
+  grid_b = wgrad_plan<CB, OB, MB, PB, TWB, THB, ACT>(b, grid_b, &pb, &lds_b);
+  const size_t lds = lds_a > lds_b ? lds_a : lds_b;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return AVA_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid_a + grid_b), dim3(256), lds, st, pa, pb, grid_a);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+int ava_conv3x3_wgrad_mfma_pair(const WgradArgs& a, int grid_a, const WgradCall& ca, const WgradArgs& b, int grid_b,
+                                const WgradCall& cb, hipStream_t st) {
+  auto is = [](const WgradCall& c, const WgradArgs& w, int ci, int co, int md, int pro, int tw, int th) {
+    return c.Cin == ci && c.Cout == co && c.mode == md && c.dy_pro == pro && w.Wo % tw == 0 && w.Ho % th == 0;
+  };
+  // encoder: conv7 (24 -> 32, given dU) + conv6 (24 -> 24, stride 2)
+  if (is(ca, a, 24, 32, MODE_S1, PRO_ID, 16, 8) && is(cb, b, 24, 24, MODE_DOWN, PRO_BWD, 16, 4)) {
+    if (a.act_bf16) return launch_wgrad_pair_t<24, 32, MODE_S1, PRO_ID, 16, 8, 24, 24, MODE_DOWN, PRO_BWD, 16, 4, ava_bf16>(a, grid_a, b, grid_b, st);
+    return launch_wgrad_pair_t<24, 32, MODE_S1, PRO_ID, 16, 8, 24, 24, MODE_DOWN, PRO_BWD, 16, 4, float>(a, grid_a, b, grid_b, st);
+  }
+  // decoder: convt2 (24 -> 24, x2) + convt1 (32 -> 24)
+  if (is(ca, a, 24, 24, MODE_UP, PRO_BWD, 32, 8) && is(cb, b, 32, 24, MODE_S1, PRO_BWD, 16, 8)) {
+    if (a.act_bf16) return launch_wgrad_pair_t<24, 24, MODE_UP, PRO_BWD, 32, 8, 32, 24, MODE_S1, PRO_BWD, 16, 8, ava_bf16>(a, grid_a, b, grid_b, st);
+    return launch_wgrad_pair_t<24, 24, MODE_UP, PRO_BWD, 32, 8, 32, 24, MODE_S1, PRO_BWD, 16, 8, float>(a, grid_a, b, grid_b, st);
+  }
+  return AVA_EINVAL;
 }
 
 template <int CIN, int COUT, int MODE, int DYPRO, int TW, int TH>

@@ -222,15 +222,17 @@ struct LimbItem { int m0, n0, split, kbeg, kend, bx; };
 // RING: operand tiles the staging waves keep in registers (loads RING - 1 steps ahead).  MINW: waves per SIMD the
 // register allocation must allow (4 = two 512-thread workgroups per CU: the staging waves of one workgroup then run
 // beside the matrix-core waves of the other, which matters because a staging wave alone is stalled half of the time).
-template <int BN, bool A_KMAJ, bool B_KMAJ, int RING, int MINW>
-__global__ __launch_bounds__(512, MINW) void gemm_limb_kernel(const GemmArgs g, const int tiles_m, const int tiles_n,
-                                                              const int nitems) {
-  constexpr int BM = 128, T = 256, WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+// NSW: staging waves (4, or 8: the split is the long pole of a K step, section 3 item 17 of DESIGN.md -- two staging waves
+// per SIMD share it beside one matrix-core wave); the workgroup has NSW + 4 waves.
+template <int BN, bool A_KMAJ, bool B_KMAJ, int RING, int MINW, int NSW = 4>
+__global__ __launch_bounds__(64 * (NSW + 4), MINW) void gemm_limb_kernel(const GemmArgs g, const int tiles_m, const int tiles_n,
+                                                                          const int nitems) {
+  constexpr int BM = 128, T = 64 * NSW, WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int A_BYTES = 3 * BM * 64, B_BYTES = 3 * BN * 64, BUF = A_BYTES + B_BYTES;
   __shared__ __align__(16) unsigned char smem[2 * BUF];
 
   const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
-  const bool stager = wave8 < 4;
+  const bool stager = wave8 < NSW;
   // item list: workgroups on one XCD (workgroup index mod 8) take a contiguous eighth of the list, so that items which
   // share an operand panel share an L2 (speed only)
   int it, it_end, it_step;
@@ -294,16 +296,15 @@ __global__ __launch_bounds__(512, MINW) void gemm_limb_kernel(const GemmArgs g, 
             const bool fin = g.splits == 1;
 #pragma unroll
             for (int i = 0; i < LimbLoaderN<BM, T, RING>::NU; ++i) {
-              static_assert(LimbLoaderN<BM, T, RING>::KQ == 8, "the shuffle tree below sums the 8 k-quads of a column quad");
-              const int u = t + T * i, cq = u >> 3;
+              constexpr int KQA = LimbLoaderN<BM, T, RING>::KQ;      // threads (consecutive lanes) that own the same 4 columns
+              const int u = t + T * i, cq = u / KQA;
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
-                float v = la.cs[i][c];     // the 8 threads (kq = lane & 7) that own the same 4 columns, fixed order
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
+                float v = la.cs[i][c];     // the KQA threads that own the same 4 columns, fixed order
+#pragma unroll
+                for (int o = 1; o < KQA; o <<= 1) v += __shfl_xor(v, o, 64);
                 const int gm = si.m0 + 4 * cq + c;
-                if ((u & 7) == 0 && u < LimbLoaderN<BM, T, RING>::UNITS && gm < g.M) {
+                if ((u % KQA) == 0 && u < LimbLoaderN<BM, T, RING>::UNITS && gm < g.M) {
                   if (fin) g.colsum[gm] = v;
                   else g.C[(size_t)g.splits * g.M * g.N + (size_t)si.split * g.M + gm] = v;   // partial, behind the slabs
                 }
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_limb_kernel(const GemmArgs g, 
   }
 
   // -------------------------------------------------- matrix-core waves --------------------------------------------------
-  const int wave = wave8 & 3, wm = wave >> 1, wn = wave & 1;
+  const int wave = wave8 - NSW, wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, kg = lane >> 4;
   const int a_lane = (wm * WM) * 64 + pos16<!A_KMAJ>(fr) * 64 + chunk_of<!A_KMAJ>(fr, kg) * 16;
   const int b_lane = A_BYTES + (wn * WN) * 64 + pos16<!B_KMAJ>(fr) * 64 + chunk_of<!B_KMAJ>(fr, kg) * 16;
@@ -491,12 +492,13 @@ void ava_gemm_limb_plan(int M, int N, int K, int a_kmajor, int* bn, int* splits,
   *bn = b; *splits = s; *klen = kl;
 }
 
-template <int BN, int RING, int MINW>
+template <int BN, int RING, int MINW, int NSW = 4>
 static void launch_limb(const GemmArgs& g, int a_k, int b_k, int tm, int tn, int nitems, int grid, hipStream_t st) {
-  if (a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, true, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
-  else if (a_k && !b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, false, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
-  else if (!a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, false, true, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
-  else hipLaunchKernelGGL((gemm_limb_kernel<BN, false, false, RING, MINW>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
+  const dim3 blk(64 * (NSW + 4));
+  if (a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, true, RING, MINW, NSW>), dim3(grid), blk, 0, st, g, tm, tn, nitems);
+  else if (a_k && !b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, true, false, RING, MINW, NSW>), dim3(grid), blk, 0, st, g, tm, tn, nitems);
+  else if (!a_k && b_k) hipLaunchKernelGGL((gemm_limb_kernel<BN, false, true, RING, MINW, NSW>), dim3(grid), blk, 0, st, g, tm, tn, nitems);
+  else hipLaunchKernelGGL((gemm_limb_kernel<BN, false, false, RING, MINW, NSW>), dim3(grid), blk, 0, st, g, tm, tn, nitems);
 }
 
 int ava_gemm_limb_launch(const GemmArgs& g0, int a_kmajor, int b_kmajor, int bn, hipStream_t st) {
@@ -513,6 +515,10 @@ int ava_gemm_limb_launch(const GemmArgs& g0, int a_kmajor, int b_kmajor, int bn,
   const int resident = ava_scale_grid((bn == 64 ? 2 : 1) * cus);     // persistent workgroups: one resident wave of them
   int grid = nitems < resident ? nitems : resident;
   { const char* e = ava_env("AVA_GEMM_LIMB_GRID"); if (e) { grid = atoi(e); if (grid > nitems) grid = nitems; if (grid < 1) grid = 1; } }
+#ifdef AVA_LAB
+  { static const int nsw = [] { const char* e = ava_env("AVA_GEMM_LIMB_NSW"); return e ? atoi(e) : 4; }();
+    if (nsw == 8 && bn == 128) { launch_limb<128, 4, 3, 8>(g, a_kmajor, b_kmajor, tm, tn, nitems, grid, st); AVA_CHECK_LAUNCH(); return AVA_OK; } }
+#endif
   if (bn == 64 && a_kmajor) {
     if (b_kmajor) hipLaunchKernelGGL((gemm_limb_kernel<64, true, true, 3, 4>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);
     else hipLaunchKernelGGL((gemm_limb_kernel<64, true, false, 3, 4>), dim3(grid), dim3(512), 0, st, g, tm, tn, nitems);

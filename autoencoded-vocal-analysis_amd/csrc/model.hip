@@ -912,9 +912,13 @@ static bool dd6_fused(const ava_model* m) {
   return on && fused_grid(m, 12, m->lastB > 0 ? m->lastB : 1) > 0 && m->lay[12].wi % 32 == 0 && m->lay[12].hi % 4 == 0;
 }
 
+int ava_conv3x3_wgrad_pair(const WgradCall& p, const WgradCall& q, int B, int act_bf16, ava_stream_t s);
+
+// `defer`: a layer without a fused kernel records its weight-gradient call there instead of launching it (the caller
+// issues two layers' calls as one pair launch; gin / gin2 must stay valid until then)
 static int conv_layer_backward(ava_model* m, int l, const float* x0, const float* gin, const float* gin2,
                                const float* ca, const float* cb, const float* cc, int pro, float* gout, int B,
-                               hipStream_t st) {
+                               hipStream_t st, WgradCall* defer = nullptr) {
   const ConvLayer& L = kLayers[l];
   const LayerDims& D = m->lay[l];
   const float* X = l == 0 ? x0 : m->X[l];
@@ -959,6 +963,10 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   mark(m, CAT_CONV_BWD_DATA, st);
   if (acc.acc_out == nullptr) TRY(finalize_bwd(m, l, ava_conv_grid(B, D.hi, D.wi, bmode), (int64_t)B * D.hi * D.wi, st));
   // weight + bias gradient (forward gather form), reduced into the reference layout inside the grad arena
+  if (defer != nullptr) {
+    *defer = WgradCall{X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], D.hi, D.wi, L.cin, L.cout, L.mode, pro};
+    return AVA_OK;
+  }
   TRY(ava_conv3x3_wgrad_ex(X, bn_scale(m, l), bn_shift(m, l), gin, gin2, ca, cb, cc, m->wg_part[l], B, D.hi, D.wi, L.cin,
                            L.cout, L.mode, pro, m->act_bf16, st));
   mark(m, CAT_CONV_WGRAD, st);
@@ -1031,6 +1039,9 @@ extern "C" int ava_backward_part(ava_model* m, const float* x, int B, int part, 
   return part == 1 ? backward_part1(m, x, B, to_stream(s)) : backward_part2(m, x, B, to_stream(s), false);
 }
 
+// offset (floats) of the upper half of a gradient ping-pong buffer (B * H * W * 8 floats each, model workspace)
+static size_t grad_half(const ava_model* m, int B) { return (size_t)B * m->H * m->W * 4; }
+
 static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, bool whole) {
   // ---- decoder convolutions, last to first ----
   float* gcur = m->gA;
@@ -1041,11 +1052,20 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
     mark(m, CAT_LAYOUT, st);
   }
   TRY(conv_layer_backward(m, 13, x, m->seed, nullptr, nullptr, nullptr, nullptr, PRO_ID, gcur, B, st));
+  const bool pair = fused_grid(m, 8, B) == 0 && fused_grid(m, 7, B) == 0;
+  WgradCall wc[2];
   for (int l = 12; l >= 7; --l) {
     // dU_l = (X_{l+1} > 0) ? A*g + Bc*X_{l+1} + Cc : 0 with the coefficients of BatchNorm l+1
-    TRY(conv_layer_backward(m, l, x, gcur, m->X[l + 1], bn_A(m, l + 1), bn_B(m, l + 1), bn_C(m, l + 1), PRO_BWD, gnext,
-                            B, st));
-    float* t = gcur; gcur = gnext; gnext = t;
+    // convt2 + convt1 (16 x 16, no fused kernel): both data gradients first, then the two weight gradients as ONE launch.
+    // convt1's data gradient goes to the upper half of the buffer that still holds convt2's dU (both are small)
+    float* gout = (pair && l == 7) ? gnext + grad_half(m, B) : gnext;
+    TRY(conv_layer_backward(m, l, x, gcur, m->X[l + 1], bn_A(m, l + 1), bn_B(m, l + 1), bn_C(m, l + 1), PRO_BWD, gout,
+                            B, st, pair && l <= 8 ? &wc[8 - l] : nullptr));
+    gnext = gcur; gcur = gout;
+  }
+  if (pair) {
+    TRY(ava_conv3x3_wgrad_pair(wc[0], wc[1], B, m->act_bf16, reinterpret_cast<ava_stream_t>(st)));
+    mark(m, CAT_CONV_WGRAD, st);
   }
   // gcur = dXhat_8 (NHWC [B,256,32]); through bn8 and fc8's ReLU back to NCHW-flatten
   const BnFin fin8 = acc_pair_bwd(m, 7) ? fin_bwd(m, 7, B) : fin_none();      // bn8: finalised inside the layout kernel
@@ -1101,12 +1121,24 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, b
   if (recomp_y1()) TRY(materialize_y1(m, x, B, st));       // TEMPORARY: until conv2's / conv1's backward recompute y1 themselves
   TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, m->P8, st));             // dU_7 (ReLU of conv7)
   mark(m, CAT_LAYOUT, st);
-  TRY(conv_layer_backward(m, 6, x, gcur, nullptr, nullptr, nullptr, nullptr, PRO_ID, gnext, B, st));
+  // conv7 + conv6 (16 x 16, no fused kernel): both data gradients first, then the two weight gradients as ONE launch
+  const bool pair = fused_grid(m, 6, B) == 0 && fused_grid(m, 5, B) == 0;
+  WgradCall wc[2];
+  TRY(conv_layer_backward(m, 6, x, gcur, nullptr, nullptr, nullptr, nullptr, PRO_ID, gnext, B, st, pair ? &wc[0] : nullptr));
   { float* t = gcur; gcur = gnext; gnext = t; }
+  bool upper = false;
   for (int l = 5; l >= 0; --l) {
-    TRY(conv_layer_backward(m, l, x, gcur, m->X[l + 1], bn_A(m, l + 1), bn_B(m, l + 1), bn_C(m, l + 1), PRO_BWD,
-                            l == 0 ? nullptr : gnext, B, st));
-    float* t = gcur; gcur = gnext; gnext = t;
+    // conv6's data gradient goes to the upper half of the buffer that still holds conv7's dU (both are small)
+    float* gout = l == 0 ? nullptr : ((pair && l == 5) ? gnext + grad_half(m, B) : gnext);
+    TRY(conv_layer_backward(m, l, x, gcur, m->X[l + 1], bn_A(m, l + 1), bn_B(m, l + 1), bn_C(m, l + 1), PRO_BWD, gout, B, st,
+                            pair && l == 5 ? &wc[1] : nullptr));
+    if (pair && l == 5) {
+      TRY(ava_conv3x3_wgrad_pair(wc[0], wc[1], B, m->act_bf16, reinterpret_cast<ava_stream_t>(st)));
+      mark(m, CAT_CONV_WGRAD, st);
+    }
+    float* freed = upper ? gcur - grad_half(m, B) : gcur;      // an upper half read by this layer: the whole buffer is free again
+    gcur = gout; gnext = freed;
+    upper = pair && l == 5;
   }
   m->bwd_scale = nullptr;              // consumed
   return reduce_wgrads(m, whole ? 0 : 0, whole ? NCONV : 7, B, st);      // encoder (whole: all 14) weight/bias gradients

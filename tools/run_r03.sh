@@ -57,6 +57,22 @@ case $pass in
     python3 bench.py --height 256 --width 256 --z-dim 128 --per-gpu-batch 64 --global-batch 0 --steps 50 --dtype bf16 --no-cpu-baseline --no-loader-path > $out/bench_256x256_z128_B64_bf16act.json 2> $out/bench_256_bf16.err
     tail -c 400 $out/bench_final.json
     ;;
+  pair)
+    # the paired weight-gradient launch of the 16 x 16 layers: bit-identity against separate launches, tests, step time
+    for B in 8 256; do
+      AB_B=$B AVA_HIP_LIB_TAG=lab AVA_WGRAD_PAIR=0 timeout 300 python tools/ab_grads.py dump /tmp/a$B.npz > /dev/null 2>&1
+      AB_B=$B AVA_HIP_LIB_TAG=lab AVA_WGRAD_PAIR=1 timeout 300 python tools/ab_grads.py dump /tmp/b$B.npz > /dev/null 2>&1
+      AB_B=$B timeout 300 python tools/ab_grads.py dump /tmp/c$B.npz > /dev/null 2>&1
+      echo "B=$B lab pair off vs on" >> $out/ab.log; python tools/ab_grads.py diff /tmp/a$B.npz /tmp/b$B.npz 2>&1 | head -n 4 >> $out/ab.log
+      echo "B=$B lab pair off vs product" >> $out/ab.log; python tools/ab_grads.py diff /tmp/a$B.npz /tmp/c$B.npz 2>&1 | head -n 4 >> $out/ab.log
+    done
+    cat $out/ab.log
+    timeout 1500 python -m pytest tests/test_gpu_step.py tests/test_gpu_graph.py tests/test_gpu_callers.py tests/test_gpu_autograd_semantics.py -x -q > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
+    timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-loader-path > $out/bench.json 2> $out/bench.err
+    AVA_HIP_LIB_TAG=lab AVA_WGRAD_PAIR=0 timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-loader-path > $out/bench_lab_off.json 2> $out/bench_lab_off.err
+    AVA_HIP_LIB_TAG=lab AVA_WGRAD_PAIR=1 timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-loader-path > $out/bench_lab_on.json 2> $out/bench_lab_on.err
+    grep -o '"ms_per_step": [0-9.]*' $out/bench.json $out/bench_lab_off.json $out/bench_lab_on.json
+    ;;
   gemmabl)
     timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k gemm > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
     for d in 0 1 2 4 8 3 6 7 15; do

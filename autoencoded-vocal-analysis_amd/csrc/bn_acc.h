@@ -58,70 +58,86 @@ __device__ __forceinline__ void bn_acc_add(long long* slot, int idx, float p) {
   if (l2 != 0.0) atomicAdd(reinterpret_cast<unsigned long long*>(a + 128 + idx), (unsigned long long)(sg * (long long)l2));
 }
 
-// consumer: value `idx` of the slot (fixed shard order: deterministic); NaN when the slot is poisoned
+// consumer: value `idx` of the slot (fixed shard order: deterministic); NaN when the slot is poisoned.
+// Plain loads: the counters were written by atomics of the PREVIOUS kernel, and a kernel boundary makes every earlier write
+// visible; the 32 lines of a slot are then served by the XCD's L2 to all but the first workgroup that asks (agent-scope
+// atomic loads took every workgroup's request to the memory side).
 __device__ __forceinline__ double bn_acc_read(const long long* slot, int idx) {
-  double s = 0.0;
+  long long v0[AVA_ACC_SHARDS], v1[AVA_ACC_SHARDS], v2[AVA_ACC_SHARDS];
   unsigned long long bad = 0;
 #pragma unroll
   for (int sh = 0; sh < AVA_ACC_SHARDS; ++sh) {
     const long long* a = slot + (size_t)sh * AVA_ACC_SHARD_LL;
-    // relaxed agent-scope loads: the counters were written by atomics of the PREVIOUS kernel (memory side)
-    const long long v0 = __hip_atomic_load(a + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long v1 = __hip_atomic_load(a + 64 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long v2 = __hip_atomic_load(a + 128 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bad |= (unsigned long long)__hip_atomic_load(a + 192, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s += ((double)v0 + (double)v1 * 0x1p32 + (double)v2 * 0x1p64) * 0x1p-48;
+    v0[sh] = a[idx]; v1[sh] = a[64 + idx]; v2[sh] = a[128 + idx];
+    bad |= (unsigned long long)a[192];
   }
+  double s = 0.0;
+#pragma unroll
+  for (int sh = 0; sh < AVA_ACC_SHARDS; ++sh) s += ((double)v0[sh] + (double)v1[sh] * 0x1p32 + (double)v2[sh] * 0x1p64) * 0x1p-48;
   return bad ? __builtin_nan("") : s;
 }
 
-// Consumer prologue, called by ALL threads of the workgroup (>= 64 threads; contains barriers): fills coef[3][32]
+// Consumer prologue, called by ALL threads of the workgroup (>= 64 threads; contains a barrier): fills coef[3][32]
 // (LDS) with {scale, shift, 0} (forward) or {A, Bc, Cc} (backward), zero beyond C, exactly as bn_finalize_kernel /
 // bn_finalize_bwd_kernel compute them; workgroup 0 also publishes what later kernels read from global memory.
-// `vals`: 64 doubles of LDS scratch.  Threads t0 .. t0+63 read the counters (pick a wave with nothing slow in flight:
-// a wave's loads return in order, so reads queued behind a tile prefetch would wait for it), t0 .. t0+31 finalise.
+// The wave of threads t0 .. t0+63 does the work (pick a wave with nothing slow in flight: a wave's loads return in order,
+// so reads queued behind a tile prefetch would wait for it): its 64 lanes read the 64 values, lanes 0..31 finalise with
+// the upper half's value handed over by a shuffle.  The per-channel parameters are requested BEFORE the counters, so the
+// chain is one memory latency long.  `vals` is unused (kept for the callers' scratch declarations).
 __device__ __forceinline__ void bn_coef_from_acc(float* coef, double* vals, const BnFin& f, int t0 = 0) {
+  (void)vals;
   const int t = (int)threadIdx.x - t0;
-  if (t >= 0 && t < 64) vals[t] = ((t & 31) < f.C) ? bn_acc_read(f.acc, t) : 0.0;
-  __syncthreads();
-  if (t >= 0 && t < 32) {
-    const int c = t;
-    float k0 = 0.f, k1 = 0.f, k2 = 0.f;
-    if (c < f.C) {
-      const bool pub = blockIdx.x == 0;
+  if (t >= 0 && t < 64) {
+    const int c = t & 31;
+    const bool live = c < f.C, lo = t < 32;
+    const bool pub = blockIdx.x == 0;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, r0 = 0.f, r1 = 0.f;
+    if (live && lo) {
+      p0 = f.gamma[c];
       if (!f.backward) {
-        const double mean = vals[c] / f.n;
-        double var = vals[32 + c] / f.n - mean * mean;          // biased variance
-        if (var < 0.0) var = 0.0;
-        const float meanf = (float)mean;
-        const float invstd = (float)(1.0 / sqrt(var + AVA_BN_EPS_D));
-        const float sc = f.gamma[c] * invstd;
-        k0 = sc;
-        k1 = f.beta[c] - meanf * sc;
-        if (pub) {
-          f.save[c] = meanf; f.save[32 + c] = invstd; f.save[64 + c] = k0; f.save[96 + c] = k1;
-          if (f.running_mean != nullptr) {
-            const double unb = f.n > 1.0 ? var * (f.n / (f.n - 1.0)) : var;
-            f.running_mean[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)f.running_mean[c] + AVA_BN_MOM_D * mean);
-            f.running_var[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)f.running_var[c] + AVA_BN_MOM_D * unb);
+        p1 = f.beta[c];
+        if (pub && f.running_mean != nullptr) { r0 = f.running_mean[c]; r1 = f.running_var[c]; }
+      } else { p1 = f.invstd[c]; p2 = f.mean[c]; }
+    }
+    const double mine = live ? bn_acc_read(f.acc, t) : 0.0;
+    const double upper = __shfl(mine, c + 32, 64);          // value 32 + c
+    if (lo) {
+      float k0 = 0.f, k1 = 0.f, k2 = 0.f;
+      if (live) {
+        if (!f.backward) {
+          const double mean = mine / f.n;
+          double var = upper / f.n - mean * mean;          // biased variance
+          if (var < 0.0) var = 0.0;
+          const float meanf = (float)mean;
+          const float invstd = (float)(1.0 / sqrt(var + AVA_BN_EPS_D));
+          const float sc = p0 * invstd;
+          k0 = sc;
+          k1 = p1 - meanf * sc;
+          if (pub) {
+            f.save[c] = meanf; f.save[32 + c] = invstd; f.save[64 + c] = k0; f.save[96 + c] = k1;
+            if (f.running_mean != nullptr) {
+              const double unb = f.n > 1.0 ? var * (f.n / (f.n - 1.0)) : var;
+              f.running_mean[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)r0 + AVA_BN_MOM_D * mean);
+              f.running_var[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)r1 + AVA_BN_MOM_D * unb);
+            }
+          }
+        } else {
+          const double dB = mine, dG = upper;
+          const double is = (double)p1, gm = (double)p0, mu = (double)p2;
+          const double a = gm * is;
+          const double b = f.eval ? 0.0 : -gm * is * is * dG / f.n;
+          k0 = (float)a;
+          k1 = (float)b;
+          k2 = f.eval ? 0.f : (float)(-a * dB / f.n - b * mu);
+          if (pub) {
+            f.dgamma[c] = (float)dG; f.dbeta[c] = (float)dB;
+            f.abc[c] = k0; f.abc[32 + c] = k1; f.abc[64 + c] = k2;
           }
         }
-      } else {
-        const double dB = vals[c], dG = vals[32 + c];
-        const double is = (double)f.invstd[c], gm = (double)f.gamma[c], mu = (double)f.mean[c];
-        const double a = gm * is;
-        const double b = f.eval ? 0.0 : -gm * is * is * dG / f.n;
-        k0 = (float)a;
-        k1 = (float)b;
-        k2 = f.eval ? 0.f : (float)(-a * dB / f.n - b * mu);
-        if (pub) {
-          f.dgamma[c] = (float)dG; f.dbeta[c] = (float)dB;
-          f.abc[c] = k0; f.abc[32 + c] = k1; f.abc[64 + c] = k2;
-        }
       }
+      coef[c] = k0; coef[32 + c] = k1; coef[64 + c] = k2;
+      if (c == 0 && pub && !f.backward && f.num_batches != nullptr) *f.num_batches += 1;
     }
-    coef[c] = k0; coef[32 + c] = k1; coef[64 + c] = k2;
-    if (c == 0 && blockIdx.x == 0 && !f.backward && f.num_batches != nullptr) *f.num_batches += 1;
   }
   __syncthreads();
 }

@@ -23,6 +23,14 @@
 // callers' second-epoch loss at 4.9x the reference's own run-to-run noise against an allowance of 4x).  The mask-imposed
 // fp64-oracle gradient tests pass for all of them.
 // Lab build: AVA_CONV_LIMB=0 (off), 1 (this table), 2 (every shape with CIN % 8 == 0), 3-9 (the other sets measured).
+// lab build: phase ablation of the wave-specialised kernel (AVA_DBG bits: 1 no MFMA, 2 no prologue / limb split / LDS write,
+// 4 no global loads, 8 no output stores); timing only
+#ifdef AVA_LAB
+#define AVA_ABL(bit) ((a.dbg & (bit)) != 0)
+#else
+#define AVA_ABL(bit) false
+#endif
+
 static bool conv_limb_on(int Cin, int Cout, int mode, int pro) {
   static const int sel = [] { const char* e = ava_env("AVA_CONV_LIMB"); return e ? atoi(e) : 1; }();
   if (sel == 0) return false;
@@ -84,6 +92,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
                             typename std::conditional<LIMB, TileStagerL<CIN, PRO, IR, IC, 256, TIN, ACT>,
                                                       TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT>>::type>::type stg;   // staging waves only (threadIdx.x 0..255)
   auto stg_store = [&](float* tile) __attribute__((always_inline)) {
+    if (AVA_ABL(2)) return;
     if constexpr (RECOMP) stg.store(tile, coef, xs);
     else if constexpr (LIMB) stg.store(reinterpret_cast<unsigned char*>(tile), coef);
     else stg.store(tile, coef);
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     if (HOIST && walk.valid()) {                                // tile 0 goes in flight BEFORE the coefficient prologue
       int b, oy0, ox0, gy0, gx0;
       origin(walk.cur, b, oy0, ox0, gy0, gx0);
-      stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+      if (!AVA_ABL(4)) stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
     }
   }
   if (a.fin.acc != nullptr) {
@@ -120,12 +129,12 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     if (walk.valid()) {
       if (!HOIST) {
         origin(walk.cur, b, oy0, ox0, gy0, gx0);
-        stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+        if (!AVA_ABL(4)) stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
       }
       stg_store(tile0);                                         // tile 0 -> buffer 0
       if (walk.has_next()) {
         origin(walk.next(), b, oy0, ox0, gy0, gx0);
-        stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);         // tile 1 in flight
+        if (!AVA_ABL(4)) stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);         // tile 1 in flight
       }
     }
     __syncthreads();                                            // (A) tile 0 ready
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         const int nn = walk.next() + walk.step;
         if (nn < walk.end) {
           origin(nn, b, oy0, ox0, gy0, gx0);
-          stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+          if (!AVA_ABL(4)) stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
         }
       }
       __syncthreads();                                          // (B) tile it consumed, tile it+1 ready
@@ -230,7 +239,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (MODE == MODE_UP) {
+      if (AVA_ABL(1)) {
+      } else if (MODE == MODE_UP) {
         const int cls = gi & 3, r = g >> 2;
         const auto px = pxp(tile, r * IC);
         if (cls == 0) f0.run(px, acc);
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
               s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);      // raw x: centred after the loop
             }
           }
-          if (obase != nullptr) ava_st4<TOUT>(obase + gout + 16 * (mtb + mt), avaf4{v[0], v[1], v[2], v[3]});
+          if (obase != nullptr && !AVA_ABL(8)) ava_st4<TOUT>(obase + gout + 16 * (mtb + mt), avaf4{v[0], v[1], v[2], v[3]});
         }
       }
     }

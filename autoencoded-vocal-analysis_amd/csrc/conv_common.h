@@ -184,40 +184,95 @@ struct TileStager {
   // masked at store time).  The loads are asynchronous (see ava_load_f4_async).
   __device__ __forceinline__ void load(const float* __restrict__ in, const float* __restrict__ in2, int b, int Hi,
                                        int Wi, int gy0, int gx0) {
-    inb = 0u;
+    unsigned nb = 0u;
     const TIN* __restrict__ base = ava_as<TIN>(in) + (size_t)b * Hi * Wi * CIN;
     const TIN2* __restrict__ base2 = PRO == PRO_BWD ? ava_as<TIN2>(in2) + (size_t)b * Hi * Wi * CIN : nullptr;
 #pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-      const int gy = gy0 + (rc[i] >> 16), gx = gx0 + (rc[i] & 0xffff);
-      const bool ok = ((live >> i) & 1u) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
-      const int cy = min(max(gy, 0), Hi - 1), cx = min(max(gx, 0), Wi - 1);
-      const int off = (cy * Wi + cx) * CIN + q4[i];
-      v[i] = ava_ld4<TIN>(base + off);
-      if (PRO == PRO_BWD) v2[i] = ava_ld4<TIN2>(base2 + off);
-      inb |= ok ? (1u << i) : 0u;
+    for (int i = 0; i < NPF; ++i) load_one(i, base, base2, Hi, Wi, gy0, gx0, nb);
+    inb = nb;
+  }
+
+  // element i of the tile at (b, gy0, gx0) into register i; its inside-the-image bit into `nb`
+  __device__ __forceinline__ void load_one(int i, const TIN* __restrict__ base, const TIN2* __restrict__ base2, int Hi, int Wi,
+                                           int gy0, int gx0, unsigned& nb) {
+    const int gy = gy0 + (rc[i] >> 16), gx = gx0 + (rc[i] & 0xffff);
+    const bool ok = ((live >> i) & 1u) && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+    const int cy = min(max(gy, 0), Hi - 1), cx = min(max(gx, 0), Wi - 1);
+    const int off = (cy * Wi + cx) * CIN + q4[i];
+    v[i] = ava_ld4<TIN>(base + off);
+    if (PRO == PRO_BWD) v2[i] = ava_ld4<TIN2>(base2 + off);
+    nb |= ok ? (1u << i) : 0u;
+  }
+
+  // Prologue coefficients of element i's channel quad, read from LDS as vectors and UNCONDITIONALLY: written as
+  // `ok ? prologue(x, coef[..]) : 0` the compiler may not speculate the LDS reads and emits, per element, four exec-masked
+  // blocks of { ds_read2_b32; s_waitcnt lgkmcnt(0); fma } -- four serialised LDS round trips (measured: 1.9 us of a
+  // 2.9 us tile step of conv4's forward).  SAMEQ: NT is a multiple of the quads per pixel, so every element of a thread
+  // has the same quad and the three vectors are fetched once per call (kq) instead of once per element.
+  static constexpr bool SAMEQ = NT % Q == 0;
+  struct Coef { avaf4 a, b, c; };
+  __device__ __forceinline__ Coef coef_of(int i, const float* __restrict__ coef) const {
+    Coef k;
+    const float* ca = coef + q4[i];
+    k.a = k.b = k.c = avaf4{0.f, 0.f, 0.f, 0.f};
+    if (PRO != PRO_ID) {
+      k.a = avaf4{ca[0], ca[1], ca[2], ca[3]};
+      k.b = avaf4{ca[32], ca[33], ca[34], ca[35]};
     }
+    if (PRO == PRO_BWD) k.c = avaf4{ca[64], ca[65], ca[66], ca[67]};
+    return k;
+  }
+  // prologue of element i (zero outside the image)
+  __device__ __forceinline__ avaf4 value_one(int i, const Coef& k) const {
+    const avaf4 x = v[i];
+    const avaf4 y = PRO == PRO_BWD ? v2[i] : x;
+    const bool ok = (inb >> i) & 1u;
+    avaf4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = prologue<PRO>(x[e], y[e], k.a[e], k.b[e], k.c[e]);
+      o[e] = ok ? p : 0.f;
+    }
+    return o;
+  }
+
+  __device__ __forceinline__ void store_one(int i, float* __restrict__ lds, const float* __restrict__ coef, const Coef& kq) {
+    const int idx = tid + NT * i;
+    const avaf4 o = SAMEQ ? value_one(i, kq) : value_one(i, coef_of(i, coef));
+    // PLANES: channel quad q of every pixel in its own [R*C][4] plane, so lanes that walk along x read 16-byte
+    // slots 16 bytes apart (conflict-free ds_read_b128) instead of CIN*4 bytes apart
+    const int dst = PLANES ? ((idx % Q) * (R * C) + idx / Q) : idx;
+    if ((live >> i) & 1u) *reinterpret_cast<avaf4*>(lds + 4 * dst) = o;
   }
 
   // wait for the loads, apply the prologue, write LDS
   __device__ __forceinline__ void store(float* __restrict__ lds, const float* __restrict__ coef) {
     ava_wait_vm0(v);
     if (PRO == PRO_BWD) ava_wait_vm0(v2);
+    const Coef kq = coef_of(0, coef);
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) store_one(i, lds, coef, kq);
+  }
+
+  // store() of the tile in the registers and load() of the tile at (b, gy0, gx0), register by register: element i of the
+  // next tile is requested as soon as element i of this one has been converted, so the next tile's loads travel under
+  // this tile's conversion (a wave's loads return in order: the wait in front of element i leaves the NPF - 1 younger
+  // requests in flight).  With store() followed by load() the whole tile was requested only after the whole conversion
+  // and the staging waves -- which have nothing else to do -- sat out its full latency (measured additive: DESIGN.md 3).
+  __device__ __forceinline__ void store_load(float* __restrict__ lds, const float* __restrict__ coef,
+                                             const float* __restrict__ in, const float* __restrict__ in2, int b, int Hi,
+                                             int Wi, int gy0, int gx0) {
+    unsigned nb = 0u;
+    const TIN* __restrict__ base = ava_as<TIN>(in) + (size_t)b * Hi * Wi * CIN;
+    const TIN2* __restrict__ base2 = PRO == PRO_BWD ? ava_as<TIN2>(in2) + (size_t)b * Hi * Wi * CIN : nullptr;
+    const Coef kq = coef_of(0, coef);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int idx = tid + NT * i;
-      const float* ca = coef + q4[i];
-      const avaf4 x = v[i];
-      const avaf4 y = PRO == PRO_BWD ? v2[i] : x;
-      const bool ok = (inb >> i) & 1u;
-      avaf4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = ok ? prologue<PRO>(x[e], y[e], ca[e], ca[32 + e], ca[64 + e]) : 0.f;
-      // PLANES: channel quad q of every pixel in its own [R*C][4] plane, so lanes that walk along x read 16-byte
-      // slots 16 bytes apart (conflict-free ds_read_b128) instead of CIN*4 bytes apart
-      const int dst = PLANES ? ((idx % Q) * (R * C) + idx / Q) : idx;
-      if ((live >> i) & 1u) *reinterpret_cast<avaf4*>(lds + 4 * dst) = o;
+      store_one(i, lds, coef, kq);
+      load_one(i, base, base2, Hi, Wi, gy0, gx0, nb);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    inb = nb;
   }
 };
 
@@ -253,29 +308,42 @@ struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2> {
   static constexpr int NPIX = R * C, Q8 = CIN / 8;
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
   static constexpr int TILE_BYTES = 3 * PLANE_BYTES;
+  using Coef = typename Base::Coef;
+  __device__ __forceinline__ void store_one(int i, unsigned char* __restrict__ lds, const float* __restrict__ coef, const Coef& kq) {
+    const int idx = this->tid + NT * i;
+    const avaf4 o = Base::SAMEQ ? this->value_one(i, kq) : this->value_one(i, this->coef_of(i, coef));
+    ava_u32x2 p0, p1, p2;
+    uint32_t a, b, c;
+    ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
+    ava_limb_split2(o[2], o[3], a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
+    const int q = idx % Base::Q, pix = idx / Base::Q;
+    unsigned char* d = lds + ((q >> 1) * NPIX + pix) * 16 + (q & 1) * 8;
+    if ((this->live >> i) & 1u) {
+      *reinterpret_cast<ava_u32x2*>(d) = p0;
+      *reinterpret_cast<ava_u32x2*>(d + PLANE_BYTES) = p1;
+      *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
+    }
+  }
   __device__ __forceinline__ void store(unsigned char* __restrict__ lds, const float* __restrict__ coef) {
+    const Coef kq = this->coef_of(0, coef);
+#pragma unroll
+    for (int i = 0; i < Base::NPF; ++i) store_one(i, lds, coef, kq);
+  }
+  // see TileStager::store_load
+  __device__ __forceinline__ void store_load(unsigned char* __restrict__ lds, const float* __restrict__ coef,
+                                             const float* __restrict__ in, const float* __restrict__ in2, int b, int Hi,
+                                             int Wi, int gy0, int gx0) {
+    unsigned nb = 0u;
+    const TIN* __restrict__ base = ava_as<TIN>(in) + (size_t)b * Hi * Wi * CIN;
+    const TIN2* __restrict__ base2 = PRO == PRO_BWD ? ava_as<TIN2>(in2) + (size_t)b * Hi * Wi * CIN : nullptr;
+    const Coef kq = this->coef_of(0, coef);
 #pragma unroll
     for (int i = 0; i < Base::NPF; ++i) {
-      const int idx = this->tid + NT * i;
-      const float* ca = coef + this->q4[i];
-      const avaf4 x = this->v[i];
-      const avaf4 y = PRO == PRO_BWD ? this->v2[i] : x;
-      const bool ok = (this->inb >> i) & 1u;
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = ok ? prologue<PRO>(x[e], y[e], ca[e], ca[32 + e], ca[64 + e]) : 0.f;
-      ava_u32x2 p0, p1, p2;
-      uint32_t a, b, c;
-      ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
-      ava_limb_split2(o[2], o[3], a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
-      const int q = idx % Base::Q, pix = idx / Base::Q;
-      unsigned char* d = lds + ((q >> 1) * NPIX + pix) * 16 + (q & 1) * 8;
-      if ((this->live >> i) & 1u) {
-        *reinterpret_cast<ava_u32x2*>(d) = p0;
-        *reinterpret_cast<ava_u32x2*>(d + PLANE_BYTES) = p1;
-        *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
-      }
+      store_one(i, lds, coef, kq);
+      this->load_one(i, base, base2, Hi, Wi, gy0, gx0, nb);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    this->inb = nb;
   }
 };
 

@@ -91,6 +91,14 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   typename std::conditional<RECOMP, Y1MfmaStager<IC, ACT>,
                             typename std::conditional<LIMB, TileStagerL<CIN, PRO, IR, IC, 256, TIN, ACT>,
                                                       TileStager<CIN, PRO, IR, IC, false, 256, TIN, ACT>>::type>::type stg;   // staging waves only (threadIdx.x 0..255)
+  // DEEP: the limb tiles of the stride-2 layers with >= 16 channels fill the LDS of a CU with ONE workgroup (two buffers of
+  // 56 / 43 KB), so one tile in flight per workgroup is all the memory-level parallelism the CU has: the staging waves hold
+  // TWO tiles in registers (the workgroup's 8 waves may use 256 VGPRs each) and request tile it+3 while tile it+1 is converted
+  // (two register sets of NPF float4 -- twice that with the saved activation of PRO_BWD -- must leave room: <= 128 VGPRs)
+  constexpr int STG_NPF = (IR * IC * (CIN / 4) + 255) / 256;
+  constexpr bool DEEP = LIMB && !RECOMP && (size_t)2 * TILE_F * sizeof(float) > 80 * 1024 &&
+                        STG_NPF * (PRO == PRO_BWD ? 2 : 1) * 8 <= 128;
+  decltype(stg) stg2;
   auto stg_store = [&](float* tile) __attribute__((always_inline)) {
     if (AVA_ABL(2)) return;
     if constexpr (RECOMP) stg.store(tile, coef, xs);
@@ -99,9 +107,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   };
   // stride-2 gathers hold the most staging registers: keeping their first tile in flight across the prologue raised
   // conv2's forward from 70 to 112 VGPRs (3 -> 2 resident workgroups per CU, 42 -> 50 us); they load after it instead
-  constexpr bool HOIST = MODE != MODE_DOWN;
+  constexpr bool HOIST = MODE != MODE_DOWN || DEEP;
   if (stager) {
     if constexpr (RECOMP) stg.init(a.rc, xs); else stg.init();
+    if constexpr (DEEP) stg2.init();
     if (HOIST && walk.valid()) {                                // tile 0 goes in flight BEFORE the coefficient prologue
       int b, oy0, ox0, gy0, gx0;
       origin(walk.cur, b, oy0, ox0, gy0, gx0);
@@ -126,6 +135,32 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     // reverse, matrix-core waves first, costs +26 us)
     __builtin_amdgcn_s_setprio(3);
     int b, oy0, ox0, gy0, gx0;
+    if constexpr (DEEP) {
+      // tile k of this workgroup's list, clamped to a valid tile behind its end (branch-free loads: see store_load)
+      auto tile_k = [&](int k) { const int tl = walk.cur + k * walk.step; return tl < walk.end ? tl : walk.cur; };
+      unsigned char* const buf0 = reinterpret_cast<unsigned char*>(tile0);
+      unsigned char* const buf1 = reinterpret_cast<unsigned char*>(tile0 + TILE_F);
+      if (walk.valid()) {
+        origin(tile_k(1), b, oy0, ox0, gy0, gx0);
+        stg2.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);                     // tile 1 -> register set 2
+        origin(tile_k(2), b, oy0, ox0, gy0, gx0);
+        stg.store_load(buf0, coef, a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);    // tile 0 -> buffer 0, tile 2 -> register set 1
+      }
+      __syncthreads();                                                       // (A)
+      int it = 0;
+      for (; walk.valid(); walk.advance(), ++it) {
+        if (walk.has_next()) {
+          origin(tile_k(3), b, oy0, ox0, gy0, gx0);                          // relative to the advancing walk.cur: tile it+3
+          if ((it & 1) == 0) stg2.store_load(buf1, coef, a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+          else stg.store_load(buf0, coef, a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
+        }
+        __syncthreads();                                                     // (B)
+      }
+      if (MSPLIT) __syncthreads();
+      __syncthreads();
+      __syncthreads();
+      return;
+    }
     if (walk.valid()) {
       if (!HOIST) {
         origin(walk.cur, b, oy0, ox0, gy0, gx0);

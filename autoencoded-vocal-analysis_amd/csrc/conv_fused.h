@@ -27,6 +27,7 @@ struct FusedArgs {
   int skip_dx;           // thin 8 -> 1 backward: only the weight gradient + BatchNorm sums (its data gradient is formed by the consumer)
   RecompArgs rc;         // rc.G1 != null: `x` is the raw spectrogram batch; the layer input y1 is recomputed from it (conv_recomp.h)
   int sweep;             // thin kernels: workgroups sweep the tile list together instead of per-XCD chunks
+  int dbg;               // lab build: phase ablation bits of the wave-specialised kernel (AVA_FDBG; timing only)
 };
 
 // 0 when (Cin, Cout, mode, size) has no fused instantiation

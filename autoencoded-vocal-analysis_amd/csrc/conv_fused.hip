@@ -306,6 +306,14 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
   for (int e = t; e < NW + CO; e += 256) prow[e] = wacc[e];
 }
 
+// lab build: phase ablation (AVA_FDBG bits: 1 no data-gradient MFMA, 2 no weight-gradient MFMA, 4 no prologue / LDS write of
+// the staging waves, 8 no tile loads, 16 no dx stores, 32 no raw-x loads of the matrix-core waves); timing only
+#ifdef AVA_LAB
+#define AVA_FABL(bit) ((a.dbg & (bit)) != 0)
+#else
+#define AVA_FABL(bit) false
+#endif
+
 // DUREC (convt6's backward): the upstream gradient dy (8 channels, full resolution) does not exist in memory -- it is
 // convt7's data gradient, a 3x3 gather of the 1-channel seed a.dy, formed on the matrix cores by the staging waves as
 // they build the dU tile (conv_recomp.h: DU1to8Stager).
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   auto prefetch = [&](int tl) {
     int b, y0, x0, gy, gx;
     origin(tl, b, y0, x0);
+    if (AVA_FABL(8)) return;
     x_origin(y0, x0, gy, gx);
     sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy, gx);
     d_origin(y0, x0, gy, gx);
@@ -397,8 +406,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
     // reverse, matrix-core waves first, costs +26 us)
     __builtin_amdgcn_s_setprio(3);
     if (walk.valid()) {
-      sx.store(smem, cx);
-      sd_store(smem + XF);
+      if (!AVA_FABL(4)) { sx.store(smem, cx); sd_store(smem + XF); }
       if (walk.has_next()) prefetch(walk.next());
     }
     __syncthreads();                                            // (A) tile 0 ready
@@ -406,8 +414,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
     for (; walk.valid(); walk.advance(), ++it) {
       if (walk.has_next()) {                                    // tile it+1 -> the other buffer, tile it+2 in flight
         float* nb = smem + ((it + 1) & 1) * BUF_F;
-        sx.store(nb, cx);
-        sd_store(nb + XF);
+        if (!AVA_FABL(4)) { sx.store(nb, cx); sd_store(nb + XF); }
         const int nn = walk.next() + walk.step;
         if (nn < walk.end) prefetch(nn);
       }
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
       }
   };
 
-  if (walk.valid()) load_ex(walk.cur);
+  if (walk.valid() && !AVA_FABL(32)) load_ex(walk.cur);
   __syncthreads();                                              // (A)
   int it = 0;
   for (; walk.valid(); walk.advance(), ++it) {
@@ -502,7 +509,8 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (BMODE == MODE_UP) {
+      if (AVA_FABL(1)) {
+      } else if (BMODE == MODE_UP) {
         const int cls = gi & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;   // GPW % 4 == 0: cls is compile-time
         const float* px = dut + (r * DC + 16 * cb) * CO;
         if (cls == 0) f0.run(px, acc);
@@ -526,15 +534,16 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
             s1[mt][r] += v[r];
             s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
           }
-          *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
+          if (!AVA_FABL(16)) *reinterpret_cast<float4*>(obase + gout + 16 * mt) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
 
-    if (walk.has_next()) load_ex(walk.next());
+    if (walk.has_next() && !AVA_FABL(32)) load_ex(walk.next());
 
     // ---- phase 2: weight / bias gradient over the tile's interior dU pixels ----
-    if (LMODE == MODE_UP) {
+    if (AVA_FABL(2)) {
+    } else if (LMODE == MODE_UP) {
       // x-space rows r = wave + 4 rr, columns c = 4 s + kg; the four output-parity classes of each x pixel
 #pragma unroll 1
       for (int rr = 0; rr < TH / 4; ++rr) {
@@ -771,7 +780,9 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
   return nt < ava_scale_grid(cap) ? nt : ava_scale_grid(cap);
 }
 
-int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
+int ava_conv3x3_bwd_fused_launch(const FusedArgs& a_, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
+  FusedArgs a = a_;
+  { static const int dbg = [] { const char* e = ava_env("AVA_FDBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
   const int grid = ava_conv_fused_grid_for(a.B, a.Hi, a.Wi, Cin, Cout, mode);
   if (grid <= 0) return AVA_EINVAL;
   if (Cin == 1 || Cout == 1) return ava_thin_bwd_fused_launch(a, grid, Cin, dy_pro, st);

@@ -250,19 +250,23 @@ struct DU1to8Stager {
   // lds: the [9 x C x 8] fp32 tile; coef: A [0..7], Bc [32..39], Cc [64..71]
   __device__ __forceinline__ void store(float* __restrict__ lds, const float* __restrict__ coef, float* __restrict__ xs_all) {
     core.stage(xs_all, [](float v) { return v; });               // PRO_ID on the seed
+    // the lane's channel quad is the same for every unit: its coefficients are read once, unconditionally (inside the
+    // `in && y > 0 ? .. : 0` select the compiler may not speculate the LDS reads and serialises them per value)
+    const float* ca = coef + 4 * ((core.lane >> 4) & 1);
+    const avaf4 kA = {ca[0], ca[1], ca[2], ca[3]}, kB = {ca[32], ca[33], ca[34], ca[35]}, kC = {ca[64], ca[65], ca[66], ca[67]};
 #pragma unroll
     for (int u = 0; u < Core::NUW; ++u) {
       int row, col, quad, pb, g;
       const bool v = core.unit(u, row, col, quad, pb, g);
       if (u >= Core::NG && core.wave + 4 * (u - Core::NG) >= Core::NG) continue;      // wave-uniform: no such group
       const f32x4 acc = core.mma(xs_all, pb, g);
-      const float* ca = coef + 4 * quad;
       const bool in = (yin >> u) & 1u;
       avaf4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float y = y2[u][r];
-        o[r] = (in && y > 0.f) ? fmaf(ca[r], acc[r], fmaf(ca[32 + r], y, ca[64 + r])) : 0.f;
+        const float du = fmaf(kA[r], acc[r], fmaf(kB[r], y, kC[r]));
+        o[r] = (in && y > 0.f) ? du : 0.f;
       }
       if (v) *reinterpret_cast<avaf4*>(lds + (row * C + col) * 8 + 4 * quad) = o;
     }

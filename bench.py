@@ -470,8 +470,9 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
            "dtype": ("f32" if args.dtype == "f32" else "f32 arithmetic, bf16 activation storage")
-                    + " (fc1/fc8 products: fp32 operands as three bf16 limbs on bf16 MFMA, six limb products, fp32 accumulate; "
-                      "convolutions and the small products on fp32 MFMA / packed fp32 FMA)", "data": "synthetic",
+                    + " (fc1/fc8 products and the forward / data-gradient convolutions with >= 16 input channels: fp32 operands as "
+                      "three bf16 limbs on bf16 MFMA, six limb products, fp32 accumulate; the other convolutions, the fused backward "
+                      "kernels and the small products on fp32 MFMA / packed fp32 FMA)", "data": "synthetic",
            "config": {"workload": "configs[%d]: mouse_sylls VAE, batch %d synthetic %dx%d fp32 spectrograms per GPU, z=%d, "
                                   "train step = zero_grad+forward+backward%s+Adam, device-resident batches"
                                   % (4 if (H, W) != (128, 128) else (3 if world > 1 else (2 if args.z_dim == 64 else 1)), B, H, W, args.z_dim,

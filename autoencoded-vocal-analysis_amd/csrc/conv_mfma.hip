@@ -653,6 +653,10 @@ static int wgrad_plan(const WgradArgs& a, int grid, WgradArgs* b, size_t* lds_ou
   if (grid > b->ntiles) grid = b->ntiles;
   static const int resident = ava_resident_grid(kernel, lds);
   if (grid > ava_scale_grid(resident)) grid = ava_scale_grid(resident);          // one resident wave of workgroups = partial rows written
+  // the split kernels (the 16 x 16 layers): one workgroup per CU.  Each workgroup ends with a 5-7 k-float partial row,
+  // which at one or two tiles per workgroup costs more than the tiles (same-box A/B of the step: 512 -> 256 workgroups
+  // -13 us, 384 +-0, 128 +13 us)
+  if (SPLIT && grid > ava_scale_grid(256)) grid = ava_scale_grid(256);
   { const char* e = ava_env("AVA_WGRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }
   return grid;
 }

@@ -178,6 +178,24 @@ __device__ __forceinline__ void load_nchw_quarter(float (*tile)[QPIX + 1], const
     tile[c][p] = src[(size_t)b * 32 * P + (size_t)c * P + q * QPIX + p];
   }
 }
+// the same tile from a product left as two split-K slabs (gemm.hip: ava_gemm_defer2): summed as splitk_reduce_kernel sums
+// them (0 + slab0 + slab1, + bias, activation), and written back to `full` (the NCHW tensor the reduce would have produced)
+// when a later kernel reads it
+__device__ __forceinline__ void load_nchw_quarter_slabs(float (*tile)[QPIX + 1], const float* __restrict__ s0,
+                                                        const float* __restrict__ s1, const float* __restrict__ bias, int relu,
+                                                        float* __restrict__ full, int b, int q, int P) {
+  for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
+    const int c = i / QPIX, p = i % QPIX;
+    const size_t n = (size_t)c * P + q * QPIX + p, o = (size_t)b * 32 * P + n;
+    float s = 0.f;
+    s += s0[o];
+    s += s1[o];
+    if (bias != nullptr) s += bias[n];
+    if (relu) s = fmaxf(s, 0.f);
+    if (full != nullptr) full[o] = s;
+    tile[c][p] = s;
+  }
+}
 __device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const float* __restrict__ src, int b, int q, int P) {
   for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
     const int p = i >> 5, c = i & 31;                        // the slab is one contiguous 8 KB range
@@ -186,10 +204,13 @@ __device__ __forceinline__ void load_nhwc_quarter(float (*tile)[QPIX + 1], const
 }
 
 // f8 [B][32*P] (c*P+p) -> out [B][P][32] (an ACTIVATION: stored as ACT), plus per-channel {sum, sum^2} partials for bn8
-template <typename ACT>
+// SLABS: `in` is slab 0 of a deferred two-slab product, slab1 / bias / relu complete it and `full` receives the reduced tensor
+template <typename ACT, bool SLABS = false>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __restrict__ in, float* __restrict__ out_,
                                                                  float* __restrict__ partials, int B, int P,
-                                                                 long long* acc_out) {
+                                                                 long long* acc_out, const float* __restrict__ slab1 = nullptr,
+                                                                 const float* __restrict__ bias = nullptr, int relu = 0,
+                                                                 float* __restrict__ full = nullptr) {
   ACT* __restrict__ out = reinterpret_cast<ACT*>(out_);
   __shared__ float tile[32][QPIX + 1];
   __shared__ float red[8][64];
@@ -199,7 +220,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_stats_kernel(const float* __
   for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
     const int b = w / nq, q = w - b * nq;
     __syncthreads();
-    load_nchw_quarter(tile, in, b, q, P);
+    if constexpr (SLABS) load_nchw_quarter_slabs(tile, in, slab1, bias, relu, full, b, q, P);
+    else load_nchw_quarter(tile, in, b, q, P);
     __syncthreads();
     for (int i = t; i < 32 * QPIX; i += 256) {
       const int p = i >> 5, c = i & 31;     // c == t & 31 for every i of this thread
@@ -238,15 +260,18 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }
 
 // dU7 (NHWC) = (y7 > 0) ? dy7 (NCHW-flatten, from fc1's backward) : 0       (ReLU of vae.py:223)
+// slab1 != null: dy is slab 0 of a deferred two-slab product (fc1's dX), summed on the way in
 __global__ __launch_bounds__(256) void relu_mask_to_nhwc_kernel(const float* __restrict__ dy_nchw,
                                                                 const float* __restrict__ y_nhwc,
-                                                                float* __restrict__ du_nhwc, int B, int P) {
+                                                                float* __restrict__ du_nhwc, int B, int P,
+                                                                const float* __restrict__ slab1) {
   __shared__ float tile[32][QPIX + 1];
   const int nq = P / QPIX;
   for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
     const int b = w / nq, q = w - b * nq;
     __syncthreads();
-    load_nchw_quarter(tile, dy_nchw, b, q, P);
+    if (slab1 != nullptr) load_nchw_quarter_slabs(tile, dy_nchw, slab1, nullptr, 0, nullptr, b, q, P);
+    else load_nchw_quarter(tile, dy_nchw, b, q, P);
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
       const size_t o = (size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i;
@@ -360,6 +385,18 @@ int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, 
 }
 
 // internal (model.hip)
+// the same from a product left as two split-K slabs: slab0 + slab1 + bias, ReLU; `full` receives the reduced NCHW tensor
+int ava_nchw_to_nhwc_stats_slabs(const float* slab0, const float* slab1, const float* bias, int relu, float* full, float* out,
+                                 float* partials, int B, int P, int act_bf16, long long* acc_out, int* nparts, hipStream_t st) {
+  if (P < QPIX || P % QPIX != 0) return AVA_EINVAL;
+  const int nw = (P / QPIX) * B;
+  const int grid = nw < 1024 ? nw : 1024;
+  if (act_bf16) hipLaunchKernelGGL((nchw_to_nhwc_stats_kernel<unsigned short, true>), dim3(grid), dim3(256), 0, st, slab0, out, partials, B, P, acc_out, slab1, bias, relu, full);
+  else hipLaunchKernelGGL((nchw_to_nhwc_stats_kernel<float, true>), dim3(grid), dim3(256), 0, st, slab0, out, partials, B, P, acc_out, slab1, bias, relu, full);
+  AVA_CHECK_LAUNCH();
+  *nparts = grid;
+  return AVA_OK;
+}
 int ava_nchw_to_nhwc_stats(const float* in, float* out, float* partials, int B, int P, int act_bf16, long long* acc_out,
                            int* nparts, hipStream_t st) {
   if (P < QPIX || P % QPIX != 0) return AVA_EINVAL;
@@ -377,8 +414,8 @@ int ava_nhwc_to_nchw(const float* in, float* out, int B, int P, hipStream_t st) 
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
-int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, int P, hipStream_t st) {
-  hipLaunchKernelGGL(relu_mask_to_nhwc_kernel, dim3(layout_grid(B, P)), dim3(256), 0, st, dy_nchw, y_nhwc, du, B, P);
+int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* slab1, const float* y_nhwc, float* du, int B, int P, hipStream_t st) {
+  hipLaunchKernelGGL(relu_mask_to_nhwc_kernel, dim3(layout_grid(B, P)), dim3(256), 0, st, dy_nchw, y_nhwc, du, B, P, slab1);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

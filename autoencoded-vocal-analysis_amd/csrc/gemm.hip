@@ -477,9 +477,30 @@ static void launch_gemm(const GemmArgs& g, int a_k, int b_k, dim3 grid, hipStrea
   else hipLaunchKernelGGL((gemm_kernel<BM, BM, false, false, BK, VEC>), grid, dim3(256), 0, st, g);
 }
 
+static int gemm_impl(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                     const float* mask, float* colsum, int M, int N, int K, int a_kmajor, int b_kmajor, int act,
+                     void* ws, size_t ws_bytes, ava_stream_t s, int* deferred_slabs);
+
 extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
                         const float* mask, float* colsum, int M, int N, int K, int a_kmajor, int b_kmajor, int act,
                         void* ws, size_t ws_bytes, ava_stream_t s) {
+  return gemm_impl(A, lda, B, ldb, bias, C, ldc, mask, colsum, M, N, K, a_kmajor, b_kmajor, act, ws, ws_bytes, s, nullptr);
+}
+
+// internal (model.hip): the same product, but when it runs as exactly TWO split-K slabs of the limb kernel the reduce
+// launch is left to the consumer -- a layout kernel that reads the product once anyway sums the slabs in the reduce
+// kernel's order, adds the bias and applies the activation on the way in (bn.hip: load_nchw_quarter_slabs).  *slabs = 2:
+// the slabs are ws[0 .. M*N) and ws[M*N .. 2*M*N), C is untouched; *slabs = 1: C is complete.
+int ava_gemm_defer2(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                    const float* mask, float* colsum, int M, int N, int K, int a_kmajor, int b_kmajor, int act,
+                    void* ws, size_t ws_bytes, ava_stream_t s, int* slabs) {
+  *slabs = 1;
+  return gemm_impl(A, lda, B, ldb, bias, C, ldc, mask, colsum, M, N, K, a_kmajor, b_kmajor, act, ws, ws_bytes, s, slabs);
+}
+
+static int gemm_impl(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                     const float* mask, float* colsum, int M, int N, int K, int a_kmajor, int b_kmajor, int act,
+                     void* ws, size_t ws_bytes, ava_stream_t s, int* deferred_slabs) {
   if (A == nullptr || B == nullptr || C == nullptr || M <= 0 || N <= 0 || K <= 0) return AVA_EINVAL;
   int bm, splits, klen;
   plan(M, N, K, &bm, &splits, &klen);
@@ -509,6 +530,10 @@ extern "C" int ava_gemm(const float* A, int lda, const float* B, int ldb, const 
     g.C = splits > 1 ? reinterpret_cast<float*>(ws) : C;
     const int rc = ava_gemm_limb_launch(g, a_kmajor, b_kmajor, lbn, st);
     if (rc != AVA_OK) return rc;
+    if (splits == 2 && deferred_slabs != nullptr && mask == nullptr && colsum == nullptr && g.ldc == N) {
+      *deferred_slabs = 2;                 // the consumer reduces
+      return AVA_OK;
+    }
     if (splits > 1) {
       const size_t mn = (size_t)M * N;
       int blocks = (int)((mn + 255) / 256);

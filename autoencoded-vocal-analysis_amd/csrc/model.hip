@@ -22,7 +22,12 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
                    const float* epi_mean, const float* epi_invstd, float* partials, int B, int Hi, int Wi, int Cin,
                    int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, const ConvAcc* acc, ava_stream_t s);
 int ava_nhwc_to_nchw(const float* in, float* out, int B, int P, hipStream_t st);
-int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* y_nhwc, float* du, int B, int P, hipStream_t st);
+int ava_relu_mask_to_nhwc(const float* dy_nchw, const float* slab1, const float* y_nhwc, float* du, int B, int P, hipStream_t st);
+int ava_nchw_to_nhwc_stats_slabs(const float* slab0, const float* slab1, const float* bias, int relu, float* full, float* out,
+                                 float* partials, int B, int P, int act_bf16, long long* acc_out, int* nparts, hipStream_t st);
+int ava_gemm_defer2(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                    const float* mask, float* colsum, int M, int N, int K, int a_kmajor, int b_kmajor, int act,
+                    void* ws, size_t ws_bytes, ava_stream_t s, int* slabs);
 int ava_bn_bwd_apply_to_nchw(const float* g, const float* f8, const float* A, const float* Bc, const float* Cc,
                              float* out, int B, int P, int act_bf16, const BnFin* fin, hipStream_t st);
 int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, const float* gamma, const float* mean,
@@ -148,6 +153,7 @@ struct ava_model {
   float* Gf[NCONV];
   float* Gb[NCONV];
   float *gA, *gB;           // gradient ping-pong, B*131072 floats each
+  int dy7_slabs;            // 2: fc1's dX of the last backward part 1 sits in the GEMM workspace as two split-K slabs
   float* wg_part[NCONV];    // wgrad partial rows, one region per layer (reduced in one launch at the end)
   float *dF8, *dh7, *dh6, *dh5, *dz, *dmu, *du, *dlogd, *dh3, *dh2, *dh1, *dy7;
   float* gemm_ws;
@@ -703,6 +709,13 @@ static int gemm(ava_model* m, const float* A, int lda, const float* B, int ldb, 
   return ava_gemm(A, lda, B, ldb, bias, C, ldc, mask, colsum, M, N, K, ak, bk, act, m->gemm_ws, m->gemm_ws_bytes, st);
 }
 
+// the product with its split-K reduce left to the consumer when it runs as two slabs (gemm.hip: ava_gemm_defer2)
+static int gemm_defer2(ava_model* m, const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                       int M, int N, int K, int ak, int bk, int act, hipStream_t st, int* slabs) {
+  struct Mk { ava_model* m; hipStream_t st; ~Mk() { mark(m, CAT_GEMM, st); } } _mk{m, st};
+  return ava_gemm_defer2(A, lda, B, ldb, bias, C, ldc, nullptr, nullptr, M, N, K, ak, bk, act, m->gemm_ws, m->gemm_ws_bytes, st, slabs);
+}
+
 struct AvaGemmProblem {
   const float* A; int lda; const float* B; int ldb; const float* bias; float* C; int ldc; const float* mask;
   float* colsum; int M, N, K; int act;
@@ -813,10 +826,19 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
   TRY(gemm(m, zin, 0, PP(m, FC5), 0, PP(m, FC5 + 1), m->h5, 0, nullptr, nullptr, B, 64, z, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h5, 0, PP(m, FC6), 0, PP(m, FC6 + 1), m->h6, 0, nullptr, nullptr, B, 256, 64, 1, 1, ACT_RELU, st));
   TRY(gemm(m, m->h6, 0, PP(m, FC7), 0, PP(m, FC7 + 1), m->h7, 0, nullptr, nullptr, B, 1024, 256, 1, 1, ACT_RELU, st));
-  TRY(gemm(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, nullptr, nullptr, B, m->F, 1024, 1, 1, ACT_RELU, st));
+  // fc8: when the product runs as two split-K slabs, the layout kernel behind it sums them (+ bias, ReLU) on the way in and
+  // writes f8 as well -- one launch and one pass over the tensor fewer
+  int slabs8 = 1;
+  TRY(gemm_defer2(m, m->h7, 0, PP(m, FC8), 0, PP(m, FC8 + 1), m->f8, 0, B, m->F, 1024, 1, 1, ACT_RELU, st, &slabs8));
   int nparts = 0;
   long long* acc7 = (train && acc_pair_fwd(m, 7)) ? acc_slot(m, 7) : nullptr;     // bn8's sums: finalised by convt1's kernel
-  TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, m->P8, m->act_bf16, acc7, &nparts, st));
+  if (slabs8 == 2) {
+    const float* s0 = reinterpret_cast<const float*>(m->gemm_ws);
+    TRY(ava_nchw_to_nhwc_stats_slabs(s0, s0 + (size_t)B * m->F, PP(m, FC8 + 1), 1, m->f8, m->X[7], m->bn_part, B, m->P8,
+                                     m->act_bf16, acc7, &nparts, st));
+  } else {
+    TRY(ava_nchw_to_nhwc_stats(m->f8, m->X[7], m->bn_part, B, m->P8, m->act_bf16, acc7, &nparts, st));
+  }
   mark(m, CAT_LAYOUT, st);
   if (train && acc7 == nullptr) TRY(finalize_fwd(m, 7, nparts, (int64_t)B * m->P8, st));
   for (int l = 7; l < NCONV; ++l) {
@@ -1099,7 +1121,10 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   TRY(gemm(m, m->dh3, 0, PP(m, FC31), 0, nullptr, m->dh2, 0, m->h2, nullptr, B, 256, 192, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh2, 0, PP(m, FC2), 0, nullptr, m->dh1, 0, m->h1, nullptr, B, 1024, 256, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh1, 0, m->y7t, 0, nullptr, GG(m, FC1), 0, nullptr, GG(m, FC1 + 1), 1024, m->F, B, 0, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, nullptr, nullptr, B, m->F, 1024, 1, 0, ACT_NONE, st));
+  // fc1's dX: left as two slabs where it runs so (part 2's ReLU-mask / layout kernel sums them; no split-K product runs in
+  // between, so the workspace keeps them)
+  m->dy7_slabs = 1;
+  TRY(gemm_defer2(m, m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, B, m->F, 1024, 1, 0, ACT_NONE, st, &m->dy7_slabs));
   // ---- the eight small weight gradients (K = batch): fc7, fc6, fc5, fc41/42/43, fc31|32|33, fc2 ----
   const AvaGemmProblem dws[8] = {
       {m->dh7, 0, m->h6, 0, nullptr, GG(m, FC7), 0, nullptr, GG(m, FC7 + 1), 1024, 256, B, ACT_NONE},
@@ -1119,7 +1144,12 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, b
   float* gnext = m->gB;
   mark(m, -1, st);
   if (recomp_y1()) TRY(materialize_y1(m, x, B, st));       // TEMPORARY: until conv2's / conv1's backward recompute y1 themselves
-  TRY(ava_relu_mask_to_nhwc(m->dy7, m->y7, gcur, B, m->P8, st));             // dU_7 (ReLU of conv7)
+  if (m->dy7_slabs == 2) {
+    const float* s0 = reinterpret_cast<const float*>(m->gemm_ws);
+    TRY(ava_relu_mask_to_nhwc(s0, s0 + (size_t)B * m->F, m->y7, gcur, B, m->P8, st));
+  } else {
+    TRY(ava_relu_mask_to_nhwc(m->dy7, nullptr, m->y7, gcur, B, m->P8, st));  // dU_7 (ReLU of conv7)
+  }
   mark(m, CAT_LAYOUT, st);
   // conv7 + conv6 (16 x 16, no fused kernel): both data gradients first, then the two weight gradients as ONE launch
   const bool pair = fused_grid(m, 6, B) == 0 && fused_grid(m, 5, B) == 0;

@@ -11,11 +11,13 @@
 #include "conv_recomp.h"
 
 // Which shapes run the limb form: every forward-type launch with 16 or more input channels (conv4..conv6, convt1..convt5
-// forward and the four 16 x 16 layers' data gradients).  Measured on every shape (profiles/r03/limb_conv_forward.txt,
+// forward and the four 16 x 16 layers' data gradients) and, since the staging waves' prologue lost its serialised LDS reads
+// (conv_common.h: TileStager::coef_of) and has room for the split, the forward of conv2 and conv3 (8 input channels:
+// isolated 42.2 -> 35.2 and 40.1 -> 32.5 us, step -7 us; whole -m gpu suite unchanged).  Measured earlier on every shape (profiles/r03/limb_conv_forward.txt,
 // limb_conv_configs.txt): conv5 16 -> 24: 31.3 -> 24 us, convt5 16 -> 8: 45.8 -> 32 us, the others +-1 us (at one or two
 // tiles per workgroup they are bound by launch / prologue latency, not by the matrix pipe; the 24- and 32-channel ones need
 // > 128 VGPRs for three limbs of weights and run one workgroup per CU), conv4 29 -> 35 us (stride 2: the fragments are read
-// with a 32-byte lane stride, two-way LDS conflicts).  The 8-channel layers are HBM-bound and would only pay the split.
+// with a 32-byte lane stride, two-way LDS conflicts; 26 us once it holds two tiles in registers).
 // Choice among the sets that are about equally fast (-17 .. -26 us per step): every arithmetic (the fp32 MFMA one included)
 // flips a different handful of ReLU masks against the reference's fp32 goldens, and the golden /
 // trajectory / callers tests pass at their round-2 tolerances for this set and for {convt5}; the faster sets each trip one
@@ -42,7 +44,8 @@ static bool conv_limb_on(int Cin, int Cout, int mode, int pro) {
   if (sel == 7) return Cin >= 16 && mode != MODE_DOWN && pro == PRO_BN;                // forward layers only, not stride 2
   if (sel == 8) return Cin == 16 && pro == PRO_BN;                                     // the 16-channel forward layers
   if (sel == 9) return Cin == 16 && mode == MODE_S1 && pro == PRO_BN;                  // conv5 + convt5
-  return Cin >= 16;
+  if (sel == 10) return Cin >= 16;                                                     // the table before conv2 / conv3 joined
+  return Cin >= 16 || pro == PRO_BN;
 }
 
 // ACT: storage type of the activations this launch touches -- the input of a forward layer (PRO_BN), the saved
@@ -404,7 +407,7 @@ int launch_mfma_ws(const ConvArgs& a, int grid, hipStream_t st) {
 #ifdef AVA_LAB
   constexpr bool kLimbBuilt = CIN % 8 == 0;
 #else
-  constexpr bool kLimbBuilt = CIN >= 16 && CIN % 8 == 0;
+  constexpr bool kLimbBuilt = CIN % 8 == 0 && (CIN >= 16 || PRO == PRO_BN);
 #endif
   if constexpr (kLimbBuilt) {
     if (conv_limb_on(CIN, COUT, MODE, PRO)) {

@@ -470,7 +470,7 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
            "dtype": ("f32" if args.dtype == "f32" else "f32 arithmetic, bf16 activation storage")
-                    + " (fc1/fc8 products and the forward / data-gradient convolutions with >= 16 input channels: fp32 operands as "
+                    + " (fc1/fc8 products, the forward convolutions with >= 8 input channels and the 16x16 layers' data gradients: fp32 operands as "
                       "three bf16 limbs on bf16 MFMA, six limb products, fp32 accumulate; the other convolutions, the fused backward "
                       "kernels and the small products on fp32 MFMA / packed fp32 FMA)", "data": "synthetic",
            "config": {"workload": "configs[%d]: mouse_sylls VAE, batch %d synthetic %dx%d fp32 spectrograms per GPU, z=%d, "

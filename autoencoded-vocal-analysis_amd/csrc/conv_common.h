@@ -207,10 +207,22 @@ struct TileStager {
   // Prologue coefficients of element i's channel quad, read from LDS as vectors and UNCONDITIONALLY: written as
   // `ok ? prologue(x, coef[..]) : 0` the compiler may not speculate the LDS reads and emits, per element, four exec-masked
   // blocks of { ds_read2_b32; s_waitcnt lgkmcnt(0); fma } -- four serialised LDS round trips (measured: 1.9 us of a
-  // 2.9 us tile step of conv4's forward).  SAMEQ: NT is a multiple of the quads per pixel, so every element of a thread
-  // has the same quad and the three vectors are fetched once per call (kq) instead of once per element.
-  static constexpr bool SAMEQ = NT % Q == 0;
+  // 2.9 us tile step of conv4's forward).  Where NT is a multiple of the quads per pixel every element of a
+  // thread has the same quad and the three vectors are fetched once per call instead of once per element.
+  // In general a thread's elements cycle through QP = Q / gcd(NT mod Q, Q) quads (24 channels: 6 quads, 256 threads -> 3):
+  // the QP coefficient sets are fetched once per call (Coefs) and element i takes set i mod QP.
+  static constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+  static constexpr int QP = (NT % Q == 0) ? 1 : Q / gcd_(NT % Q, Q);
+  static constexpr bool SAMEQ = QP <= 4;            // coefficient sets held in registers for the whole call
+  static constexpr int NKQ = SAMEQ ? (QP < NPF ? QP : NPF) : 1;
   struct Coef { avaf4 a, b, c; };
+  struct Coefs { Coef k[NKQ]; };
+  __device__ __forceinline__ Coefs coefs_of(const float* __restrict__ coef) const {
+    Coefs r;
+#pragma unroll
+    for (int j = 0; j < NKQ; ++j) r.k[j] = coef_of(j, coef);
+    return r;
+  }
   __device__ __forceinline__ Coef coef_of(int i, const float* __restrict__ coef) const {
     Coef k;
     const float* ca = coef + q4[i];
@@ -236,9 +248,9 @@ struct TileStager {
     return o;
   }
 
-  __device__ __forceinline__ void store_one(int i, float* __restrict__ lds, const float* __restrict__ coef, const Coef& kq) {
+  __device__ __forceinline__ void store_one(int i, float* __restrict__ lds, const float* __restrict__ coef, const Coefs& kq) {
     const int idx = tid + NT * i;
-    const avaf4 o = SAMEQ ? value_one(i, kq) : value_one(i, coef_of(i, coef));
+    const avaf4 o = SAMEQ ? value_one(i, kq.k[i % NKQ]) : value_one(i, coef_of(i, coef));
     // PLANES: channel quad q of every pixel in its own [R*C][4] plane, so lanes that walk along x read 16-byte
     // slots 16 bytes apart (conflict-free ds_read_b128) instead of CIN*4 bytes apart
     const int dst = PLANES ? ((idx % Q) * (R * C) + idx / Q) : idx;
@@ -249,7 +261,7 @@ struct TileStager {
   __device__ __forceinline__ void store(float* __restrict__ lds, const float* __restrict__ coef) {
     ava_wait_vm0(v);
     if (PRO == PRO_BWD) ava_wait_vm0(v2);
-    const Coef kq = coef_of(0, coef);
+    const Coefs kq = coefs_of(coef);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) store_one(i, lds, coef, kq);
   }
@@ -265,7 +277,7 @@ struct TileStager {
     unsigned nb = 0u;
     const TIN* __restrict__ base = ava_as<TIN>(in) + (size_t)b * Hi * Wi * CIN;
     const TIN2* __restrict__ base2 = PRO == PRO_BWD ? ava_as<TIN2>(in2) + (size_t)b * Hi * Wi * CIN : nullptr;
-    const Coef kq = coef_of(0, coef);
+    const Coefs kq = coefs_of(coef);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       store_one(i, lds, coef, kq);
@@ -309,9 +321,10 @@ struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2> {
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
   static constexpr int TILE_BYTES = 3 * PLANE_BYTES;
   using Coef = typename Base::Coef;
-  __device__ __forceinline__ void store_one(int i, unsigned char* __restrict__ lds, const float* __restrict__ coef, const Coef& kq) {
+  using Coefs = typename Base::Coefs;
+  __device__ __forceinline__ void store_one(int i, unsigned char* __restrict__ lds, const float* __restrict__ coef, const Coefs& kq) {
     const int idx = this->tid + NT * i;
-    const avaf4 o = Base::SAMEQ ? this->value_one(i, kq) : this->value_one(i, this->coef_of(i, coef));
+    const avaf4 o = Base::SAMEQ ? this->value_one(i, kq.k[i % Base::NKQ]) : this->value_one(i, this->coef_of(i, coef));
     ava_u32x2 p0, p1, p2;
     uint32_t a, b, c;
     ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
@@ -325,7 +338,7 @@ struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2> {
     }
   }
   __device__ __forceinline__ void store(unsigned char* __restrict__ lds, const float* __restrict__ coef) {
-    const Coef kq = this->coef_of(0, coef);
+    const Coefs kq = this->coefs_of(coef);
 #pragma unroll
     for (int i = 0; i < Base::NPF; ++i) store_one(i, lds, coef, kq);
   }
@@ -336,7 +349,7 @@ struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2> {
     unsigned nb = 0u;
     const TIN* __restrict__ base = ava_as<TIN>(in) + (size_t)b * Hi * Wi * CIN;
     const TIN2* __restrict__ base2 = PRO == PRO_BWD ? ava_as<TIN2>(in2) + (size_t)b * Hi * Wi * CIN : nullptr;
-    const Coef kq = this->coef_of(0, coef);
+    const Coefs kq = this->coefs_of(coef);
 #pragma unroll
     for (int i = 0; i < Base::NPF; ++i) {
       store_one(i, lds, coef, kq);

@@ -337,6 +337,17 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
   const bool do_colsum = g.colsum != nullptr && bx == 0;     // bias gradient: column sums of A (m-major A only)
   f32x4g acc = {0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
+  // wave 0's epilogue operands (bias, ReLU mask of the producing layer) are requested here, in front of the operand loads:
+  // fetched after the reduction barrier they were one more exposed memory latency in a kernel that is three latencies long
+  const int gn = n0 + i;
+  float bv = 0.f, mk[4] = {1.f, 1.f, 1.f, 1.f};
+  if (wave == 0 && gn < g.N) {
+    if (g.bias != nullptr) bv = g.bias[gn];
+    if (g.mask != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mk[r] = g.mask[(size_t)min(m0 + 4 * kg + r, g.M - 1) * g.ldc + gn];
+    }
+  }
   constexpr int U = 4;                            // chunks in flight per wave (8 measured slower)
   for (int c0 = wave; c0 < nchunks; c0 += nw * U) {
     f32x4g a[U], b[U];
@@ -386,9 +397,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
     for (int w = 1; w < nw; ++w) cs += cred[w][i];
     g.colsum[m0 + i] = cs;
   }
-  const int gn = n0 + i;
   if (gn >= g.N) return;
-  const float bv = g.bias != nullptr ? g.bias[gn] : 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gm = m0 + 4 * kg + r;
@@ -396,7 +405,7 @@ __device__ __forceinline__ void gemm_skinny_body(const GemmArgs& g, const int bx
       float v = acc[r];
       for (int w = 0; w + 1 < nw; ++w) v += red[w][lane][r];          // wave order: deterministic
       v = apply_act(v + bv, g.act);
-      if (g.mask != nullptr && !(g.mask[(size_t)gm * g.ldc + gn] > 0.f)) v = 0.f;
+      if (!(mk[r] > 0.f)) v = 0.f;
       g.C[(size_t)gm * g.ldc + gn] = v;
     }
   }

@@ -120,6 +120,18 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
       if (!AVA_ABL(4)) stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
     }
   }
+  // The matrix-core waves touch the packed weights now: their fragment loads come after the coefficient barrier, where a
+  // first-touch miss (every workgroup of the launch asks for the same 2-27 KB at once) was one more exposed memory latency
+  // of the prologue.  The values are only held until the barrier (the loads may not be dropped).
+  constexpr int WPF = (9 * CIN * COUT / 4 + 255) / 256;      // float4 per matrix-core thread
+  avaf4 wpf[WPF];
+  if (!stager) {
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) {
+      const int o = min((t - 256) + 256 * i, 9 * CIN * COUT / 4 - 1);
+      wpf[i] = *reinterpret_cast<const avaf4*>(a.G + 4 * o);
+    }
+  }
   if (a.fin.acc != nullptr) {
     // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h), by the first matrix-core wave, under
     // the staging waves' first tile load
@@ -130,6 +142,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
   }
   __syncthreads();                          // coef[] visible
+  if (!stager) {
+#pragma unroll
+    for (int i = 0; i < WPF; ++i) asm volatile("" ::"v"(wpf[i][0]), "v"(wpf[i][1]), "v"(wpf[i][2]), "v"(wpf[i][3]));
+  }
 
   if (stager) {
     // ---------------- staging waves ----------------

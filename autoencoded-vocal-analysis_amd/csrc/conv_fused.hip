@@ -381,23 +381,41 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
     if (walk.valid()) prefetch(walk.cur);    // tile 0 goes in flight BEFORE the coefficient prologue
   }
   __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
+  // Everything the prologue and the epilogue read from global memory is requested HERE, in front of the coefficient
+  // finalisation and its barrier: x's scale / shift, the packed data-gradient weights (touched: the fragment loads behind the
+  // barrier then hit) and the statistics the final reduction centres with.  Requested where they are used, each was one
+  // more exposed memory latency of a kernel whose skeleton is 15-27 us.
+  float cxv = 0.f;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    cxv = (sx != nullptr && c < CI) ? sx[c] : 0.f;
+  }
+  // (one float per 128-byte line and thread: 256 threads cover 32 KB, the largest weight array is 27 KB)
+  static_assert(9 * CI * CO * 4 <= 256 * 128, "one touch per thread covers the packed weights");
+  float wpf = 0.f;
+  __shared__ float ems[64];                   // mean [0..31], invstd [32..63] of x's BatchNorm for the final reduction
+  if (!stager) {
+    wpf = a.Gb[min(32 * (t - 256), 9 * CI * CO - 1)];
+    const int e = t - 320;                    // the SECOND matrix-core wave: the first one finalises the coefficients
+    if (e >= 0 && e < 64) {
+      const int c = e & 31;
+      ems[e] = c < CI ? (e < 32 ? a.mean[c] : a.invstd[c]) : 0.f;
+    }
+  }
   if (a.fin.acc != nullptr) {
     // A, Bc, Cc of the BatchNorm above finalised here from the accumulated sums of the kernel that ran before
     // (by the first matrix-core wave, under the staging waves' first tile load)
     bn_coef_from_acc(cd, accvals, a.fin, 256);
-    if (t < 96) {
-      const int which = t >> 5, c = t & 31;
-      const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
-      cx[t] = (sx != nullptr && c < CI) ? sx[c] : 0.f;
-    }
+    if (t < 96) cx[t] = cxv;
   } else if (t < 96) {
     const int which = t >> 5, c = t & 31;
-    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
     const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
-    cx[t] = (sx != nullptr && c < CI) ? sx[c] : 0.f;
+    cx[t] = cxv;
     cd[t] = (sd != nullptr && c < CO) ? sd[c] : 0.f;
   }
   __syncthreads();                           // cx / cd / zero pads visible
+  if (!stager) asm volatile("" ::"v"(wpf));
 
   if (stager) {
     // ---------------- staging waves ----------------
@@ -596,7 +614,7 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
       {
         // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here: sum g*xhat = invstd * (sum g*x - mean * sum g)
         const int cc = 16 * mt + cq + r;
-        const float mu = cc < CI ? a.mean[cc] : 0.f, is = cc < CI ? a.invstd[cc] : 0.f;
+        const float mu = ems[cc & 31], is = ems[32 + (cc & 31)];  // requested in the prologue (zero beyond CI)
         v2 = fmaf(-mu, v1, v2) * is;
       }
 #pragma unroll

@@ -123,15 +123,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   // The matrix-core waves touch the packed weights now: their fragment loads come after the coefficient barrier, where a
   // first-touch miss (every workgroup of the launch asks for the same 2-27 KB at once) was one more exposed memory latency
   // of the prologue.  The values are only held until the barrier (the loads may not be dropped).
-  constexpr int WPF = (9 * CIN * COUT / 4 + 255) / 256;      // float4 per matrix-core thread
-  avaf4 wpf[WPF];
-  if (!stager) {
-#pragma unroll
-    for (int i = 0; i < WPF; ++i) {
-      const int o = min((t - 256) + 256 * i, 9 * CIN * COUT / 4 - 1);
-      wpf[i] = *reinterpret_cast<const avaf4*>(a.G + 4 * o);
-    }
-  }
+  // (one float per 128-byte line and thread: 256 threads cover 32 KB, the largest weight array is 27 KB)
+  static_assert(9 * CIN * COUT * 4 <= 256 * 128, "one touch per thread covers the packed weights");
+  float wpf = 0.f;
+  if (!stager) wpf = a.G[min(32 * (t - 256), 9 * CIN * COUT - 1)];
   if (a.fin.acc != nullptr) {
     // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h), by the first matrix-core wave, under
     // the staging waves' first tile load
@@ -142,10 +137,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
   }
   __syncthreads();                          // coef[] visible
-  if (!stager) {
-#pragma unroll
-    for (int i = 0; i < WPF; ++i) asm volatile("" ::"v"(wpf[i][0]), "v"(wpf[i][1]), "v"(wpf[i][2]), "v"(wpf[i][3]));
-  }
+  if (!stager) asm volatile("" ::"v"(wpf));
 
   if (stager) {
     // ---------------- staging waves ----------------

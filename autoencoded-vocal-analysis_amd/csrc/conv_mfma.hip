@@ -503,13 +503,6 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int w
   float* cd = cx + 96;                            // [3][32]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n = lane & 15, kg = lane >> 4;
-  if (t < 96) {
-    const int which = t >> 5, c = t & 31;
-    const float* sx = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
-    const float* sd = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
-    cx[t] = (sx != nullptr && c < CIN) ? sx[c] : 0.f;
-    cd[t] = (sd != nullptr && c < COUT) ? sd[c] : 0.f;
-  }
   if (t < 16) dyt[TH * TW * COUT + t] = 0.f;
 
   WSplit<CIN, COUT, MODE, 0, IC> w0;
@@ -541,6 +534,15 @@ __device__ __forceinline__ void wgrad_split_body(const WgradArgs& a, const int w
     origin(walk.cur, b, oy0, ox0, gy0, gx0);
     sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy0, gx0);
     sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, oy0, ox0);
+  }
+  // the prologue coefficients are requested BEHIND the first tile (in front of it they were a serial memory latency of
+  // their own; now both are in flight together and the loop's first barrier covers the LDS writes)
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sx_ = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    const float* sd_ = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
+    cx[t] = (sx_ != nullptr && c < CIN) ? sx_[c] : 0.f;
+    cd[t] = (sd_ != nullptr && c < COUT) ? sd_[c] : 0.f;
   }
   for (; walk.valid(); walk.advance()) {
     __syncthreads();

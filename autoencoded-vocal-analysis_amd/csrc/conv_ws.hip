@@ -126,7 +126,15 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   // (one float per 128-byte line and thread: 256 threads cover 32 KB, the largest weight array is 27 KB)
   static_assert(9 * CIN * COUT * 4 <= 256 * 128, "one touch per thread covers the packed weights");
   float wpf = 0.f;
-  if (!stager) wpf = a.G[min(32 * (t - 256), 9 * CIN * COUT - 1)];
+  __shared__ float ems[64];                 // EPI_BWD: mean [0..31], invstd [32..63] of the statistics the final reduction centres with
+  if (!stager) {
+    wpf = a.G[min(32 * (t - 256), 9 * CIN * COUT - 1)];
+    const int e = t - 320;                  // the second matrix-core wave (the first one finalises the coefficients)
+    if (EPI == EPI_BWD && e >= 0 && e < 64) {
+      const int c = e & 31;
+      ems[e] = c < COUT ? (e < 32 ? a.epi_mean[c] : a.epi_invstd[c]) : 0.f;
+    }
+  }
   if (a.fin.acc != nullptr) {
     // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h), by the first matrix-core wave, under
     // the staging waves' first tile load
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
       if (EPI == EPI_BWD) {
         // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here: sum g*xhat = invstd * (sum g*x - mean * sum g)
         const int cc = 16 * (mtb + mt) + cq + r;
-        const float mu = cc < COUT ? a.epi_mean[cc] : 0.f, is = cc < COUT ? a.epi_invstd[cc] : 0.f;
+        const float mu = ems[cc & 31], is = ems[32 + (cc & 31)];      // requested in the prologue (zero beyond COUT)
         v2 = fmaf(-mu, v1, v2) * is;
       }
 #pragma unroll

@@ -319,7 +319,7 @@ class VAE(nn.Module):
         B = x.shape[0]
         self._ensure(B)
         self._generation += 1
-        _dist.apply_cu_reserve(_lib.load())        # data parallel: leave wave slots for the collective's workgroups
+        _dist.apply_cu_reserve(_lib.load(), False)  # no collective is in flight during a forward: grids for the whole chip
         if self.noise_source is None:
             # device counter RNG: the noise is drawn inside the forward's first launch (same stream as ava_fill_normal)
             n = B * (self.z_dim + 1)
@@ -359,10 +359,15 @@ class VAE(nn.Module):
         # then the encoder) is all-reduced asynchronously while the next part is still running
         # the "d not positive" word first: MAX over ranks, so that ava_adam_step's device-side guard and the epoch loop's
         # poll see the SAME word on every rank (one rank's NaN gradients reach every rank through the all-reduce below)
-        pending = [_dist.allreduce_max_async(self._status)]
+        # CU reserve (dist.cu_reserve): part 0 runs with no collective in flight -- the status word goes out behind it,
+        # with the first bucket -- so only parts 1 and 2 launch on grids that leave room for the collective's workgroups
+        pending = []
         for part in range(lib.ava_backward_num_parts()):
+            _dist.apply_cu_reserve(lib, part > 0)
             _lib.check(lib.ava_backward_part(self._handle, x.data_ptr(), x.shape[0], part, _lib.stream()),
                        "ava_backward_part")
+            if part == 0:
+                pending.append(_dist.allreduce_max_async(self._status))
             off, cnt = ctypes.c_int64(), ctypes.c_int64()
             _lib.check(lib.ava_grad_bucket(self._handle, part, ctypes.byref(off), ctypes.byref(cnt)), "ava_grad_bucket")
             if self._sharded_adam():
@@ -376,6 +381,7 @@ class VAE(nn.Module):
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         _dist.wait_all(pending)
+        _dist.apply_cu_reserve(lib, False)          # every collective of the step is complete: Adam and the next forward use the whole chip
         if evs is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()

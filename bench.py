@@ -368,7 +368,7 @@ def main():
                  "ranks_seen": world, "grad_allreduce_bytes_per_step": int(model._grads.numel()) * 4 if world > 1 else 0,
                  "buckets": _lib.load().ava_backward_num_parts() if world > 1 else 0,
                  # CUs every persistent grid leaves free for the collective's workgroups (dist.cu_reserve); sharded optimizer?
-                 "cu_reserve": _lib.load().ava_get_cu_reserve(), "sharded_adam": bool(model._sharded_adam()) if world > 1 else False}
+                 "cu_reserve": adist.cu_reserve() if world > 1 else 0, "cu_reserve_applies_to": "backward parts 1 and 2 (beside the bucket all-reduces)" if world > 1 else None, "sharded_adam": bool(model._sharded_adam()) if world > 1 else False}
     if world > 1:
         t = torch.ones(1, device="cuda")
         torch.distributed.all_reduce(t)

@@ -94,3 +94,24 @@ def test_single_process_is_passthrough():
     assert adist.allreduce_gradients(t) is t and not adist.active()
     assert adist.rank() == 0 and adist.world_size() == 1 and adist.global_dataset_len(7) == 7
     assert adist.global_loss(torch.tensor(5.0), 32, 10.0, 3) == 5.0
+
+
+def test_cu_reserve_is_applied_only_where_a_collective_is_in_flight(monkeypatch):
+    """dist.apply_cu_reserve: grids sized for 256 - r CUs only for the launches that run beside a collective (backward parts
+    1 and 2); the forward, backward part 0 and Adam get the whole chip; nothing is touched in a single-process run."""
+    from ava_amd import dist as adist
+
+    class Lib:
+        def __init__(self): self.calls = []
+        def ava_set_cu_reserve(self, v): self.calls.append(v); return 0
+
+    monkeypatch.setattr(adist, "_reserve_applied", None)
+    lib = Lib()
+    monkeypatch.setattr(adist, "active", lambda: False)
+    assert adist.apply_cu_reserve(lib, True) == 0 and adist.apply_cu_reserve(lib, False) == 0 and lib.calls == []
+    monkeypatch.setattr(adist, "active", lambda: True)
+    monkeypatch.delenv("AVA_CU_RESERVE", raising=False)
+    seq = [adist.apply_cu_reserve(lib, f) for f in (False, False, True, True, False)]     # forward, part 0, part 1, part 2, after the wait
+    assert seq == [0, 0, 32, 32, 0] and lib.calls == [0, 32, 0]
+    monkeypatch.setenv("AVA_CU_RESERVE", "16")
+    assert adist.apply_cu_reserve(lib, True) == 16 and lib.calls[-1] == 16

@@ -293,23 +293,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_to_nchw_kernel(const float* 
   __shared__ float tile[32][QPIX + 1];
   __shared__ float coef[96];
   __shared__ double accvals[64];
+  constexpr int NE = 32 * QPIX / 256;       // elements per thread and tile
+  const int nq = P / QPIX;
+  // The first tile's operands (the launch has one tile per workgroup at batch 256) are requested in front of the coefficient
+  // finalisation: behind it the kernel was five dependent round trips long (counters, parameters, g, f8, store).
+  float gv[NE], fv[NE];
+  {
+    const int w = blockIdx.x < nq * B ? blockIdx.x : 0, b = w / nq, q = w - b * nq;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = threadIdx.x + 256 * k, c = i / QPIX, p = i % QPIX;
+      gv[k] = g_nhwc[(size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i];                 // load_nhwc_quarter's element i
+      fv[k] = f8_nchw[(size_t)b * 32 * P + (size_t)c * P + q * QPIX + p];
+    }
+  }
   if (fin.acc != nullptr) {                 // bn8's A, Bc, Cc from the sums convt1's data-gradient kernel accumulated (bn_acc.h)
     bn_coef_from_acc(coef, accvals, fin, 0);
   } else {
     if (threadIdx.x < 32) { coef[threadIdx.x] = A[threadIdx.x]; coef[32 + threadIdx.x] = Bc[threadIdx.x]; coef[64 + threadIdx.x] = Cc[threadIdx.x]; }
     __syncthreads();
   }
-  const int nq = P / QPIX;
-  for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
+  bool first = true;
+  for (int w = blockIdx.x; w < nq * B; w += gridDim.x, first = false) {
     const int b = w / nq, q = w - b * nq;
     __syncthreads();
-    load_nhwc_quarter(tile, g_nhwc, b, q, P);
+    if (first) {
+#pragma unroll
+      for (int k = 0; k < NE; ++k) { const int i = threadIdx.x + 256 * k; tile[i & 31][i >> 5] = gv[k]; }
+    } else {
+      load_nhwc_quarter(tile, g_nhwc, b, q, P);
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
-      const int c = i / QPIX, p = i % QPIX;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = threadIdx.x + 256 * k, c = i / QPIX, p = i % QPIX;
       const size_t o = (size_t)b * 32 * P + (size_t)c * P + q * QPIX + p;
-      const float f = ava_stored_bn<ACT>(f8_nchw[o]);
-      out_nchw[o] = f > 0.f ? fmaf(coef[c], tile[c][p], fmaf(coef[32 + c], f, coef[64 + c])) : 0.f;
+      const float f = ava_stored_bn<ACT>(first ? fv[k] : f8_nchw[o]);
+      const float kA = coef[c], kB = coef[32 + c], kC = coef[64 + c];           // read unconditionally (not inside the select)
+      const float du = fmaf(kA, tile[c][p], fmaf(kB, f, kC));
+      out_nchw[o] = f > 0.f ? du : 0.f;
     }
   }
 }

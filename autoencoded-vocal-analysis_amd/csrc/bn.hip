@@ -270,12 +270,19 @@ __global__ __launch_bounds__(256) void relu_mask_to_nhwc_kernel(const float* __r
   for (int w = blockIdx.x; w < nq * B; w += gridDim.x) {
     const int b = w / nq, q = w - b * nq;
     __syncthreads();
+    // the mask operand is requested together with the tile (behind the barrier it was one more dependent round trip)
+    constexpr int NE = 32 * QPIX / 256;
+    float yv[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) yv[k] = y_nhwc[(size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + threadIdx.x + 256 * k];
     if (slab1 != nullptr) load_nchw_quarter_slabs(tile, dy_nchw, slab1, nullptr, 0, nullptr, b, q, P);
     else load_nchw_quarter(tile, dy_nchw, b, q, P);
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * QPIX; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = threadIdx.x + 256 * k;
       const size_t o = (size_t)b * 32 * P + (size_t)(q * QPIX) * 32 + i;
-      du_nhwc[o] = y_nhwc[o] > 0.f ? tile[i & 31][i >> 5] : 0.f;
+      du_nhwc[o] = yv[k] > 0.f ? tile[i & 31][i >> 5] : 0.f;
     }
   }
 }

@@ -47,6 +47,15 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
   if (gi < row) {
     const float* p = partials + gi;
     int r = rg;
+    // sixteen loads in flight per thread, consumed in the grouping of the four-at-a-time loop below (same sums, same
+    // order): with four in flight a thread went through 16 dependent round trips for 512 partial rows
+    for (; r + 120 < nparts; r += 128) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(r + 8 * k) * row];
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) s += ((double)v[k] + (double)v[k + 1]) + ((double)v[k + 2] + (double)v[k + 3]);
+    }
     for (; r + 24 < nparts; r += 32) {                // 4 independent loads in flight per thread
       const float a0 = p[(size_t)r * row], a1 = p[(size_t)(r + 8) * row];
       const float a2 = p[(size_t)(r + 16) * row], a3 = p[(size_t)(r + 24) * row];

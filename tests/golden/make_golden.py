@@ -407,11 +407,67 @@ def shotgun_case():
     return out
 
 
+# margin of the flip-free fixture per batch size: a fraction of a channel's rms that no ReLU pre-activation may come closer to
+# zero than.  The mean spacing of a channel's pre-activations near zero shrinks with the batch (B * H * W values per channel),
+# so the widest empty interval that exists within the allowed bias shift does too: 2e-5 at B = 8, 4e-6 at B = 64.
+FLIPFREE_MARGIN = {8: 2e-5, 64: 4e-6}
+
+
+def flipfree_case(B, z_dim=32):
+    """the REAL reference on the flip-free fixture (tests/flipfree.py: the Appendix-E parameters with the
+    ReLU layers' biases nudged so that no pre-activation of this batch lies within ``margin`` (relative to its channel's rms)
+    of zero).  No ReLU mask can differ between two correct evaluations there, so the reference's own fp32 gradients are a
+    flip-free target: loss, its three sums, all 80 gradient norms and sampled entries are stored, together with the nudged
+    biases (so that the test does not depend on re-deriving them bit for bit) and the margin actually reached."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from flipfree import flipfree_parameters
+    x = syn.spectrograms(B)
+    eps_w, eps_d = syn.noise(B, z_dim)
+    fp, min_rel = flipfree_parameters(syn.fixture_parameters(z_dim), x, eps_w, eps_d, margin=FLIPFREE_MARGIN[B])
+    out = {"margin": np.float64(FLIPFREE_MARGIN[B]), "min_rel": np.float64(min_rel)}
+    base = syn.fixture_parameters(z_dim)
+    for k in fp:
+        if k.endswith(".bias") and not np.array_equal(fp[k], base[k]):
+            out["bias." + k] = fp[k]
+    m = RefVAE(save_dir="", z_dim=z_dim, device_name="cpu")
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            p.copy_(torch.from_numpy(fp[name]))
+    m.train()
+    xt = torch.from_numpy(x)
+    # the three sums of the ELBO (a throw-away copy: encode/decode move the running statistics)
+    probe = RefVAE(save_dir="", z_dim=z_dim, device_name="cpu")
+    probe.load_state_dict(m.state_dict())
+    probe.train()
+    push_noise(eps_w, eps_d)
+    with torch.no_grad():
+        mu, u, d = probe.encode(xt)
+        dist = lrmvn.LowRankMultivariateNormal(mu, u, d)
+        zs = dist.rsample()
+        xr = probe.decode(zs)
+    out["sum_z2"] = float((zs.double() ** 2).sum())
+    out["sse"] = float(((xt.view(B, -1).double() - xr.double()) ** 2).sum())
+    out["sum_h"] = float(dist.entropy().double().sum())
+    m.optimizer.zero_grad()
+    push_noise(eps_w, eps_d)
+    loss = m.forward(xt)
+    out["loss"] = float(loss.item())
+    loss.backward()
+    grads_summary(m, out, "")
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "callers":
         torch.set_num_threads(8)
         np.savez_compressed(os.path.join(HERE, "callers.npz"), **callers_with_selfnoise())
         print("callers.npz written")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "flipfree":
+        for B in (8, 64):
+            out = flipfree_case(B)
+            np.savez_compressed(os.path.join(HERE, "flipfree_B%d_z32.npz" % B), **out)
+            print("flipfree B=%d: min |pre-activation| / rms = %.3g, loss = %r" % (B, out["min_rel"], out["loss"]))
         return
     if len(sys.argv) > 1 and sys.argv[1] == "shotgun":
         np.savez_compressed(os.path.join(HERE, "shotgun.npz"), **shotgun_case())
@@ -429,6 +485,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "callers.npz"), **callers_with_selfnoise())
     np.savez_compressed(os.path.join(HERE, "mmd.npz"), **mmd_case())
     np.savez_compressed(os.path.join(HERE, "shotgun.npz"), **shotgun_case())
+    for B in (8, 64):
+        np.savez_compressed(os.path.join(HERE, "flipfree_B%d_z32.npz" % B), **flipfree_case(B))
     assert not _QUEUE
     print("golden vectors written to", HERE)
 

@@ -105,6 +105,64 @@ def test_oracle_step_matches_reference(B, z, steps):
         assert rel(out["loss"], G["eval_fresh.loss"]) < 1e-5
 
 
+def flipfree_fixture(B, z=32):
+    """parameters of the flip-free golden (tests/golden/make_golden.py: flipfree_case): the Appendix-E fixture with the nudged
+    biases the golden stores; inputs and noise from the recipe"""
+    G = load_golden("flipfree_B%d_z%d.npz" % (B, z))
+    fp = syn.fixture_parameters(z)
+    for k, v in G.items():
+        if k.startswith("bias."):
+            fp[k[5:]] = v
+    ew, ed = syn.noise(B, z)
+    return G, fp, syn.spectrograms(B), ew, ed
+
+
+def assert_flipfree_gradients(grads, G, z, tol=1e-4):
+    """every one of the 80 tensors against the REAL reference's fp32 gradients on the flip-free fixture: norm and sampled
+    entries within `tol`, relative to the tensor's norm / largest entry.  conv1 / bn1 gradients are sums that cancel to ~1e-6
+    of their summands: "relative" there is against the conv1.bias gradient norm (same summands) when that is larger, as in
+    test_oracle_step_matches_reference.  No flip allowance anywhere: no ReLU mask of this fixture can differ."""
+    cb = float(G["gradnorm.conv1.bias"])
+    worst = {}
+    for s in param_specs(z):
+        g = np.asarray(grads[s.name], np.float64).ravel()
+        ref_n = float(G["gradnorm." + s.name])
+        scale = max(ref_n, cb if s.layer in ("conv1", "bn1") else 0.0)
+        e_norm = abs(np.sqrt((g * g).sum()) - ref_n) / scale
+        ref_s = np.asarray(G["grad." + s.name], np.float64)
+        e_smp = np.abs(g[sample_idx(g.size, s.index)] - ref_s).max() / max(np.abs(g).max(), scale / np.sqrt(g.size), 1e-300)
+        worst[s.name] = max(e_norm, e_smp)
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, bad
+    return max(worst.values())
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_oracle_flipfree_matches_reference(B):
+    """The oracle against the real reference where no ReLU mask can flip: every gradient tensor 1e-4, the
+    ELBO and its sums 1e-5 -- no flip-aware tolerances.  Also checks that the golden's fixture is what it says: no
+    pre-activation within the stored margin of zero (re-derived in float64 at B = 8)."""
+    z = 32
+    G, fp, x, ew, ed = flipfree_fixture(B, z)
+    assert float(G["min_rel"]) >= 0.95 * float(G["margin"])
+    P = O.to_params(fp, requires_grad=True)
+    out = O.forward(P, torch.from_numpy(x), torch.from_numpy(ew), torch.from_numpy(ed), None, True)
+    out["loss"].backward()
+    assert rel(float(out["loss"].detach()), G["loss"]) < 1e-5
+    for k in ("sum_z2", "sse", "sum_h"):
+        assert rel(float(out[k]), G[k]) < 1e-5, k
+    worst = assert_flipfree_gradients({k: v.grad.numpy() for k, v in P.items()}, G, z)
+    print("B=%d: fp32 oracle vs reference on the flip-free fixture: worst tensor %.2e" % (B, worst))
+    if B == 8:
+        import sys, os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from flipfree import flipfree_parameters
+        fp2, min_rel = flipfree_parameters(syn.fixture_parameters(z), x, ew, ed, margin=float(G["margin"]))
+        assert min_rel >= 0.95 * float(G["margin"])
+        for k in fp:
+            np.testing.assert_allclose(fp2[k], fp[k], rtol=0, atol=1e-6, err_msg=k)
+
+
 def test_oracle_get_latent_train_mode_quirk():
     G = load_golden("get_latent.npz")
     P = O.to_params(syn.fixture_parameters(32))

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ava_debug_materialize": (_i, [_p, _p, _i, _p]),
     "ava_set_cu_reserve": (_i, [_i]),
     "ava_get_cu_reserve": (_i, []),
+    "ava_model_set_cu_reserve": (_i, [_p, _i]),
+    "ava_model_get_cu_reserve": (_i, [_p]),
     "ava_occupy_cus": (_i, [_i, _i, _f, _p]),
     "ava_profile_enable": (_i, [_p, _i]),
     "ava_profile_read": (_i, [_p, C.POINTER(_f), C.POINTER(_i)]),

@@ -1,0 +1,536 @@
+// Fused backward of one conv / convT layer with BOTH products on the bf16 matrix cores (gfx950, v_mfma_f32_16x16x32_bf16),
+// fp32 operands as three bf16 limbs (x = x0 + x1 + x2 exactly; six limb products with i + j <= 2, fp32 accumulate: as close
+// to fp64 as the fp32 MFMA it replaces -- conv_common.h, gemm_limb.hip) at 6/16 of the fp32 MFMA's matrix time.
+// Same contract as conv3x3_bwd_fused_ws_kernel (conv_fused.hip): one staging of the dU window and of the layer-input window
+// feeds the data gradient (+ BatchNorm-backward sums) and the weight / bias gradient (reference: autograd's convolution
+// backward behind loss.backward(), ava/models/vae.py:352).
+//
+// What is different from the fp32 kernel:
+//  * LDS tiles are limb planes ([limb][channel octet][pixel][8] bf16, written by TileStagerL): a pixel's octet is one 16-byte
+//    slot.  The data-gradient phase reads them row-wise (ds_read_b128: 8 channels of one pixel = 8 consecutive k of the
+//    implicit GEMM, ClassFragL / PairFragL).  The weight-gradient phase sums over PIXELS (K = 32 consecutive dU pixels per
+//    MFMA), i.e. it needs 8 consecutive pixels of one channel per lane -- the transpose of the same image -- and reads it with
+//    ds_read_b64_tr_b16 (a 4-pixel x 16-channel block delivered column-major): no second image, no shuffles.
+//      A operand: M = 16 rows of (tap, ci), lane group g / lane 4q+p supplies the address of pixel k = 8g + 4h + q (+ tap
+//      offset of rows 4p..4p+3), channels ci(4p)..+3 -- 8 contiguous bytes of that pixel's slot; B operand: N = 16 output
+//      channels, same pixels, channels 4p..4p+3 of the dU slot.  D = dG rows (tap, ci) x co, the layout WClass::flush writes.
+//    The bias gradient is one more M row whose A operand is the constant 1 (limb 0 only): three MFMAs per K step.
+//  * The matrix-core waves are split by role: ND data-gradient waves (limb weights of the flipped kernel in registers, dx
+//    stores, BatchNorm-backward sums) and 4 - ND weight-gradient waves (accumulators persist over all tiles of the workgroup).
+//    The weight-gradient waves deal the M tiles among themselves (each sweeps ALL pixels of a tile for its rows), so a wave's
+//    rows of the partial result are final: no cross-wave reduction, the accumulators go to the partial row straight from
+//    registers.  Neither role's registers are live in the other's waves -- three limbs of weights (up to 84 VGPRs) and the
+//    accumulators (up to 80) do not fit one 128-register wave together.
+#include <stdlib.h>
+#include <type_traits>
+#include "conv_mfma.h"
+#include "conv_fused.h"
+
+typedef short ava_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char ava_lds_u8;
+typedef __attribute__((address_space(3))) ava_s16x4 ava_lds_s16x4;
+
+// 8 bf16 of one MFMA operand fragment by two transposed LDS reads: k sub-blocks 0..3 at p, 4..7 at p + HB
+template <int HB>
+__device__ __forceinline__ ava_bf16x8 ava_lds_tr8(ava_lds_u8* p) {
+  const ava_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<ava_lds_s16x4*>(p));
+  const ava_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<ava_lds_s16x4*>(p + HB));
+  return __builtin_bit_cast(ava_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// six limb products of one 16 x 16 x 32 step, smallest terms first (the order of ClassFragL::run)
+__device__ __forceinline__ f32x4 ava_limb_mfma6(const ava_bf16x8 (&a)[3], const ava_bf16x8 (&b)[3], f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
+template <int LMODE, int TW, int TH>
+struct FGeomL {
+  // x window [XR x XC], dU window [DR x DC], dU interior at offset (DOFF, DOFF), dx region [OH x OW]  (= conv_fused.hip: FGeom)
+  static constexpr int XR = LMODE == MODE_S1 ? TH + 2 : (LMODE == MODE_DOWN ? 2 * TH + 1 : TH + 1);
+  static constexpr int XC = LMODE == MODE_S1 ? TW + 2 : (LMODE == MODE_DOWN ? 2 * TW + 1 : TW + 1);
+  static constexpr int DR = LMODE == MODE_S1 ? TH + 2 : (LMODE == MODE_DOWN ? TH + 1 : 2 * TH + 1);
+  static constexpr int DC = LMODE == MODE_S1 ? TW + 2 : (LMODE == MODE_DOWN ? TW + 1 : 2 * TW + 1);
+  static constexpr int DOFF = LMODE == MODE_DOWN ? 0 : 1;
+  static constexpr int OH = LMODE == MODE_DOWN ? 2 * TH : TH;
+  static constexpr int OW = LMODE == MODE_DOWN ? 2 * TW : TW;
+};
+
+template <int N> using ava_ic = std::integral_constant<int, N>;
+
+// number of M tiles (units) of the weight gradient over all tap classes
+template <int LMODE> __host__ __device__ constexpr int wl_units(int cin) { return wsplit_base<LMODE>(n_classes<LMODE>(), cin); }
+
+// ACT: storage type of the activations x (layer input) and dy2 (saved output); dy and dx are fp32 gradients.
+// ND: data-gradient waves (1 or 2); the other 4 - ND matrix-core waves form the weight gradient.
+// WPS: minimum waves per SIMD for the register allocator (4: two workgroups per CU, 128 VGPRs; 2: one per CU, 256 VGPRs)
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int ND, int WPS, typename ACT>
+__global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const FusedArgs a) {
+  using FG = FGeomL<LMODE, TW, TH>;
+  constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
+  constexpr int BMODE = LMODE == MODE_S1 ? MODE_S1 : (LMODE == MODE_DOWN ? MODE_UP : MODE_DOWN);   // gather pattern of dx
+  constexpr int MT = (CI + 15) / 16;        // dx channel tiles
+  constexpr int NT = (CO + 15) / 16;        // dG column tiles
+  constexpr int NW_ = 9 * CI * CO;
+  constexpr int BCLS = n_classes<BMODE>(), WCLS = n_classes<LMODE>();
+  constexpr int NWV = 4 - ND;               // weight-gradient waves
+  static_assert(ND == 1 || ND == 2, "one or two data-gradient waves");
+  static_assert(CI % 8 == 0 && CO % 8 == 0, "limb planes are made of channel octets");
+  // stride-1 layers with 8 input channels: the data gradient has 8 output channels -> two dx rows per MFMA tile
+  constexpr bool PAIR = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
+  // two dx channel tiles and two data-gradient waves: each wave takes one tile for ALL pixel groups (half the limb weights)
+  constexpr bool DSPLIT = MT == 2 && ND == 2;
+  constexpr int MTD = DSPLIT ? 1 : MT;
+  constexpr int XNPIX = XR * XC, DNPIX = DR * DC;
+  constexpr int XPLANE = (CI / 8) * XNPIX * 16, DPLANE = (CO / 8) * DNPIX * 16;      // bytes
+  constexpr int XBYTES = 3 * XPLANE, BUF = XBYTES + 3 * DPLANE;
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  float* cx = reinterpret_cast<float*>(smem_b + 2 * BUF);     // [3][32]
+  float* cd = cx + 96;                                         // [3][32]
+  float* red = cd + 96;                                        // [ND][32 * MT]
+  __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
+  __shared__ float ems[64];                 // mean [0..31], invstd [32..63] of x's BatchNorm for the final reduction
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool stager = wave8 < 4;             // waves 0-3 stage tiles, 4 .. 4+ND-1 data gradient, the rest weight gradient
+  const int n = lane & 15, kg = lane >> 4;
+
+  // tile -> image, low-resolution origin, window origins
+  auto origin = [&](int tl, int& b, int& y0, int& x0) {
+    b = tl / (a.tiles_y * a.tiles_x);
+    const int rem = tl - b * (a.tiles_y * a.tiles_x);
+    y0 = (rem / a.tiles_x) * TH;
+    x0 = (rem % a.tiles_x) * TW;
+  };
+  auto x_origin = [&](int y0, int x0, int& gy, int& gx) {
+    if (LMODE == MODE_S1) { gy = y0 - 1; gx = x0 - 1; }
+    else if (LMODE == MODE_DOWN) { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
+    else { gy = y0; gx = x0; }
+  };
+  auto d_origin = [&](int y0, int x0, int& gy, int& gx) {
+    if (LMODE == MODE_S1) { gy = y0 - 1; gx = x0 - 1; }
+    else if (LMODE == MODE_DOWN) { gy = y0; gx = x0; }
+    else { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
+  };
+  TileWalk walk(a.ntiles);
+  TileStagerL<CI, PRO_BN, XR, XC, 256, ACT, ACT> sx;          // staging waves only (threadIdx.x 0..255)
+  TileStagerL<CO, DYPRO, DR, DC, 256, float, ACT> sd;
+  auto prefetch = [&](int tl) {
+    int b, y0, x0, gy, gx;
+    origin(tl, b, y0, x0);
+    x_origin(y0, x0, gy, gx);
+    sx.load(a.x, nullptr, b, a.Hi, a.Wi, gy, gx);
+    d_origin(y0, x0, gy, gx);
+    sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
+  };
+  if (stager) {
+    sx.init();
+    sd.init();
+    if (walk.valid()) prefetch(walk.cur);    // tile 0 goes in flight BEFORE the coefficient prologue
+  }
+  // everything the prologue and the epilogue read from global memory is requested in front of the coefficient finalisation
+  // and its barrier (conv_fused.hip)
+  float cxv = 0.f;
+  if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sxp = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
+    cxv = (sxp != nullptr && c < CI) ? sxp[c] : 0.f;
+  }
+  static_assert(9 * CI * CO * 4 <= 256 * 128, "one touch per thread covers the packed weights");
+  float wpf = 0.f;
+  if (!stager) {
+    wpf = a.Gb[min(32 * (t - 256), 9 * CI * CO - 1)];
+    const int e = t - 320;                    // the SECOND matrix-core wave: the first one finalises the coefficients
+    if (e >= 0 && e < 64) {
+      const int c = e & 31;
+      ems[e] = c < CI ? (e < 32 ? a.mean[c] : a.invstd[c]) : 0.f;
+    }
+  }
+  if (a.fin.acc != nullptr) {
+    bn_coef_from_acc(cd, accvals, a.fin, 256);
+    if (t < 96) cx[t] = cxv;
+  } else if (t < 96) {
+    const int which = t >> 5, c = t & 31;
+    const float* sdp = which == 0 ? a.da : (which == 1 ? a.db : a.dc);
+    cx[t] = cxv;
+    cd[t] = (sdp != nullptr && c < CO) ? sdp[c] : 0.f;
+  }
+  __syncthreads();                           // cx / cd visible
+  if (!stager) asm volatile("" ::"v"(wpf));
+
+  if (stager) {
+    // ---------------- staging waves ----------------
+    __builtin_amdgcn_s_setprio(3);           // issue priority over the matrix-core waves of the same SIMD (conv_fused.hip)
+    if (walk.valid()) {
+      sx.store(smem_b, cx);
+      sd.store(smem_b + XBYTES, cd);
+      if (walk.has_next()) prefetch(walk.next());
+    }
+    __syncthreads();                                            // (A) tile 0 ready
+    int it = 0;
+    for (; walk.valid(); walk.advance(), ++it) {
+      if (walk.has_next()) {                                    // tile it+1 -> the other buffer, tile it+2 in flight
+        unsigned char* nb = smem_b + ((it + 1) & 1) * BUF;
+        sx.store(nb, cx);
+        sd.store(nb + XBYTES, cd);
+        const int nn = walk.next() + walk.step;
+        if (nn < walk.end) prefetch(nn);
+      }
+      __syncthreads();                                          // (B)
+    }
+    __syncthreads();                                            // (E) the reduction barrier of the matrix-core waves
+    return;
+  }
+
+  if (wave8 < 4 + ND) {
+    // ---------------- data-gradient waves ----------------
+    const int dw = wave8 - 4;
+    const int mtb = DSPLIT ? dw : 0;                            // first dx channel tile of this wave
+    constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
+    typename std::conditional<PAIR, PairFragL<CO, DC, DNPIX>, ClassFragL<CO, CI, BMODE, 0, DC, DNPIX, MTD>>::type f0;
+    ClassFragL<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC, DNPIX, MTD> f1;
+    ClassFragL<CO, CI, BMODE, (BCLS > 1 ? 2 : 0), DC, DNPIX, MTD> f2;
+    ClassFragL<CO, CI, BMODE, (BCLS > 1 ? 3 : 0), DC, DNPIX, MTD> f3;
+    f0.init(a.Gb, lane, SPB * n, mtb);
+    if (BCLS > 1) { f1.init(a.Gb, lane, n, mtb); f2.init(a.Gb, lane, n, mtb); f3.init(a.Gb, lane, n, mtb); }
+    const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
+    const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
+    float s1[MTD][4], s2[MTD][4];
+#pragma unroll
+    for (int mt = 0; mt < MTD; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s1[mt][r] = s2[mt][r] = 0.f;
+
+    // pixel groups of the dx region: 16 consecutive pixels of a row (UP pattern: of one parity class)
+    constexpr int CB = FG::OW / (BMODE == MODE_UP ? 32 : 16);          // column blocks
+    constexpr int GROUPS = PAIR ? (FG::OH / 2) * CB : (BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB);
+    constexpr int GPW = DSPLIT ? GROUPS : GROUPS / ND;
+    static_assert(GROUPS % ND == 0 && (BMODE != MODE_UP || GPW % 4 == 0), "tile must split evenly over the data-gradient waves");
+    const int g0 = DSPLIT ? 0 : dw * GPW;
+    auto group_out = [&](int g) -> int {
+      if (BMODE == MODE_UP) {
+        const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
+        return ((2 * r + (cls >> 1)) * a.Wi + 32 * cb + (cls & 1)) * CI;
+      }
+      return (((PAIR ? 2 : 1) * (g / CB)) * a.Wi + 16 * (g % CB)) * CI;
+    };
+    // raw x at this lane's dx pixels (BatchNorm-backward sums), loaded one tile ahead (conv_fused.hip)
+    avaf4 ex[GPW * MTD];
+    auto load_ex = [&](int tl) {
+      int b, y0, x0;
+      origin(tl, b, y0, x0);
+      const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+      const ACT* __restrict__ xb = ava_as<ACT>(a.x) + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
+#pragma unroll
+      for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) {
+          const int cb4 = 16 * (mtb + mt) + cq;
+          // lanes whose 4-channel slot lies beyond CI re-read slot 0: stays in bounds
+          ex[gi * MTD + mt] = ava_ld4<ACT>(xb + group_out(g0 + gi) + (cb4 < CI ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
+        }
+    };
+    if (walk.valid()) load_ex(walk.cur);
+    __syncthreads();                                              // (A)
+    int it = 0;
+    for (; walk.valid(); walk.advance(), ++it) {
+      int b, y0, x0;
+      origin(walk.cur, b, y0, x0);
+      const unsigned char* dut = smem_b + (it & 1) * BUF + XBYTES;
+      const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+      const size_t tile_pix = ((size_t)b * a.Hi + oy0) * a.Wi + ox0;
+      float* __restrict__ obase = a.dx + tile_pix * CI;
+#pragma unroll
+      for (int gi = 0; gi < GPW; ++gi) {
+        const int g = g0 + gi;
+        f32x4 acc[2][MTD];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int mt = 0; mt < MTD; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (BMODE == MODE_UP) {
+          const int cls = gi & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;   // GPW % 4 == 0: cls is compile-time
+          const unsigned char* px = dut + (r * DC + 16 * cb) * 16;
+          if (cls == 0) f0.run(px, acc);
+          else if (cls == 1) f1.run(px, acc);
+          else if (cls == 2) f2.run(px, acc);
+          else f3.run(px, acc);
+        } else {
+          constexpr int S = (BMODE == MODE_S1 && !PAIR) ? 1 : 2;        // PAIR: a group is a pair of dx rows
+          constexpr int SX = BMODE == MODE_DOWN ? 2 : 1;
+          f0.run(dut + (S * (g / CB) * DC + SX * 16 * (g % CB)) * 16, acc);
+        }
+        const int gout = group_out(g) + lane_out;
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) {
+          const int cb4 = 16 * (mtb + mt) + cq;
+          if (cb4 < CI) {
+            const f32x4 v = acc[0][mt] + acc[1][mt];
+            const avaf4 xr = ex[gi * MTD + mt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s1[mt][r] += v[r];
+              s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
+            }
+            *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+      if (walk.has_next()) load_ex(walk.next());
+      __syncthreads();                                            // (B)
+    }
+    // ---- BatchNorm-backward partial sums: over the 16 pixel lanes, then over the data-gradient waves (fixed order) ----
+#pragma unroll
+    for (int mt = 0; mt < MTD; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v1 = s1[mt][r], v2 = s2[mt][r];
+        {
+          // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here
+          const int cc = 16 * (mtb + mt) + cq + r;
+          const float mu = ems[cc & 31], is = ems[32 + (cc & 31)];  // requested in the prologue (zero beyond CI)
+          v2 = fmaf(-mu, v1, v2) * is;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+        if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair
+        if (n == 0 && (!PAIR || kg < 2)) {
+          const int ci = 16 * (mtb + mt) + cq + r;
+          red[dw * 32 * MT + ci] = v1;
+          red[dw * 32 * MT + 16 * MT + ci] = v2;
+        }
+      }
+    __syncthreads();                                              // (E)
+    const int tc = t - 256;                                       // first data-gradient wave: 2 * CI <= 64 lanes
+    if (tc < 2 * CI) {
+      const int which = tc / CI, ci = tc - which * CI;
+      const int idx = which * 16 * MT + ci;
+      float tot;
+      if (DSPLIT) tot = red[(ci >> 4) * 32 * MT + idx];           // a channel tile belongs to one wave
+      else if (ND == 2) tot = red[idx] + red[32 * MT + idx];
+      else tot = red[idx];
+      if (a.acc_out != nullptr) bn_acc_add(a.acc_out, which * 32 + ci, tot);
+      else a.bn_partials[(size_t)blockIdx.x * 2 * CI + tc] = tot;
+    }
+    return;
+  }
+
+  // ---------------- weight-gradient waves ----------------
+  // Units: the M tiles (16 rows of (tap, ci)) of every tap class, numbered class by class, plus the bias row as unit NU.
+  // Unit u belongs to wave u % NWV, slot u / NWV.  K = 32 pixels per step: KW consecutive pixels of 32 / KW rows.
+  constexpr int NU = wl_units<LMODE>(CI);
+  constexpr int MAXOWN = (NU + 1 + NWV - 1) / NWV;
+  constexpr int KW = TW >= 32 ? 32 : TW;                     // pixels of one row inside a K step
+  static_assert(KW == 32 || KW == 16, "K steps are 32 pixels: one row of 32 or two rows of 16");
+  constexpr int KSTEPS = TH * TW / 32;
+  static_assert((TH * TW) % 32 == 0 && (KW == 32 || TH % 2 == 0), "tile must be made of whole K steps");
+  constexpr int SA = LMODE == MODE_DOWN ? 2 : 1;             // x-window pixels per step pixel
+  constexpr int SB = LMODE == MODE_UP ? 2 : 1;               // dU-window pixels per step pixel
+  const int ww = wave8 - 4 - ND;                             // wave-uniform
+  ava_lds_u8* const lbase = (ava_lds_u8*)smem_b;
+  // lane's pixel inside a K step (k sub-block 0): lane group g = lane >> 4 holds k = 8 g + {0..7}; lane 4 q + p of the group
+  // supplies the address of k = 8 g + q (second read: + 4), columns 4 p .. 4 p + 3
+  const int q = n >> 2, p = n & 3;
+  const int k0 = 8 * kg + q, kr = k0 / KW, kc = k0 % KW;
+
+  auto w_role = [&](auto ww_c) __attribute__((always_inline)) {
+    constexpr int WW = decltype(ww_c)::value;
+    constexpr int NOWN = (NU + 1 - WW + NWV - 1) / NWV;       // units WW, WW + NWV, ...
+    constexpr bool OWNS_BIAS = NU % NWV == WW;
+    int offA[NOWN > 0 ? NOWN : 1];
+    f32x4 acc[NOWN > 0 ? NOWN : 1][NT];
+    int offB[NT];
+    // ---- per-lane LDS byte offsets (plane 0, k sub-block 0, step origin 0) ----
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int co4 = 16 * nt + 4 * p;
+      if (co4 >= CO) co4 -= 8;                                 // padding columns re-read valid channels (results unused)
+      offB[nt] = ((co4 >> 3) * DNPIX + (SB * kr + DOFF) * DC + SB * kc + DOFF) * 16 + (co4 & 7) * 2;
+    }
+    auto for_units = [&](auto&& fn) __attribute__((always_inline)) {
+      // fn(class, tile in class, unit) for every M tile, classes in order
+      auto one = [&](auto cls_c) __attribute__((always_inline)) {
+        constexpr int CLS = decltype(cls_c)::value;
+        constexpr int MTK = (n_taps<LMODE>(CLS) * CI + 15) / 16;
+        constexpr int UB = wsplit_base<LMODE>(CLS, CI);
+#pragma unroll
+        for (int mt = 0; mt < MTK; ++mt) fn(cls_c, mt, UB + mt);
+      };
+      one(ava_ic<0>{});
+      if constexpr (WCLS > 1) { one(ava_ic<1>{}); one(ava_ic<2>{}); one(ava_ic<3>{}); }
+    };
+    for_units([&](auto cls_c, int mt, int u) __attribute__((always_inline)) {
+      constexpr int CLS = decltype(cls_c)::value;
+      constexpr int KROWS = n_taps<LMODE>(CLS) * CI;
+      if (u % NWV == WW) {
+        const int mm = 16 * mt + 4 * p;
+        int tapg, ci, dr, dc;
+        WClass<CI, CO, LMODE, CLS, XC>::tap_of_row(mm < KROWS ? mm : 0, tapg, ci, dr, dc);
+        offA[u / NWV] = ((ci >> 3) * XNPIX + (SA * kr + dr) * XC + SA * kc + dc) * 16 + (ci & 7) * 2;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[u / NWV][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    });
+    if (OWNS_BIAS) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[NU / NWV][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // the bias row's A operand: 1 in limb 0 of M row 0 (lanes 0, 16, 32, 48: all 8 k), 0 elsewhere
+    ava_bf16x8 ones;
+    {
+      const uint32_t v = n == 0 ? 0x3f803f80u : 0u;
+      const ava_u32x4 vv = {v, v, v, v};
+      ones = __builtin_bit_cast(ava_bf16x8, vv);
+    }
+
+    __syncthreads();                                              // (A)
+    int it = 0;
+    for (; walk.valid(); walk.advance(), ++it) {
+      ava_lds_u8* const xl = lbase + (it & 1) * BUF;
+      ava_lds_u8* const dl = xl + XBYTES;
+#pragma unroll 1
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        // step origin in step-pixel units (dU interior pixels; LMODE_UP: x pixels)
+        const int sy = KW == 32 ? ks / (TW / 32) : 2 * ks, sx0 = KW == 32 ? 32 * (ks % (TW / 32)) : 0;
+        ava_lds_u8* const xs = xl + (SA * sy * XC + SA * sx0) * 16;
+        ava_lds_u8* const ds = dl + (SB * sy * DC + SB * sx0) * 16;
+        auto one = [&](auto cls_c) __attribute__((always_inline)) {
+          constexpr int CLS = decltype(cls_c)::value;
+          constexpr int MTK = (n_taps<LMODE>(CLS) * CI + 15) / 16;
+          constexpr int UB = wsplit_base<LMODE>(CLS, CI);
+          constexpr int CLSOFF = LMODE == MODE_UP ? ((CLS >> 1) * DC + (CLS & 1)) * 16 : 0;    // output parity (py, px)
+          ava_bf16x8 bfr[NT][3];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int L = 0; L < 3; ++L) bfr[nt][L] = ava_lds_tr8<4 * SB * 16>(ds + offB[nt] + L * DPLANE + CLSOFF);
+          if (OWNS_BIAS) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              f32x4 c = acc[NU / NWV][nt];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[nt][2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[nt][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[nt][0], c, 0, 0, 0);
+              acc[NU / NWV][nt] = c;
+            }
+          }
+#pragma unroll
+          for (int mt = 0; mt < MTK; ++mt) {
+            if ((UB + mt) % NWV == WW) {
+              constexpr int dummy = 0; (void)dummy;
+              const int sl = (UB + mt) / NWV;
+              ava_bf16x8 afr[3];
+#pragma unroll
+              for (int L = 0; L < 3; ++L) afr[L] = ava_lds_tr8<4 * SA * 16>(xs + offA[sl] + L * XPLANE);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[sl][nt] = ava_limb_mfma6(afr, bfr[nt], acc[sl][nt]);
+            }
+          }
+        };
+        one(ava_ic<0>{});
+        if constexpr (WCLS > 1) { one(ava_ic<1>{}); one(ava_ic<2>{}); one(ava_ic<3>{}); }
+      }
+      __syncthreads();                                            // (B)
+    }
+    __syncthreads();                                              // (E)
+    // ---- this wave's rows of the partial result, straight from the accumulators (gather layout [tap][ci][co] + bias) ----
+    float* __restrict__ prow = a.wg_partials + (size_t)blockIdx.x * (NW_ + CO);
+    for_units([&](auto cls_c, int mt, int u) __attribute__((always_inline)) {
+      constexpr int CLS = decltype(cls_c)::value;
+      constexpr int KROWS = n_taps<LMODE>(CLS) * CI;
+      if (u % NWV == WW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mm = 16 * mt + 4 * kg + r;
+          if (mm < KROWS) {
+            int tapg, ci, dr, dc;
+            WClass<CI, CO, LMODE, CLS, XC>::tap_of_row(mm, tapg, ci, dr, dc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int co = 16 * nt + n;
+              if (co < CO) prow[(tapg * CI + ci) * CO + co] = acc[u / NWV][nt][r];
+            }
+          }
+        }
+      }
+    });
+    if (OWNS_BIAS && kg == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = 16 * nt + n;
+        if (co < CO) prow[NW_ + co] = acc[NU / NWV][nt][0];
+      }
+    }
+  };
+  if (ww == 0) w_role(ava_ic<0>{});
+  else if (NWV > 1 && ww == 1) w_role(ava_ic<(NWV > 1 ? 1 : 0)>{});
+  else if (NWV > 2) w_role(ava_ic<(NWV > 2 ? 2 : 0)>{});
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int ND, int WPS, typename ACT>
+static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
+  using FG = FGeomL<LMODE, TW, TH>;
+  constexpr int MT = (CI + 15) / 16;
+  constexpr size_t buf = (size_t)3 * 16 * ((CI / 8) * FG::XR * FG::XC + (CO / 8) * FG::DR * FG::DC);
+  constexpr size_t lds = 2 * buf + (192 + 2 * 32 * MT) * sizeof(float);
+  static_assert(lds + 1024 <= (WPS == 4 ? 80 : 160) * 1024, "two workgroups per CU need two tile-buffer pairs in 160 KB of LDS");
+  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, ND, WPS, ACT>);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVA_ELAUNCH;
+    attr_set = true;
+  }
+  FusedArgs b = a;
+  const int hl = LMODE == MODE_DOWN ? a.Ho : a.Hi, wl = LMODE == MODE_DOWN ? a.Wo : a.Wi;   // low-resolution side
+  if (hl % TH != 0 || wl % TW != 0) return AVA_EINVAL;
+  b.tiles_y = hl / TH;
+  b.tiles_x = wl / TW;
+  b.ntiles = a.B * b.tiles_y * b.tiles_x;
+  if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
+  hipLaunchKernelGGL((conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, ND, WPS, ACT>), dim3(grid), dim3(512), lds, st, b);
+  AVA_CHECK_LAUNCH();
+  return AVA_OK;
+}
+
+template <int CI, int CO, int LMODE, int TW, int TH, int ND, int WPS>
+static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream_t st) {
+  if (dy_pro == PRO_BWD) {
+    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, ND, WPS, ava_bf16>(a, grid, st);
+    return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, ND, WPS, float>(a, grid, st);
+  }
+  if (dy_pro == PRO_ID) {
+    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, ND, WPS, ava_bf16>(a, grid, st);
+    return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, ND, WPS, float>(a, grid, st);
+  }
+  return AVA_EINVAL;
+}
+
+// Shapes with a limb instantiation: (cin, cout, mode) -> low-resolution tile (the fp32 kernel's, so that the grid and the
+// partial-row count of ava_conv_fused_grid_for hold for both), data-gradient waves, waves per SIMD.
+#define AVA_FUSED_LIMB_SHAPES(X) \
+  X(8, 16, MODE_S1, 32, 4, 2, 4)  \
+  X(16, 8, MODE_S1, 32, 4, 2, 4)
+
+bool ava_conv_fused_limb_has(int Cin, int Cout, int mode) {
+#define X(ci, co, md, tww, thh, nd, wps) if (Cin == ci && Cout == co && mode == md) return true;
+  AVA_FUSED_LIMB_SHAPES(X)
+#undef X
+  return false;
+}
+
+// AVA_EINVAL when the shape has no limb instantiation (the caller then runs the fp32 kernel)
+int ava_conv3x3_bwd_fused_limb_launch(const FusedArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
+  if (a.rcd.G1 != nullptr || a.rc.G1 != nullptr || a.dx == nullptr) return AVA_EINVAL;
+#define X(ci, co, md, tww, thh, nd, wps) \
+  if (Cin == ci && Cout == co && mode == md) return launch_fused_limb<ci, co, md, tww, thh, nd, wps>(a, grid, dy_pro, st);
+  AVA_FUSED_LIMB_SHAPES(X)
+#undef X
+  return AVA_EINVAL;
+}

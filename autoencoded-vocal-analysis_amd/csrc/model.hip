@@ -153,7 +153,10 @@ struct ava_model {
   float* Gf[NCONV];
   float* Gb[NCONV];
   float *gA, *gB;           // gradient ping-pong, B*131072 floats each
-  int dy7_slabs;            // 2: fc1's dX of the last backward part 1 sits in the GEMM workspace as two split-K slabs
+  int dy7_slabs;            // 2: fc1's dX of the last backward sits in dy7_ws as two split-K slabs (summed by part 3's layout kernel)
+  float* dy7_ws;            // workspace of that ONE product only: no other launch may reuse it between the backward parts
+  size_t dy7_ws_bytes;
+  int cu_reserve;           // CUs this model's persistent grids leave free (ava_model_set_cu_reserve); -1: the process-wide setting
   float* wg_part[NCONV];    // wgrad partial rows, one region per layer (reduced in one launch at the end)
   float *dF8, *dh7, *dh6, *dh5, *dz, *dmu, *du, *dlogd, *dh3, *dh2, *dh1, *dy7;
   float* gemm_ws;
@@ -191,7 +194,10 @@ struct Carver {
   }
 };
 
-static size_t max_gemm_ws(int z, int B, int F) {
+// largest split-K workspace any product of a step needs, for EVERY batch size up to maxB: the split plans are not monotonic
+// in the batch (a 128-row product may run as four slabs where the 256-row one runs as two), and a model created for a large
+// batch also runs smaller ones
+static size_t max_gemm_ws_at(int z, int B, int F) {
   size_t mx = 0;
   const int shapes[][3] = {{B, 1024, F}, {B, 256, 1024}, {B, 192, 256}, {B, z, 64}, {B, 64, z}, {B, 256, 64},
                            {B, 1024, 256}, {B, F, 1024},
@@ -205,6 +211,16 @@ static size_t max_gemm_ws(int z, int B, int F) {
     size_t b = ava_gemm_workspace_bytes(s[0], s[1], s[2]);
     if (b > mx) mx = b;
   }
+  return mx;
+}
+static size_t max_gemm_ws(int z, int maxB, int F) {
+  size_t mx = 0;
+  for (int b = 1; b <= maxB; ++b) { const size_t v = max_gemm_ws_at(z, b, F); if (v > mx) mx = v; }
+  return mx;
+}
+static size_t max_dy7_ws(int maxB, int F) {
+  size_t mx = 0;
+  for (int b = 1; b <= maxB; ++b) { const size_t v = ava_gemm_workspace_bytes(b, F, 1024); if (v > mx) mx = v; }
   return mx;
 }
 
@@ -249,6 +265,8 @@ static void carve(ava_model* m, void* ws, size_t* total) {
   m->dh3 = c.take(B * 192); m->dh2 = c.take(B * 256); m->dh1 = c.take(B * 1024); m->dy7 = c.take(B * F);
   m->gemm_ws_bytes = max_gemm_ws(z, (int)B, m->F);
   m->gemm_ws = c.take(m->gemm_ws_bytes / sizeof(float) + 64);
+  m->dy7_ws_bytes = max_dy7_ws((int)B, m->F);
+  m->dy7_ws = c.take(m->dy7_ws_bytes / sizeof(float) + 64);
   m->loss_dev = c.take(64);
   m->status_dev = reinterpret_cast<int*>(c.take(64));
   *total = c.off;
@@ -256,16 +274,34 @@ static void carve(ava_model* m, void* ws, size_t* total) {
 
 extern "C" int ava_version(void) { return 100; }
 
-// CUs left free by every persistent launch (common.h: ava_scale_grid).  Process-wide: the grids are sized deep inside the
-// launchers; set it before the first step of a run and leave it (the data-parallel binding does, dist.py).
-static int g_cu_reserve = 0;
-int ava_cu_reserve(void) { return g_cu_reserve; }
+// CUs left free by every persistent launch (common.h: ava_scale_grid).  The grids are sized deep inside the launchers, which
+// read the CURRENT value: a thread-local that every model entry point (forward, backward part, Adam, encode, decode) sets for
+// its own duration from the model's setting (ava_model_set_cu_reserve; -1 = the process-wide default below) and restores on
+// return (ReserveScope).  So a producer / consumer pair of launches inside one entry point (partial rows written by one
+// kernel, counted by the next) always sees one value, two models or two host threads cannot disturb each other, and the
+// per-kernel entry points (ava_conv3x3 ..., tests and tools) run under the process-wide default.
+static int g_cu_reserve_default = 0;
+static thread_local int t_cu_reserve = -1;             // -1: no model entry point is active on this thread
+int ava_cu_reserve(void) { return t_cu_reserve >= 0 ? t_cu_reserve : g_cu_reserve_default; }
 extern "C" int ava_set_cu_reserve(int cus) {
   if (cus < 0 || cus > 128) return AVA_EINVAL;
-  g_cu_reserve = cus;
+  g_cu_reserve_default = cus;
   return AVA_OK;
 }
-extern "C" int ava_get_cu_reserve(void) { return g_cu_reserve; }
+extern "C" int ava_get_cu_reserve(void) { return g_cu_reserve_default; }
+struct ReserveScope {
+  int saved;
+  explicit ReserveScope(const ava_model* m) : saved(t_cu_reserve) {
+    if (m != nullptr) t_cu_reserve = m->cu_reserve >= 0 ? m->cu_reserve : g_cu_reserve_default;
+  }
+  ~ReserveScope() { t_cu_reserve = saved; }
+};
+extern "C" int ava_model_set_cu_reserve(ava_model* m, int cus) {
+  if (m == nullptr || cus < -1 || cus > 128) return AVA_EINVAL;
+  m->cu_reserve = cus;
+  return AVA_OK;
+}
+extern "C" int ava_model_get_cu_reserve(const ava_model* m) { return m == nullptr ? -1 : m->cu_reserve; }
 
 // Test / measurement helper: `workgroups` persistent 256-thread workgroups that hold their wave slots for `usec`
 // microseconds (s_memrealtime, 100 MHz) and do nothing else -- stands in for a collective's persistent kernel on a side
@@ -358,6 +394,8 @@ extern "C" int ava_model_create_ex(ava_model** out, int z_dim, int H, int W, int
   if (need > workspace_bytes) { delete m; return AVA_EWORKSPACE; }
   m->lastB = 0;
   m->last_train = 1;
+  m->cu_reserve = -1;
+  m->dy7_slabs = 1;
   m->acc0_slot = -1; m->acc0_used = -1;
   m->status_last = nullptr;
   m->bwd_scale = nullptr;
@@ -382,7 +420,7 @@ extern "C" int ava_model_create_ex(ava_model** out, int z_dim, int H, int W, int
   m->dbg["xrec"] = {m->xrec, (int64_t)B * XD}; m->dbg["seed"] = {m->seed, (int64_t)B * XD};
   m->dbg["bn_save"] = {m->bn_save, NCONV * 4 * 32}; m->dbg["bn_bwd"] = {m->bn_bwd, NCONV * 3 * 32};
   m->dbg["dz"] = {m->dz, (int64_t)B * z_dim}; m->dbg["dF8"] = {m->dF8, (int64_t)B * F};
-  m->dbg["dy7"] = {m->dy7, (int64_t)B * F};
+  // (no "dy7" entry: fc1's data gradient usually stays as two split-K slabs in dy7_ws, summed by the encoder's first kernel)
   *out = m;
   return AVA_OK;
 }
@@ -864,6 +902,7 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
 static int forward_impl(ava_model* m, const float* x, int B, const float* eps_w, const float* eps_d, int bn_train,
                         float* loss_out, double* loss_accum, int* status_out, ava_stream_t s, NoiseGen ng) {
   if (m == nullptr || x == nullptr || eps_w == nullptr || eps_d == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
+  const ReserveScope rs(m);
   hipStream_t st = to_stream(s);
   const int z = m->z;
   int pre = 0;
@@ -903,6 +942,7 @@ extern "C" int ava_encode(ava_model* m, const float* x, int B, int bn_train, flo
                           ava_stream_t s) {
   if (m == nullptr || x == nullptr || mu == nullptr || u == nullptr || d == nullptr || B < 1 || B > m->maxB)
     return AVA_EINVAL;
+  const ReserveScope rs(m);
   hipStream_t st = to_stream(s);
   m->lastB = 0;                       // the saved activations of the last ava_forward are overwritten
   TRY(pack_weights(m, false, st));
@@ -911,6 +951,7 @@ extern "C" int ava_encode(ava_model* m, const float* x, int B, int bn_train, flo
 
 extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, float* x_rec, ava_stream_t s) {
   if (m == nullptr || z == nullptr || x_rec == nullptr || B < 1 || B > m->maxB) return AVA_EINVAL;
+  const ReserveScope rs(m);
   hipStream_t st = to_stream(s);
   m->lastB = 0;
   TRY(pack_weights(m, false, st));
@@ -1020,16 +1061,20 @@ static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
 
 // Gradient buckets for the data-parallel all-reduce, in the order backward completes them:
 //   bucket 0 = [fc8.weight .. end of arena)   fc8, convt1..7, bn8..14 (33.6 MB)  -- complete after part 0
-//   bucket 1 = [fc1.weight .. fc8.weight)     fc1 .. fc7              (36.0 MB)  -- complete after part 1
-//   bucket 2 = [0 .. fc1.weight)              conv1..7, bn1..7        (84 KB)    -- complete after part 2
-// so the two large all-reduces run under the fully connected and the encoder halves of backward.
-#define AVA_BACKWARD_PARTS 3
+//   bucket 1 = [fc1.weight .. fc1.bias)       fc1's weight alone      (33.6 MB)  -- complete after part 1
+//   bucket 2 = [fc1.bias .. fc8.weight)       fc1.bias, fc2 .. fc7    (2.5 MB)   -- complete after part 2
+//   bucket 3 = [0 .. fc1.weight)              conv1..7, bn1..7        (84 KB)    -- complete after part 3
+// so the two large all-reduces run under the fully connected and the encoder halves of backward; fc1's weight gradient goes
+// out the moment its product has been enqueued (it is the last big product of the fully connected chain), with the rest
+// of part 1's old tail (fc1's dX, the eight small weight gradients) still to run beside it.
+#define AVA_BACKWARD_PARTS 4
 extern "C" int ava_backward_num_parts(void) { return AVA_BACKWARD_PARTS; }
 extern "C" int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count) {
   if (m == nullptr || offset == nullptr || count == nullptr || bucket < 0 || bucket >= AVA_BACKWARD_PARTS) return AVA_EINVAL;
-  const int64_t fc1 = m->tab[28].off, fc8 = m->tab[50].off;      // fc1.weight, fc8.weight
+  const int64_t fc1 = m->tab[28].off, fc1b = m->tab[29].off, fc8 = m->tab[50].off;      // fc1.weight, fc1.bias, fc8.weight
   if (bucket == 0) { *offset = fc8; *count = m->arena - fc8; }
-  else if (bucket == 1) { *offset = fc1; *count = fc8 - fc1; }
+  else if (bucket == 1) { *offset = fc1; *count = fc1b - fc1; }
+  else if (bucket == 2) { *offset = fc1b; *count = fc8 - fc1b; }
   else { *offset = 0; *count = fc1; }
   return AVA_OK;
 }
@@ -1038,6 +1083,7 @@ extern "C" int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_
 // reduction is deferred and runs together with the encoder's in ONE launch at the end of part 2
 static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, bool whole);
 static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st);
+static int backward_part1b(ava_model* m, const float* x, int B, hipStream_t st);
 static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, bool whole);
 
 extern "C" int ava_set_backward_scale(ava_model* m, const float* loss_scale) {
@@ -1048,17 +1094,23 @@ extern "C" int ava_set_backward_scale(ava_model* m, const float* loss_scale) {
 
 extern "C" int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s) {
   if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr) return AVA_EINVAL;
+  const ReserveScope rs(m);
   TRY(backward_part0(m, x, B, to_stream(s), true));
   TRY(backward_part1(m, x, B, to_stream(s)));
+  TRY(backward_part1b(m, x, B, to_stream(s)));
   return backward_part2(m, x, B, to_stream(s), true);
 }
-// part 0: decoder convolutions, bn8, fc8's weight gradient;  part 1: the fully connected layers and the latent
-// block;  part 2: the encoder convolutions.  Each completes the gradient bucket of the same number.
+// part 0: decoder convolutions, bn8, fc8's weight gradient;  part 1: the data-gradient chain of the fully connected layers,
+// the latent block and fc1's weight gradient;  part 2: fc1's data gradient and the small weight gradients;  part 3: the
+// encoder convolutions.  Each completes the gradient bucket of the same number.
 extern "C" int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s) {
   if (m == nullptr || x == nullptr || B != m->lastB || m->G == nullptr || part < 0 || part >= AVA_BACKWARD_PARTS)
     return AVA_EINVAL;
+  const ReserveScope rs(m);
   if (part == 0) return backward_part0(m, x, B, to_stream(s), false);
-  return part == 1 ? backward_part1(m, x, B, to_stream(s)) : backward_part2(m, x, B, to_stream(s), false);
+  if (part == 1) return backward_part1(m, x, B, to_stream(s));
+  if (part == 2) return backward_part1b(m, x, B, to_stream(s));
+  return backward_part2(m, x, B, to_stream(s), false);
 }
 
 // offset (floats) of the upper half of a gradient ping-pong buffer (B * H * W * 8 floats each, model workspace)
@@ -1120,11 +1172,24 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   TRY(gemm_group(m, hdx, 3, 1, 0, st));
   TRY(gemm(m, m->dh3, 0, PP(m, FC31), 0, nullptr, m->dh2, 0, m->h2, nullptr, B, 256, 192, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh2, 0, PP(m, FC2), 0, nullptr, m->dh1, 0, m->h1, nullptr, B, 1024, 256, 1, 0, ACT_NONE, st));
-  TRY(gemm(m, m->dh1, 0, m->y7t, 0, nullptr, GG(m, FC1), 0, nullptr, GG(m, FC1 + 1), 1024, m->F, B, 0, 0, ACT_NONE, st));
-  // fc1's dX: left as two slabs where it runs so (part 2's ReLU-mask / layout kernel sums them; no split-K product runs in
-  // between, so the workspace keeps them)
+  // fc1's weight gradient (its bias gradient -- the column sums -- is written by the same launch but belongs to bucket 2:
+  // nothing reads it before part 2 is complete)
+  return gemm(m, m->dh1, 0, m->y7t, 0, nullptr, GG(m, FC1), 0, nullptr, GG(m, FC1 + 1), 1024, m->F, B, 0, 0, ACT_NONE, st);
+}
+
+static int backward_part1b(ava_model* m, const float* x, int B, hipStream_t st) {
+  const int z = m->z;
+  (void)x;
+  mark(m, -1, st);
+  // fc1's dX: left as two slabs where it runs so (the last part's ReLU-mask / layout kernel sums them).  The product runs in
+  // a workspace region of its own (dy7_ws), so no launch between the parts -- whatever split-K product is added there
+  // later -- can overwrite the slabs
   m->dy7_slabs = 1;
-  TRY(gemm_defer2(m, m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, B, m->F, 1024, 1, 0, ACT_NONE, st, &m->dy7_slabs));
+  {
+    struct Mk { ava_model* m; hipStream_t st; ~Mk() { mark(m, CAT_GEMM, st); } } _mk{m, st};
+    TRY(ava_gemm_defer2(m->dh1, 0, PP(m, FC1), 0, nullptr, m->dy7, 0, nullptr, nullptr, B, m->F, 1024, 1, 0, ACT_NONE,
+                        m->dy7_ws, m->dy7_ws_bytes, st, &m->dy7_slabs));
+  }
   // ---- the eight small weight gradients (K = batch): fc7, fc6, fc5, fc41/42/43, fc31|32|33, fc2 ----
   const AvaGemmProblem dws[8] = {
       {m->dh7, 0, m->h6, 0, nullptr, GG(m, FC7), 0, nullptr, GG(m, FC7 + 1), 1024, 256, B, ACT_NONE},
@@ -1145,7 +1210,7 @@ static int backward_part2(ava_model* m, const float* x, int B, hipStream_t st, b
   mark(m, -1, st);
   if (recomp_y1()) TRY(materialize_y1(m, x, B, st));       // TEMPORARY: until conv2's / conv1's backward recompute y1 themselves
   if (m->dy7_slabs == 2) {
-    const float* s0 = reinterpret_cast<const float*>(m->gemm_ws);
+    const float* s0 = reinterpret_cast<const float*>(m->dy7_ws);
     TRY(ava_relu_mask_to_nhwc(s0, s0 + (size_t)B * m->F, m->y7, gcur, B, m->P8, st));
   } else {
     TRY(ava_relu_mask_to_nhwc(m->dy7, nullptr, m->y7, gcur, B, m->P8, st));  // dU_7 (ReLU of conv7)
@@ -1181,6 +1246,7 @@ extern "C" int ava_adam_step_range(ava_model* m, int64_t offset, int64_t count, 
   if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr || offset < 0 || count <= 0 ||
       offset + count > m->arena || offset % 4 != 0 || count % 4 != 0)
     return AVA_EINVAL;
+  const ReserveScope rs(m);
   mark(m, -1, to_stream(s));
   const int rc = ava_adam_flat_guarded(m->P + offset, m->G + offset, m->M + offset, m->V + offset, count, lr, beta1, beta2,
                                        eps, step, m->status_last, to_stream(s));
@@ -1191,6 +1257,7 @@ extern "C" int ava_adam_step_range(ava_model* m, int64_t offset, int64_t count, 
 extern "C" int ava_adam_step(ava_model* m, double lr, double beta1, double beta2, double eps, int step,
                              ava_stream_t s) {
   if (m == nullptr || m->G == nullptr || m->M == nullptr || m->V == nullptr) return AVA_EINVAL;
+  const ReserveScope rs(m);
   mark(m, -1, to_stream(s));
   // the reference raises inside forward() when d is not positive (vae.py:312) and never reaches optimizer.step():
   // the update is skipped on the device when the last forward set its status word

@@ -28,31 +28,33 @@ def world_size():
     return td.get_world_size() if (td.is_available() and td.is_initialized()) else 1
 
 
-_reserve_applied = None
-
-
 def cu_reserve():
-    """CUs every persistent conv / GEMM grid leaves free while torch.distributed is active, so that the collective's own
+    """CUs every persistent conv / GEMM grid leaves free while a collective is in flight, so that the collective's own
     persistent workgroups (RCCL: one per channel, resident for the length of an all-reduce) find wave slots instead of
-    pushing part of a statically partitioned conv grid into a second wave (``include/ava_hip.h: ava_set_cu_reserve``).
-    ``AVA_CU_RESERVE`` overrides the default of 32 (an eighth of the chip); 0 switches the reservation off."""
+    pushing part of a statically partitioned conv grid into a second wave (``include/ava_hip.h: ava_model_set_cu_reserve``).
+    Default 0: the reservation costs +0.27 % of the reserved launches' time per CU unconditionally and has only been
+    sized against a stand-in for RCCL (``ava_occupy_cus``), never against RCCL itself; it stays off
+    until an N >= 2 RCCL run shows a net win.  ``bench.py --gpus N`` measures exactly that (``dist.reserve_sweep``: 0, 16,
+    32) and runs its timed region on the best; ``AVA_CU_RESERVE`` sets it by hand."""
     import os
     try:
-        return max(0, min(128, int(os.environ.get("AVA_CU_RESERVE", "32"))))
+        return max(0, min(128, int(os.environ.get("AVA_CU_RESERVE", "0"))))
     except ValueError:
-        return 32
+        return 0
 
 
-def apply_cu_reserve(lib, collectives_in_flight=True):
-    """Idempotent: size the library's persistent grids for the kernels about to be launched.  The reservation is only
-    worth its price (+0.27 % of step time per reserved CU) while a collective IS in flight: ``VAE._backward_kernels``
-    applies it to the backward parts that run beside the gradient buckets' all-reduces (parts 1 and 2) and launches
-    everything else -- the forward, backward part 0, Adam -- on grids sized for the whole chip (no-op in a single-process run)."""
-    global _reserve_applied
-    want = cu_reserve() if (active() and collectives_in_flight) else 0
-    if _reserve_applied != want and (active() or _reserve_applied is not None):
-        lib.ava_set_cu_reserve(want)
-        _reserve_applied = want
+def apply_cu_reserve(lib, handle, collectives_in_flight=True):
+    """Size the persistent grids of the model ``handle`` for the kernels about to be launched (the C entry points read the
+    model's setting once, at their start).  The reservation is only worth its price while a collective IS in flight:
+    ``VAE._backward_kernels`` applies it to the backward parts that run beside the gradient buckets' all-reduces (parts 1..3)
+    and launches everything else -- the forward, backward part 0 -- on grids sized for the whole chip.  No-op in a
+    single-process run and with the default reserve of 0."""
+    if handle is None or not active():
+        return 0
+    want = cu_reserve() if collectives_in_flight else 0
+    if want == 0 and cu_reserve() == 0:
+        return 0                                   # nothing was ever reserved: the model keeps following the process default
+    lib.ava_model_set_cu_reserve(handle, want)
     return want
 
 

@@ -64,16 +64,40 @@ class FlatAdam(torch.optim.Adam):
         self._step_count_flat += 1
         b1, b2 = g['betas']
         lib = _lib.load()
-        if m._handle is not None and m._sharded_adam():
-            # data parallel, sharded optimizer: this rank's slice of every bucket, then the parameters to everyone
-            from . import dist as _dist
-            rc, handles = 0, []
+        from . import dist as _dist
+        if m._handle is not None and _dist.active():
+            # Data parallel: one guarded launch per gradient bucket, each behind ITS all-reduce only -- bucket 0's update
+            # runs while bucket 1 is still on the wire (the buckets arrive deferred from VAE._backward_device(defer_comm=True);
+            # otherwise they are complete already and the waits are no-ops).  Elementwise the same kernel as the flat step:
+            # bit-identical parameters and moments (tests/test_cpu_dist.py, tests/test_gpu_dist.py).
+            # Sharded form (dist.sharded_adam): this rank's slice of every bucket, then the parameters to everyone.
+            sharded = m._sharded_adam()
+            pending = {b: h for b, h in m._take_pending_comm()}
+            if None in pending:
+                _dist.wait_all([pending.pop(None)])       # the status word's MAX: the kernel's guard reads it
+            evs = getattr(m, "_comm_events", None)
+            rc, handles, blocked = 0, [], []
             for off, cnt in m._buckets():
-                so, sc = _dist.shard_of(off, cnt)
-                rc = rc or lib.ava_adam_step_range(m._handle, so, sc, float(g['lr']), float(b1), float(b2),
-                                                   float(g['eps']), self._step_count_flat, _lib.stream())
-                handles.append(_dist.all_gather_bucket_async(m._params, off, cnt))
-            _dist.wait_all(handles)
+                h = pending.pop((off, cnt), None)
+                if h is not None:
+                    if evs is not None:
+                        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                    _dist.wait_all([h])
+                    if evs is not None:
+                        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                        blocked.append((e0, e1))
+                so, sc = _dist.shard_of(off, cnt) if sharded else (off, cnt)
+                rc = lib.ava_adam_step_range(m._handle, so, sc, float(g['lr']), float(b1), float(b2),
+                                             float(g['eps']), self._step_count_flat, _lib.stream())
+                if rc != 0:
+                    break                                 # no further collective is enqueued behind a failed launch
+                if sharded:
+                    handles.append(_dist.all_gather_bucket_async(m._params, off, cnt))
+            _dist.wait_all(list(pending.values()) + handles)
+            if evs is not None and blocked:
+                evs.extend(blocked)                       # bench.py: exposed communication = the sum of these waits per step
+            if sharded:
+                m._adam_state_stale = True                # exp_avg / exp_avg_sq complete on this rank for its own slices only
         elif m._handle is not None:
             rc = lib.ava_adam_step(m._handle, float(g['lr']), float(b1), float(b2), float(g['eps']),
                                    self._step_count_flat, _lib.stream())
@@ -85,6 +109,11 @@ class FlatAdam(torch.optim.Adam):
         return None
 
     def state_dict(self):
+        if getattr(self._model, "_adam_state_stale", False):
+            # sharded optimizer: the moments of the slices other ranks own are stale here; gathering is a collective that
+            # every rank has to enter, so it cannot be done silently from a rank-0-only save_state()
+            raise RuntimeError("optimizer state is sharded over the ranks: call model.gather_adam_state() on EVERY rank "
+                               "before state_dict() / save_state() (train_loop does)")
         if self._step_count_flat > 0:
             self._materialise_state()
         sd = super().state_dict()

@@ -319,7 +319,8 @@ class VAE(nn.Module):
         B = x.shape[0]
         self._ensure(B)
         self._generation += 1
-        _dist.apply_cu_reserve(_lib.load(), False)  # no collective is in flight during a forward: grids for the whole chip
+        self._finish_comm()                               # (a deferred all-reduce nobody consumed: never leave one in flight)
+        _dist.apply_cu_reserve(_lib.load(), self._handle, False)  # no collective is in flight during a forward: grids for the whole chip
         if self.noise_source is None:
             # device counter RNG: the noise is drawn inside the forward's first launch (same stream as ava_fill_normal)
             n = B * (self.z_dim + 1)
@@ -340,61 +341,86 @@ class VAE(nn.Module):
         self._last_noise = (ew, ed)
         return self._loss_buf[0]
 
-    def _backward_device(self, x):
+    def _backward_device(self, x, defer_comm=False):
         """ava_backward into the gradient arena with torch's accumulation rule: after ``zero_grad()`` the arena is
         overwritten; a second backward without ``zero_grad()`` in between ADDS to it (gradient accumulation over
-        micro-batches), at the price of one extra pass over the arena for that call only."""
+        micro-batches), at the price of one extra pass over the arena for that call only.
+
+        ``defer_comm`` (data parallel only; the epoch loop and ``bench.py`` set it): the gradient buckets' all-reduces are
+        left in flight and ``optimizer.step()`` consumes them bucket by bucket -- bucket 0's parameters are updated while
+        bucket 1 is still on the wire.  ``p.grad`` must not be read in between (it is complete only after the step); every
+        other caller gets the gradients complete on return."""
         lib = _lib.load()
         held = self._grads.clone() if self._grad_state == "filled" else None
-        self._backward_kernels(lib, x)
+        self._backward_kernels(lib, x, defer_comm and held is None)
         if held is not None:
             self._grads.add_(held)
         self._grad_state = "filled"
 
-    def _backward_kernels(self, lib, x):
+    def _backward_kernels(self, lib, x, defer_comm=False):
         if not _dist.active():
             _lib.check(lib.ava_backward(self._handle, x.data_ptr(), x.shape[0], _lib.stream()), "ava_backward")
             return
-        # data parallel: backward runs in parts; the gradient bucket a part completes (fc8 + decoder, then fc1..fc7,
-        # then the encoder) is all-reduced asynchronously while the next part is still running
-        # the "d not positive" word first: MAX over ranks, so that ava_adam_step's device-side guard and the epoch loop's
-        # poll see the SAME word on every rank (one rank's NaN gradients reach every rank through the all-reduce below)
-        # CU reserve (dist.cu_reserve): part 0 runs with no collective in flight -- the status word goes out behind it,
-        # with the first bucket -- so only parts 1 and 2 launch on grids that leave room for the collective's workgroups
+        # data parallel: backward runs in parts; the gradient bucket a part completes (fc8 + decoder, fc1's weight, the
+        # other fully connected layers, the encoder) is all-reduced asynchronously while the next part is still running.
+        # The "d not positive" word goes first: MAX over ranks, so that the Adam kernel's device-side guard and the epoch
+        # loop's poll see the SAME word on every rank (one rank's NaN gradients reach every rank through the all-reduce).
+        # CU reserve (dist.cu_reserve, default 0): part 0 runs with no collective in flight -- the status word goes out
+        # behind it, with the first bucket -- so only the later parts launch on grids that leave room for a collective.
+        self._finish_comm()
         pending = []
-        for part in range(lib.ava_backward_num_parts()):
-            _dist.apply_cu_reserve(lib, part > 0)
+        for part, (off, cnt) in enumerate(self._buckets()):
+            _dist.apply_cu_reserve(lib, self._handle, part > 0)
             _lib.check(lib.ava_backward_part(self._handle, x.data_ptr(), x.shape[0], part, _lib.stream()),
                        "ava_backward_part")
             if part == 0:
-                pending.append(_dist.allreduce_max_async(self._status))
-            off, cnt = ctypes.c_int64(), ctypes.c_int64()
-            _lib.check(lib.ava_grad_bucket(self._handle, part, ctypes.byref(off), ctypes.byref(cnt)), "ava_grad_bucket")
+                pending.append((None, _dist.allreduce_max_async(self._status)))
             if self._sharded_adam():
-                pending.append(_dist.reduce_scatter_bucket_async(self._grads, off.value, cnt.value))
+                pending.append(((off, cnt), _dist.reduce_scatter_bucket_async(self._grads, off, cnt)))
             else:
-                pending.append(_dist.allreduce_gradients_async(self._grads[off.value:off.value + cnt.value]))
-        # bench.py sets _comm_events to a list: the time the compute stream then spends blocked on the collectives
-        # (end of the last backward kernel -> all buckets reduced) is the exposed communication of the step
+                pending.append(((off, cnt), _dist.allreduce_gradients_async(self._grads[off:off + cnt])))
+        _dist.apply_cu_reserve(lib, self._handle, False)
+        self._pending_comm = pending
+        if not defer_comm:
+            self._finish_comm()
+
+    def _finish_comm(self):
+        """Make the compute stream wait for every collective ``_backward_kernels`` left in flight (gradients complete
+        afterwards).  bench.py sets ``_comm_events`` to a list: the time the compute stream then spends blocked on the
+        collectives (end of the last backward kernel -> all buckets reduced) is the exposed communication of the step."""
+        pending = getattr(self, "_pending_comm", None)
+        if not pending:
+            return
+        self._pending_comm = None
         evs = getattr(self, "_comm_events", None)
         if evs is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        _dist.wait_all(pending)
-        _dist.apply_cu_reserve(lib, False)          # every collective of the step is complete: Adam and the next forward use the whole chip
+        _dist.wait_all([h for _, h in pending])
         if evs is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             evs.append((e0, e1))
 
+    def _take_pending_comm(self):
+        """The collectives ``_backward_kernels(defer_comm=True)`` left in flight, as [(bucket or None, handle)] in issue
+        order, handed to the optimizer (FlatAdam.step waits for and updates one bucket at a time)."""
+        pending = getattr(self, "_pending_comm", None)
+        self._pending_comm = None
+        return pending or []
+
     def _buckets(self):
         """(offset, count) of the gradient buckets, in the order the backward parts complete them"""
+        out = getattr(self, "_bucket_cache", None)
+        if out is not None and out[0] is self._handle:
+            return out[1]
         lib = _lib.load()
         out = []
         for part in range(lib.ava_backward_num_parts()):
             off, cnt = ctypes.c_int64(), ctypes.c_int64()
             _lib.check(lib.ava_grad_bucket(self._handle, part, ctypes.byref(off), ctypes.byref(cnt)), "ava_grad_bucket")
             out.append((off.value, cnt.value))
+        self._bucket_cache = (self._handle, out)
         return out
 
     def _sharded_adam(self):
@@ -415,6 +441,7 @@ class VAE(nn.Module):
             hs.append(_dist.all_gather_bucket_async(self._exp_avg, o, c))
             hs.append(_dist.all_gather_bucket_async(self._exp_avg_sq, o, c))
         _dist.wait_all(hs)
+        self._adam_state_stale = False
 
     def _check_status(self):
         """Blocking check of the device status word (d not positive in some forward so far).  Under data parallelism
@@ -431,8 +458,8 @@ class VAE(nn.Module):
         # vae.py:312, and never reaches ``optimizer.step()``).  What is NOT rolled back: the forwards that ran in the
         # meantime (at most the polling lag, two steps) have moved the BatchNorm running statistics.
         skipped = int(self._status[1].item())
-        if self._sharded_adam():
-            skipped //= len(self._buckets())         # one guarded launch per bucket slice and step
+        if _dist.active():
+            skipped //= len(self._buckets())         # data parallel: one guarded launch per bucket (slice) and step
         opt = getattr(self, "optimizer", None)
         if opt is not None and skipped > 0:
             opt._step_count_flat = max(0, opt._step_count_flat - skipped)
@@ -548,7 +575,7 @@ class VAE(nn.Module):
             self.optimizer.zero_grad()
             data = self._prep_x(data)
             self._forward_device(data, need_grad=True, accumulate=True)
-            self._backward_device(data)
+            self._backward_device(data, defer_comm=True)     # data parallel: the step below consumes the buckets one by one
             self.optimizer.step()
             self._poll_status()
         self._check_status()

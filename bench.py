@@ -112,7 +112,7 @@ def one_step(model, x):
     """The body of VAE.train_epoch's loop (vae.py:347-353)."""
     model.optimizer.zero_grad()
     model._forward_device(x, need_grad=True, accumulate=True)
-    model._backward_device(x)
+    model._backward_device(x, defer_comm=True)       # data parallel: the Adam step consumes the gradient buckets one by one
     model.optimizer.step()
 
 
@@ -357,6 +357,19 @@ def main():
 
     B = args.batch
     pool = make_pool(B)
+    # CU reserve (dist.cu_reserve): measured, not assumed -- with more than one rank and no AVA_CU_RESERVE given, short timed
+    # runs at 0 / 16 / 32 reserved CUs decide which one the timed region below runs with (every rank takes the same decision:
+    # the times are MAX-reduced).  Part of the warm-up as far as the contract goes: nothing here is counted in `value`.
+    reserve_sweep = None
+    if world > 1 and "AVA_CU_RESERVE" not in os.environ:
+        reserve_sweep = {}
+        ssteps = max(5, args.steps // 2)
+        for r in (0, 16, 32):
+            os.environ["AVA_CU_RESERVE"] = str(r)
+            reserve_sweep[str(r)] = round(1e3 * timed(pool, ssteps, max(3, args.warmup // 2)) / ssteps, 4)
+        best_r = min(reserve_sweep, key=lambda k: reserve_sweep[k])
+        os.environ["AVA_CU_RESERVE"] = best_r
+        reserve_sweep = {"ms_per_step": reserve_sweep, "steps_each": ssteps, "chosen": int(best_r)}
     dt = timed(pool, args.steps, args.warmup)
     model._check_status()
     ms_per_step = 1e3 * dt / args.steps
@@ -368,7 +381,10 @@ def main():
                  "ranks_seen": world, "grad_allreduce_bytes_per_step": int(model._grads.numel()) * 4 if world > 1 else 0,
                  "buckets": _lib.load().ava_backward_num_parts() if world > 1 else 0,
                  # CUs every persistent grid leaves free for the collective's workgroups (dist.cu_reserve); sharded optimizer?
-                 "cu_reserve": adist.cu_reserve() if world > 1 else 0, "cu_reserve_applies_to": "backward parts 1 and 2 (beside the bucket all-reduces)" if world > 1 else None, "sharded_adam": bool(model._sharded_adam()) if world > 1 else False}
+                 "cu_reserve": adist.cu_reserve() if world > 1 else 0, "reserve_sweep": reserve_sweep,
+                 "cu_reserve_applies_to": "backward parts 1..3 (beside the bucket all-reduces)" if world > 1 else None,
+                 "adam": "per bucket, each behind its own all-reduce" if world > 1 else "one flat launch",
+                 "sharded_adam": bool(model._sharded_adam()) if world > 1 else False}
     if world > 1:
         t = torch.ones(1, device="cuda")
         torch.distributed.all_reduce(t)
@@ -380,7 +396,7 @@ def main():
         sync()
         ev = model._comm_events
         model._comm_events = None
-        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(n_comm, 1)      # waits of a step: one per bucket
         te = torch.tensor([exposed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
         dist_info["exposed_comm_ms_per_step"] = round(float(te.item()), 4)

@@ -103,10 +103,11 @@ int ava_backward(ava_model* m, const float* x, int B, ava_stream_t s);
  * (the seed gradient and the prior/entropy terms are multiplied by it: the gradient is linear in it), then forgotten.
  * NULL (the default after every ava_forward) means 1.  Replaces a 70 MB pass over the gradient arena. */
 int ava_set_backward_scale(ava_model* m, const float* loss_scale);
-/* The same backward in ava_backward_num_parts() (= 3) consecutive parts, so that a data-parallel caller can
+/* The same backward in ava_backward_num_parts() (= 4) consecutive parts, so that a data-parallel caller can
  * all-reduce each part's gradients while the next part runs.  Part p completes gradient bucket p, a contiguous
  * range of the arena returned by ava_grad_bucket (floats): bucket 0 = fc8, convt1..7, bn8..14 (tail of the arena),
- * bucket 1 = fc1..fc7, bucket 2 = conv1..7, bn1..7 (head).  The buckets tile the arena. */
+ * bucket 1 = fc1.weight alone (the largest tensor: it goes out as soon as its product is enqueued), bucket 2 = fc1.bias,
+ * fc2..fc7, bucket 3 = conv1..7, bn1..7 (head).  The buckets tile the arena. */
 int ava_backward_num_parts(void);
 int ava_backward_part(ava_model* m, const float* x, int B, int part, ava_stream_t s);
 int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count);
@@ -118,6 +119,11 @@ int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count);
  * usec microseconds (<= 20 ms): a stand-in for such a collective in tests. */
 int ava_set_cu_reserve(int cus);
 int ava_get_cu_reserve(void);
+/* The same per model: the grids of THIS model's entry points (forward, backward parts, Adam, encode, decode) are sized for
+ * (256 - cus) CUs from the next call on; -1 (the default) follows the process-wide setting.  Each entry point reads the
+ * value once, at its start, so launches that hand partial rows to each other inside one call always agree on the grid. */
+int ava_model_set_cu_reserve(ava_model* m, int cus);
+int ava_model_get_cu_reserve(const ava_model* m);
 int ava_occupy_cus(int workgroups, int lds_bytes, float usec, ava_stream_t s);
 /* torch.optim.Adam.step (torch/optim/adam.py:414-547), one fused pass over the four arenas.
  * `step` is the 1-based count after increment.  When the last ava_forward raised its status word (some d not > 0: the

@@ -33,11 +33,11 @@ def _worker(rank, world, port, q):
         flat = torch.zeros(total)
         for s in layout.param_specs(z):
             flat[offs[s.name]:offs[s.name] + s.numel] = P[s.name].grad.reshape(-1)
-        # three buckets (tail, middle, head of the arena), asynchronously, exactly like VAE._backward_device does
-        # under data parallelism (ava_grad_bucket: fc8 + decoder, fc1..fc7, encoder)
-        s8, s1 = offs["fc8.weight"], offs["fc1.weight"]
-        pending = [adist.allreduce_gradients_async(flat[s8:]), adist.allreduce_gradients_async(flat[s1:s8]),
-                   adist.allreduce_gradients_async(flat[:s1])]
+        # four buckets (tail, fc1's weight, the rest of the middle, head of the arena), asynchronously, exactly like
+        # VAE._backward_device does under data parallelism (ava_grad_bucket: fc8 + decoder, fc1.weight, fc1.bias..fc7, encoder)
+        s8, s1, s1b = offs["fc8.weight"], offs["fc1.weight"], offs["fc1.bias"]
+        pending = [adist.allreduce_gradients_async(flat[s8:]), adist.allreduce_gradients_async(flat[s1:s1b]),
+                   adist.allreduce_gradients_async(flat[s1b:s8]), adist.allreduce_gradients_async(flat[:s1])]
         adist.wait_all(pending)                               # SUM, not mean (the loss is a batch sum)
         norms = {s.name: float(flat[offs[s.name]:offs[s.name] + s.numel].double().norm()) for s in layout.param_specs(z)}
         gl = adist.global_loss(out["loss"].detach().double(), z, 10.0, 1)
@@ -97,21 +97,26 @@ def test_single_process_is_passthrough():
 
 
 def test_cu_reserve_is_applied_only_where_a_collective_is_in_flight(monkeypatch):
-    """dist.apply_cu_reserve: grids sized for 256 - r CUs only for the launches that run beside a collective (backward parts
-    1 and 2); the forward, backward part 0 and Adam get the whole chip; nothing is touched in a single-process run."""
+    """dist.apply_cu_reserve: OFF by default (never validated against RCCL: ADVICE r3); when AVA_CU_RESERVE asks for r, the
+    model's grids are sized for 256 - r CUs only for the launches that run beside a collective (backward parts 1..3); the
+    forward and backward part 0 get the whole chip; nothing is touched in a single-process run or without a model handle."""
     from ava_amd import dist as adist
 
     class Lib:
         def __init__(self): self.calls = []
-        def ava_set_cu_reserve(self, v): self.calls.append(v); return 0
+        def ava_model_set_cu_reserve(self, h, v): self.calls.append((h, v)); return 0
 
-    monkeypatch.setattr(adist, "_reserve_applied", None)
     lib = Lib()
     monkeypatch.setattr(adist, "active", lambda: False)
-    assert adist.apply_cu_reserve(lib, True) == 0 and adist.apply_cu_reserve(lib, False) == 0 and lib.calls == []
+    monkeypatch.setenv("AVA_CU_RESERVE", "32")
+    assert adist.apply_cu_reserve(lib, 7, True) == 0 and adist.apply_cu_reserve(lib, 7, False) == 0 and lib.calls == []
     monkeypatch.setattr(adist, "active", lambda: True)
     monkeypatch.delenv("AVA_CU_RESERVE", raising=False)
-    seq = [adist.apply_cu_reserve(lib, f) for f in (False, False, True, True, False)]     # forward, part 0, part 1, part 2, after the wait
-    assert seq == [0, 0, 32, 32, 0] and lib.calls == [0, 32, 0]
+    assert adist.cu_reserve() == 0
+    assert [adist.apply_cu_reserve(lib, 7, f) for f in (False, True, True, False)] == [0, 0, 0, 0] and lib.calls == []
+    monkeypatch.setenv("AVA_CU_RESERVE", "32")
+    seq = [adist.apply_cu_reserve(lib, 7, f) for f in (False, False, True, True, True, False)]     # forward, parts 0..3, after
+    assert seq == [0, 0, 32, 32, 32, 0] and [v for _, v in lib.calls] == seq and all(h == 7 for h, _ in lib.calls)
+    assert adist.apply_cu_reserve(lib, None, True) == 0
     monkeypatch.setenv("AVA_CU_RESERVE", "16")
-    assert adist.apply_cu_reserve(lib, True) == 16 and lib.calls[-1] == 16
+    assert adist.apply_cu_reserve(lib, 7, True) == 16 and lib.calls[-1] == (7, 16)

@@ -51,6 +51,23 @@ def test_results_do_not_depend_on_a_co_resident_kernel_and_reserve_is_reproducib
         # a different reserve is a different (equally valid) partition of the same sums: fp32 rounding apart
         (la, ga), (lb, gb) = out[0], out[32]
         assert abs(la - lb) / abs(la) < 1e-6
+        # the same reserve set PER MODEL (ava_model_set_cu_reserve: what dist.py uses) with the process-wide value at 0: the
+        # model's entry points snapshot it at their start -- bit-identical to the process-wide 32 above; a second model in the
+        # same process keeps its own setting
+        _lib.check(lib.ava_set_cu_reserve(0), "reserve")
+        model = build_model(z)
+        model.noise_source = lambda b, zz: (ew, ed)
+        model._ensure(B)
+        other = build_model(z)
+        other.noise_source = lambda b, zz: (ew, ed)
+        other._ensure(B)
+        _lib.check(lib.ava_model_set_cu_reserve(model._handle, 32), "model reserve")
+        assert lib.ava_model_get_cu_reserve(model._handle) == 32 and lib.ava_model_get_cu_reserve(other._handle) == -1
+        lm, gm = _step(model, x)
+        lo, go = _step(other, x)
+        assert lm == lb and torch.equal(gm, gb)
+        assert lo == la and torch.equal(go, ga)
+        assert lib.ava_model_set_cu_reserve(model._handle, 129) != 0 and lib.ava_model_set_cu_reserve(model._handle, -2) != 0
         num = float((ga.double() - gb.double()).norm())
         assert num / float(ga.double().norm()) < 1e-4       # fp32 rounding of the partial sums + the odd ReLU-mask flip
     finally:

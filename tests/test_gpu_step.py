@@ -299,14 +299,15 @@ def test_two_shard_data_parallel_equivalence():
 
 def test_backward_in_parts_equals_whole():
     """ava_backward_part(0..n-1) (the data-parallel overlap path) == ava_backward, bit for bit, and the gradient
-    buckets tile the arena in the order tail (fc8 + decoder), middle (fc1..fc7), head (encoder)."""
+    buckets tile the arena in the order tail (fc8 + decoder), fc1.weight, the rest of the middle (fc1.bias..fc7), head
+    (encoder)."""
     import ctypes
     from ava_amd import _lib
     lib = _lib.load()
     B, z = 8, 32
     x = torch.from_numpy(syn.spectrograms(B)).cuda()
     nparts = lib.ava_backward_num_parts()
-    assert nparts == 3
+    assert nparts == 4
     grads = []
     for split in (False, True):
         model = build_model(z)
@@ -324,9 +325,10 @@ def test_backward_in_parts_equals_whole():
         o, c = ctypes.c_int64(), ctypes.c_int64()
         assert lib.ava_grad_bucket(model._handle, b, ctypes.byref(o), ctypes.byref(c)) == 0
         rng.append((o.value, c.value))
-    assert rng[2][0] == 0 and rng[2][1] == rng[1][0] and rng[1][0] + rng[1][1] == rng[0][0]
+    assert rng[3][0] == 0 and rng[3][1] == rng[1][0] and rng[1][0] + rng[1][1] == rng[2][0] and rng[2][0] + rng[2][1] == rng[0][0]
     assert rng[0][0] + rng[0][1] == model._grads.numel()
     assert rng[0][0] == model._arena_views["fc8.weight"][0] and rng[1][0] == model._arena_views["fc1.weight"][0]
+    assert rng[2][0] == model._arena_views["fc1.bias"][0] and rng[1][1] >= model._arena_views["fc1.weight"][1]
     assert lib.ava_grad_bucket(model._handle, nparts, ctypes.byref(o), ctypes.byref(c)) != 0
 
 

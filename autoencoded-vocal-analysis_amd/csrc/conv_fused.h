@@ -37,3 +37,8 @@ int ava_conv3x3_bwd_fused_launch(const FusedArgs& a, int Cin, int Cout, int mode
 // conv1 (1 -> 8) and convt7 (8 -> 1) at 128 x 128: VALU kernels in conv_thin.hip
 int ava_thin_fused_grid(int B, int Hi, int Wi, int Cin, int Cout, int mode);
 int ava_thin_bwd_fused_launch(const FusedArgs& a, int grid, int Cin, int dy_pro, hipStream_t st);
+
+// the same backward with both products on bf16 limb MFMA (conv_fused_limb.hip); AVA_EINVAL: no limb instantiation
+bool ava_conv_fused_limb_has(int Cin, int Cout, int mode);
+int ava_conv_fused_limb_cap(int Cin, int Cout, int mode);
+int ava_conv3x3_bwd_fused_limb_launch(const FusedArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);

@@ -771,6 +771,12 @@ static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap) {
   if (gcap > 0) *cap = gcap;
 }
 
+// both products on bf16 limb MFMA where the shape has that kernel (conv_fused_limb.hip; lab: AVA_FUSED_LIMB=0 keeps fp32 MFMA)
+static bool fused_limb_on() {
+  static const bool limb = [] { const char* e = ava_env("AVA_FUSED_LIMB"); return e == nullptr || atoi(e) != 0; }();
+  return limb;
+}
+
 static int fused_variant() {
   static const int v = [] { const char* e = ava_env("AVA_FUSED_VAR"); return e ? atoi(e) : 0; }();
   return v;
@@ -795,6 +801,7 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
   const int nt = B * (hl / th) * (wl / tw);
   bool ws; int cap;
   fused_defaults(Cin, Cout, mode, &ws, &cap);   // 512 = two resident 256-thread workgroups per CU (384 / 768 / 1024 are slower)
+  if (fused_limb_on() && ava_conv_fused_limb_cap(Cin, Cout, mode) > 0) cap = ava_conv_fused_limb_cap(Cin, Cout, mode);
   return nt < ava_scale_grid(cap) ? nt : ava_scale_grid(cap);
 }
 
@@ -805,6 +812,8 @@ int ava_conv3x3_bwd_fused_launch(const FusedArgs& a_, int Cin, int Cout, int mod
   if (grid <= 0) return AVA_EINVAL;
   if (Cin == 1 || Cout == 1) return ava_thin_bwd_fused_launch(a, grid, Cin, dy_pro, st);
   if (a.dx == nullptr) return AVA_EINVAL;
+  if (fused_limb_on() && a.rcd.G1 == nullptr && ava_conv_fused_limb_has(Cin, Cout, mode))
+    return ava_conv3x3_bwd_fused_limb_launch(a, grid, Cin, Cout, mode, dy_pro, st);
   const int var = fused_variant();
 #define X(ci, co, md, vr, tww, thh, mw)                                                            \
   if (Cin == ci && Cout == co && mode == md && var == vr) {                                         \

@@ -67,10 +67,11 @@ template <int N> using ava_ic = std::integral_constant<int, N>;
 template <int LMODE> __host__ __device__ constexpr int wl_units(int cin) { return wsplit_base<LMODE>(n_classes<LMODE>(), cin); }
 
 // ACT: storage type of the activations x (layer input) and dy2 (saved output); dy and dx are fp32 gradients.
-// ND: data-gradient waves (1 or 2); the other 4 - ND matrix-core waves form the weight gradient.
-// WPS: minimum waves per SIMD for the register allocator (4: two workgroups per CU, 128 VGPRs; 2: one per CU, 256 VGPRs)
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int ND, int WPS, typename ACT>
-__global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const FusedArgs a) {
+// NS / ND / NWV: staging, data-gradient and weight-gradient waves of the workgroup (64 * (NS + ND + NWV) threads; waves are dealt
+// to the four SIMDs in turn, so with NS, ND and NWV multiples of 4 every SIMD hosts the same mix of roles).
+// WPS: minimum waves per SIMD for the register allocator (workgroups per CU x waves of a workgroup / 4)
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT>
+__global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_limb_kernel(const FusedArgs a) {
   using FG = FGeomL<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
   constexpr int BMODE = LMODE == MODE_S1 ? MODE_S1 : (LMODE == MODE_DOWN ? MODE_UP : MODE_DOWN);   // gather pattern of dx
@@ -78,13 +79,15 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
   constexpr int NT = (CO + 15) / 16;        // dG column tiles
   constexpr int NW_ = 9 * CI * CO;
   constexpr int BCLS = n_classes<BMODE>(), WCLS = n_classes<LMODE>();
-  constexpr int NWV = 4 - ND;               // weight-gradient waves
-  static_assert(ND == 1 || ND == 2, "one or two data-gradient waves");
+  constexpr int NST = 64 * NS;              // staging threads
+  static_assert(NS >= 1 && ND >= 1 && NWV >= 1 && NWV <= 4 && ND + NWV >= 4, "roles");
   static_assert(CI % 8 == 0 && CO % 8 == 0, "limb planes are made of channel octets");
   // stride-1 layers with 8 input channels: the data gradient has 8 output channels -> two dx rows per MFMA tile
   constexpr bool PAIR = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
-  // two dx channel tiles and two data-gradient waves: each wave takes one tile for ALL pixel groups (half the limb weights)
-  constexpr bool DSPLIT = MT == 2 && ND == 2;
+  // two dx channel tiles: the data-gradient waves are dealt one tile each (half the limb weights), odd and even waves
+  // sharing the pixel groups
+  constexpr bool DSPLIT = MT == 2 && ND % 2 == 0;
+  constexpr int NDG = DSPLIT ? ND / 2 : ND;     // waves that share the pixel groups of a tile
   constexpr int MTD = DSPLIT ? 1 : MT;
   constexpr int XNPIX = XR * XC, DNPIX = DR * DC;
   constexpr int XPLANE = (CI / 8) * XNPIX * 16, DPLANE = (CO / 8) * DNPIX * 16;      // bytes
@@ -92,13 +95,13 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
   extern __shared__ __align__(16) unsigned char smem_b[];
   float* cx = reinterpret_cast<float*>(smem_b + 2 * BUF);     // [3][32]
   float* cd = cx + 96;                                         // [3][32]
-  float* red = cd + 96;                                        // [ND][32 * MT]
+  float* red = cd + 96;                                        // [ND][32 * MT]: per data-gradient wave {sum g [16 MT], sum g x [16 MT]}
   __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
   __shared__ float ems[64];                 // mean [0..31], invstd [32..63] of x's BatchNorm for the final reduction
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool stager = wave8 < 4;             // waves 0-3 stage tiles, 4 .. 4+ND-1 data gradient, the rest weight gradient
+  const bool stager = wave8 < NS;            // waves 0 .. NS-1 stage tiles, the next ND form the data gradient, the rest the weight gradient
   const int n = lane & 15, kg = lane >> 4;
 
   // tile -> image, low-resolution origin, window origins
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
     else { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
   };
   TileWalk walk(a.ntiles);
-  TileStagerL<CI, PRO_BN, XR, XC, 256, ACT, ACT> sx;          // staging waves only (threadIdx.x 0..255)
-  TileStagerL<CO, DYPRO, DR, DC, 256, float, ACT> sd;
+  TileStagerL<CI, PRO_BN, XR, XC, NST, ACT, ACT> sx;          // staging waves only (threadIdx.x 0 .. NST-1)
+  TileStagerL<CO, DYPRO, DR, DC, NST, float, ACT> sd;
   auto prefetch = [&](int tl) {
     int b, y0, x0, gy, gx;
     origin(tl, b, y0, x0);
@@ -142,18 +145,18 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
     const float* sxp = which == 0 ? a.xa : (which == 1 ? a.xb : nullptr);
     cxv = (sxp != nullptr && c < CI) ? sxp[c] : 0.f;
   }
-  static_assert(9 * CI * CO * 4 <= 256 * 128, "one touch per thread covers the packed weights");
+  static_assert(9 * CI * CO * 4 <= 64 * (ND + NWV) * 128, "one touch per thread covers the packed weights");
   float wpf = 0.f;
   if (!stager) {
-    wpf = a.Gb[min(32 * (t - 256), 9 * CI * CO - 1)];
-    const int e = t - 320;                    // the SECOND matrix-core wave: the first one finalises the coefficients
+    wpf = a.Gb[min(32 * (t - NST), 9 * CI * CO - 1)];
+    const int e = t - NST - 64;               // the SECOND matrix-core wave: the first one finalises the coefficients
     if (e >= 0 && e < 64) {
       const int c = e & 31;
       ems[e] = c < CI ? (e < 32 ? a.mean[c] : a.invstd[c]) : 0.f;
     }
   }
   if (a.fin.acc != nullptr) {
-    bn_coef_from_acc(cd, accvals, a.fin, 256);
+    bn_coef_from_acc(cd, accvals, a.fin, NST);
     if (t < 96) cx[t] = cxv;
   } else if (t < 96) {
     const int which = t >> 5, c = t & 31;
@@ -188,10 +191,11 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
     return;
   }
 
-  if (wave8 < 4 + ND) {
+  if (wave8 < NS + ND) {
     // ---------------- data-gradient waves ----------------
-    const int dw = wave8 - 4;
-    const int mtb = DSPLIT ? dw : 0;                            // first dx channel tile of this wave
+    const int dw = wave8 - NS;
+    const int mtb = DSPLIT ? (dw & 1) : 0;                      // first dx channel tile of this wave
+    const int dgi = DSPLIT ? (dw >> 1) : dw;                    // which share of the pixel groups
     constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
     typename std::conditional<PAIR, PairFragL<CO, DC, DNPIX>, ClassFragL<CO, CI, BMODE, 0, DC, DNPIX, MTD>>::type f0;
     ClassFragL<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC, DNPIX, MTD> f1;
@@ -210,9 +214,9 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
     // pixel groups of the dx region: 16 consecutive pixels of a row (UP pattern: of one parity class)
     constexpr int CB = FG::OW / (BMODE == MODE_UP ? 32 : 16);          // column blocks
     constexpr int GROUPS = PAIR ? (FG::OH / 2) * CB : (BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB);
-    constexpr int GPW = DSPLIT ? GROUPS : GROUPS / ND;
-    static_assert(GROUPS % ND == 0 && (BMODE != MODE_UP || GPW % 4 == 0), "tile must split evenly over the data-gradient waves");
-    const int g0 = DSPLIT ? 0 : dw * GPW;
+    constexpr int GPW = GROUPS / NDG;
+    static_assert(GROUPS % NDG == 0 && (BMODE != MODE_UP || GPW % 4 == 0), "tile must split evenly over the data-gradient waves");
+    const int g0 = dgi * GPW;
     auto group_out = [&](int g) -> int {
       if (BMODE == MODE_UP) {
         const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
@@ -307,14 +311,15 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
         }
       }
     __syncthreads();                                              // (E)
-    const int tc = t - 256;                                       // first data-gradient wave: 2 * CI <= 64 lanes
+    const int tc = t - NST;                                       // first data-gradient wave: 2 * CI <= 64 lanes
     if (tc < 2 * CI) {
       const int which = tc / CI, ci = tc - which * CI;
       const int idx = which * 16 * MT + ci;
-      float tot;
-      if (DSPLIT) tot = red[(ci >> 4) * 32 * MT + idx];           // a channel tile belongs to one wave
-      else if (ND == 2) tot = red[idx] + red[32 * MT + idx];
-      else tot = red[idx];
+      // fixed order over the waves that hold this channel (DSPLIT: waves of the channel's tile parity)
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < ND; ++w)
+        if (!DSPLIT || (w & 1) == (ci >> 4)) tot += red[w * 32 * MT + idx];
       if (a.acc_out != nullptr) bn_acc_add(a.acc_out, which * 32 + ci, tot);
       else a.bn_partials[(size_t)blockIdx.x * 2 * CI + tc] = tot;
     }
@@ -325,14 +330,13 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
   // Units: the M tiles (16 rows of (tap, ci)) of every tap class, numbered class by class, plus the bias row as unit NU.
   // Unit u belongs to wave u % NWV, slot u / NWV.  K = 32 pixels per step: KW consecutive pixels of 32 / KW rows.
   constexpr int NU = wl_units<LMODE>(CI);
-  constexpr int MAXOWN = (NU + 1 + NWV - 1) / NWV;
   constexpr int KW = TW >= 32 ? 32 : TW;                     // pixels of one row inside a K step
   static_assert(KW == 32 || KW == 16, "K steps are 32 pixels: one row of 32 or two rows of 16");
   constexpr int KSTEPS = TH * TW / 32;
   static_assert((TH * TW) % 32 == 0 && (KW == 32 || TH % 2 == 0), "tile must be made of whole K steps");
   constexpr int SA = LMODE == MODE_DOWN ? 2 : 1;             // x-window pixels per step pixel
   constexpr int SB = LMODE == MODE_UP ? 2 : 1;               // dU-window pixels per step pixel
-  const int ww = wave8 - 4 - ND;                             // wave-uniform
+  const int ww = wave8 - NS - ND;                            // wave-uniform
   ava_lds_u8* const lbase = (ava_lds_u8*)smem_b;
   // lane's pixel inside a K step (k sub-block 0): lane group g = lane >> 4 holds k = 8 g + {0..7}; lane 4 q + p of the group
   // supplies the address of k = 8 g + q (second read: + 4), columns 4 p .. 4 p + 3
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
         for (int nt = 0; nt < NT; ++nt) acc[u / NWV][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     });
-    if (OWNS_BIAS) {
+    if constexpr (OWNS_BIAS) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[NU / NWV][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int L = 0; L < 3; ++L) bfr[nt][L] = ava_lds_tr8<4 * SB * 16>(ds + offB[nt] + L * DPLANE + CLSOFF);
-          if (OWNS_BIAS) {
+          if constexpr (OWNS_BIAS) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               f32x4 c = acc[NU / NWV][nt];
@@ -423,7 +427,6 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
 #pragma unroll
           for (int mt = 0; mt < MTK; ++mt) {
             if ((UB + mt) % NWV == WW) {
-              constexpr int dummy = 0; (void)dummy;
               const int sl = (UB + mt) / NWV;
               ava_bf16x8 afr[3];
 #pragma unroll
@@ -460,28 +463,32 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_bwd_fused_limb_kernel(const 
         }
       }
     });
-    if (OWNS_BIAS && kg == 0) {
+    if constexpr (OWNS_BIAS) {
+      if (kg == 0) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = 16 * nt + n;
-        if (co < CO) prow[NW_ + co] = acc[NU / NWV][nt][0];
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = 16 * nt + n;
+          if (co < CO) prow[NW_ + co] = acc[NU / NWV][nt][0];
+        }
       }
     }
   };
   if (ww == 0) w_role(ava_ic<0>{});
   else if (NWV > 1 && ww == 1) w_role(ava_ic<(NWV > 1 ? 1 : 0)>{});
-  else if (NWV > 2) w_role(ava_ic<(NWV > 2 ? 2 : 0)>{});
+  else if (NWV > 2 && ww == 2) w_role(ava_ic<(NWV > 2 ? 2 : 0)>{});
+  else if (NWV > 3) w_role(ava_ic<(NWV > 3 ? 3 : 0)>{});
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int ND, int WPS, typename ACT>
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT>
 static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   using FG = FGeomL<LMODE, TW, TH>;
   constexpr int MT = (CI + 15) / 16;
   constexpr size_t buf = (size_t)3 * 16 * ((CI / 8) * FG::XR * FG::XC + (CO / 8) * FG::DR * FG::DC);
-  constexpr size_t lds = 2 * buf + (192 + 2 * 32 * MT) * sizeof(float);
-  static_assert(lds + 1024 <= (WPS == 4 ? 80 : 160) * 1024, "two workgroups per CU need two tile-buffer pairs in 160 KB of LDS");
-  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, ND, WPS, ACT>);
+  constexpr size_t lds = 2 * buf + (192 + ND * 32 * MT) * sizeof(float);
+  constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
+  static_assert(WG_PER_CU >= 1 && (lds + 1024) * WG_PER_CU <= 160 * 1024, "the resident workgroups' tile buffers must fit 160 KB of LDS");
+  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT>);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVA_ELAUNCH;
@@ -494,42 +501,50 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   b.tiles_x = wl / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
-  hipLaunchKernelGGL((conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, ND, WPS, ACT>), dim3(grid), dim3(512), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT>), dim3(grid), dim3(64 * (NS + ND + NWV)), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
-template <int CI, int CO, int LMODE, int TW, int TH, int ND, int WPS>
+template <int CI, int CO, int LMODE, int TW, int TH, int NS, int ND, int NWV, int WPS>
 static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream_t st) {
   if (dy_pro == PRO_BWD) {
-    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, ND, WPS, ava_bf16>(a, grid, st);
-    return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, ND, WPS, float>(a, grid, st);
+    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, ava_bf16>(a, grid, st);
+    return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, float>(a, grid, st);
   }
   if (dy_pro == PRO_ID) {
-    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, ND, WPS, ava_bf16>(a, grid, st);
-    return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, ND, WPS, float>(a, grid, st);
+    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, NS, ND, NWV, WPS, ava_bf16>(a, grid, st);
+    return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, NS, ND, NWV, WPS, float>(a, grid, st);
   }
   return AVA_EINVAL;
 }
 
 // Shapes with a limb instantiation: (cin, cout, mode) -> low-resolution tile (the fp32 kernel's, so that the grid and the
 // partial-row count of ava_conv_fused_grid_for hold for both), data-gradient waves, waves per SIMD.
-#define AVA_FUSED_LIMB_SHAPES(X) \
-  X(8, 16, MODE_S1, 32, 4, 2, 4)  \
-  X(16, 8, MODE_S1, 32, 4, 2, 4)
+#define AVA_FUSED_LIMB_SHAPES(X)         \
+  X(8, 16, MODE_S1, 32, 4, 8, 4, 4, 4)  \
+  X(16, 8, MODE_S1, 32, 4, 8, 4, 4, 4)
 
 bool ava_conv_fused_limb_has(int Cin, int Cout, int mode) {
-#define X(ci, co, md, tww, thh, nd, wps) if (Cin == ci && Cout == co && mode == md) return true;
+#define X(ci, co, md, tww, thh, ns, nd, nwv, wps) if (Cin == ci && Cout == co && mode == md) return true;
   AVA_FUSED_LIMB_SHAPES(X)
 #undef X
   return false;
 }
 
+// workgroups of one resident wave of the limb kernel (= its grid cap = partial rows); 0: no limb instantiation
+int ava_conv_fused_limb_cap(int Cin, int Cout, int mode) {
+#define X(ci, co, md, tww, thh, ns, nd, nwv, wps) if (Cin == ci && Cout == co && mode == md) return 256 * (wps * 4 / (ns + nd + nwv));
+  AVA_FUSED_LIMB_SHAPES(X)
+#undef X
+  return 0;
+}
+
 // AVA_EINVAL when the shape has no limb instantiation (the caller then runs the fp32 kernel)
 int ava_conv3x3_bwd_fused_limb_launch(const FusedArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
   if (a.rcd.G1 != nullptr || a.rc.G1 != nullptr || a.dx == nullptr) return AVA_EINVAL;
-#define X(ci, co, md, tww, thh, nd, wps) \
-  if (Cin == ci && Cout == co && mode == md) return launch_fused_limb<ci, co, md, tww, thh, nd, wps>(a, grid, dy_pro, st);
+#define X(ci, co, md, tww, thh, ns, nd, nwv, wps) \
+  if (Cin == ci && Cout == co && mode == md) return launch_fused_limb<ci, co, md, tww, thh, ns, nd, nwv, wps>(a, grid, dy_pro, st);
   AVA_FUSED_LIMB_SHAPES(X)
 #undef X
   return AVA_EINVAL;

@@ -40,5 +40,5 @@ int ava_thin_bwd_fused_launch(const FusedArgs& a, int grid, int Cin, int dy_pro,
 
 // the same backward with both products on bf16 limb MFMA (conv_fused_limb.hip); AVA_EINVAL: no limb instantiation
 bool ava_conv_fused_limb_has(int Cin, int Cout, int mode);
-int ava_conv_fused_limb_cap(int Cin, int Cout, int mode);
+int ava_conv_fused_limb_cap(int Cin, int Cout, int mode, int* tw, int* th);
 int ava_conv3x3_bwd_fused_limb_launch(const FusedArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st);

@@ -795,13 +795,19 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
   const int thin = ava_thin_fused_grid(B, Hi, Wi, Cin, Cout, mode);
   if (thin > 0) return thin;
   int tw, th;
-  if (!fused_tile(Cin, Cout, mode, &tw, &th)) return 0;
   const int hl = mode == MODE_DOWN ? Hi / 2 : Hi, wl = mode == MODE_DOWN ? Wi / 2 : Wi;
+  if (fused_limb_on()) {                        // the limb kernel's own tile and resident-wave size (conv_fused_limb.hip)
+    const int lcap = ava_conv_fused_limb_cap(Cin, Cout, mode, &tw, &th);
+    if (lcap > 0 && hl % th == 0 && wl % tw == 0) {
+      const int nt = B * (hl / th) * (wl / tw);
+      return nt < ava_scale_grid(lcap) ? nt : ava_scale_grid(lcap);
+    }
+  }
+  if (!fused_tile(Cin, Cout, mode, &tw, &th)) return 0;
   if (hl % th != 0 || wl % tw != 0) return 0;
   const int nt = B * (hl / th) * (wl / tw);
   bool ws; int cap;
   fused_defaults(Cin, Cout, mode, &ws, &cap);   // 512 = two resident 256-thread workgroups per CU (384 / 768 / 1024 are slower)
-  if (fused_limb_on() && ava_conv_fused_limb_cap(Cin, Cout, mode) > 0) cap = ava_conv_fused_limb_cap(Cin, Cout, mode);
   return nt < ava_scale_grid(cap) ? nt : ava_scale_grid(cap);
 }
 
@@ -812,8 +818,10 @@ int ava_conv3x3_bwd_fused_launch(const FusedArgs& a_, int Cin, int Cout, int mod
   if (grid <= 0) return AVA_EINVAL;
   if (Cin == 1 || Cout == 1) return ava_thin_bwd_fused_launch(a, grid, Cin, dy_pro, st);
   if (a.dx == nullptr) return AVA_EINVAL;
-  if (fused_limb_on() && a.rcd.G1 == nullptr && ava_conv_fused_limb_has(Cin, Cout, mode))
-    return ava_conv3x3_bwd_fused_limb_launch(a, grid, Cin, Cout, mode, dy_pro, st);
+  if (fused_limb_on() && a.rcd.G1 == nullptr && ava_conv_fused_limb_has(Cin, Cout, mode)) {
+    const int rc = ava_conv3x3_bwd_fused_limb_launch(a, grid, Cin, Cout, mode, dy_pro, st);
+    if (rc != AVA_EINVAL) return rc;            // AVA_EINVAL: the image does not divide into the limb kernel's tiles
+  }
   const int var = fused_variant();
 #define X(ci, co, md, vr, tww, thh, mw)                                                            \
   if (Cin == ci && Cout == co && mode == md && var == vr) {                                         \

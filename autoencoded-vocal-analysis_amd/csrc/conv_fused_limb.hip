@@ -401,7 +401,8 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 #pragma unroll 1
       for (int ks = 0; ks < KSTEPS; ++ks) {
         // step origin in step-pixel units (dU interior pixels; LMODE_UP: x pixels)
-        const int sy = KW == 32 ? ks / (TW / 32) : 2 * ks, sx0 = KW == 32 ? 32 * (ks % (TW / 32)) : 0;
+        constexpr int SPR = TW >= 32 ? TW / 32 : 1;          // K steps per tile row
+        const int sy = KW == 32 ? ks / SPR : 2 * ks, sx0 = KW == 32 ? 32 * (ks % SPR) : 0;
         ava_lds_u8* const xs = xl + (SA * sy * XC + SA * sx0) * 16;
         ava_lds_u8* const ds = dl + (SB * sy * DC + SB * sx0) * 16;
         auto one = [&](auto cls_c) __attribute__((always_inline)) {
@@ -519,11 +520,36 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
   return AVA_EINVAL;
 }
 
-// Shapes with a limb instantiation: (cin, cout, mode) -> low-resolution tile (the fp32 kernel's, so that the grid and the
-// partial-row count of ava_conv_fused_grid_for hold for both), data-gradient waves, waves per SIMD.
-#define AVA_FUSED_LIMB_SHAPES(X)         \
-  X(8, 16, MODE_S1, 32, 4, 8, 4, 4, 4)  \
-  X(16, 8, MODE_S1, 32, 4, 8, 4, 4, 4)
+// Shapes with a limb instantiation: (cin, cout, mode) -> low-resolution tile, staging / data-gradient / weight-gradient waves,
+// waves per SIMD.  Measured in the step at batch 256 (tools/run_r04.sh variants; fp32 kernel -> this one):
+//   conv3  8 -> 16 S1   82.5 -> 63.6 us   1024 threads, 32 x 4 tiles (768 threads: 67.8; 32 x 8 tiles: 63.8)
+//   convt5 16 -> 8 S1   92.3 -> 62.4 us   768 threads (168 VGPRs), 32 x 8 tiles (1024 threads, 32 x 4: 68.6)
+//   conv5  16 -> 24 S1  65.7 -> 43.8 us   768 threads: the data-gradient waves hold 84 VGPRs of limb weights
+//   convt3 24 -> 16 S1  63.8 -> 46.2 us   the two dx channel tiles dealt to odd / even data-gradient waves
+//   convt4 16 -> 16 UP  43.8 -> 41.3 us
+// Not (yet) here: conv4 16 -> 16 DOWN (50.7 -> 63.8 us) and conv2 8 -> 8 DOWN (106.6 -> 122.4 us) on 16 x 4 tiles -- one
+// workgroup per CU keeps ONE small tile in flight where the fp32 kernel's two workgroups keep two -- and convt6, whose dU
+// window is gathered from the 1-channel seed by the staging waves (conv_recomp.h).
+// (lab experiments: -DAVA_FL_CFG="th, ns, nd, nwv, wps" overrides conv3's row: tools/lab/build_variant.sh)
+#ifndef AVA_FL_CFG
+#define AVA_FL_CFG 4, 8, 4, 4, 4
+#endif
+#ifndef AVA_FL_CFG2
+#define AVA_FL_CFG2 8, 4, 4, 4, 3
+#endif
+#define AVA_FL_ROW(X, ci, co, md, tww, ...) X(ci, co, md, tww, __VA_ARGS__)
+#ifdef AVA_FL_ALL
+#define AVA_FL_EXTRA(X) X(16, 16, MODE_DOWN, 16, 4, 8, 4, 4, 4) X(8, 8, MODE_DOWN, 16, 4, 8, 4, 4, 4)
+#else
+#define AVA_FL_EXTRA(X)
+#endif
+#define AVA_FUSED_LIMB_SHAPES(X)                    \
+  AVA_FL_ROW(X, 8, 16, MODE_S1, 32, AVA_FL_CFG)     \
+  AVA_FL_ROW(X, 16, 8, MODE_S1, 32, AVA_FL_CFG2)    \
+  X(16, 16, MODE_UP, 16, 4, 8, 4, 4, 4)             \
+  X(24, 16, MODE_S1, 32, 4, 8, 4, 4, 4)             \
+  X(16, 24, MODE_S1, 32, 4, 4, 4, 4, 3)             \
+  AVA_FL_EXTRA(X)
 
 bool ava_conv_fused_limb_has(int Cin, int Cout, int mode) {
 #define X(ci, co, md, tww, thh, ns, nd, nwv, wps) if (Cin == ci && Cout == co && mode == md) return true;
@@ -532,9 +558,11 @@ bool ava_conv_fused_limb_has(int Cin, int Cout, int mode) {
   return false;
 }
 
-// workgroups of one resident wave of the limb kernel (= its grid cap = partial rows); 0: no limb instantiation
-int ava_conv_fused_limb_cap(int Cin, int Cout, int mode) {
-#define X(ci, co, md, tww, thh, ns, nd, nwv, wps) if (Cin == ci && Cout == co && mode == md) return 256 * (wps * 4 / (ns + nd + nwv));
+// workgroups of one resident wave of the limb kernel (= its grid cap = partial rows) and its low-resolution tile;
+// 0: no limb instantiation
+int ava_conv_fused_limb_cap(int Cin, int Cout, int mode, int* tw, int* th) {
+#define X(ci, co, md, tww, thh, ns, nd, nwv, wps) \
+  if (Cin == ci && Cout == co && mode == md) { *tw = tww; *th = thh; return 256 * (wps * 4 / (ns + nd + nwv)); }
   AVA_FUSED_LIMB_SHAPES(X)
 #undef X
   return 0;

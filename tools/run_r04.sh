@@ -29,6 +29,17 @@ case $pass in
     timeout 600 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err
     head -c 300 $out/bench.json
     ;;
+  variants)
+    # same-box A/B of library variants (tools/lab/build_variant.sh): kernel parity of each, then the step under the kernel trace
+    for v in "" v1 v2 v3 v4 v5; do
+      if [ -n "$v" ] && [ ! -f autoencoded-vocal-analysis_amd/csrc/libava_hip_$v.so ]; then continue; fi
+      export AVA_HIP_LIB_TAG=$v
+      timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "backward_data_and_wgrad" > $out/pytest_kern_$v.log 2>&1; echo "pytest rc $?" >> $out/pytest_kern_$v.log
+      tail -n 3 $out/pytest_kern_$v.log
+      prof step_$v
+      echo "== variant '$v'"; python3 tools/kstats.py $out/step_${v}_kernel_stats.csv 65 | grep -E "bwd_fused|total"
+    done
+    ;;
   prof)
     prof step
     python3 tools/kstats.py $out/step_kernel_stats.csv 25 | head -60

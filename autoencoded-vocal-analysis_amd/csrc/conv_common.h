@@ -150,7 +150,9 @@ template <typename T> __device__ __forceinline__ const T* ava_as(const float* p)
 template <typename T> __device__ __forceinline__ T* ava_as(float* p) { return reinterpret_cast<T*>(p); }
 
 // TIN / TIN2: storage types of `in` and of `in2` (the saved activation of prologue PRO_BWD)
-template <int CIN, int PRO, int R, int C, bool PLANES = false, int NT = 256, typename TIN = float, typename TIN2 = float>
+// MAXQP: most coefficient sets a thread keeps in registers for a whole call (see QP below); beyond that the sets are read
+// from LDS element by element
+template <int CIN, int PRO, int R, int C, bool PLANES = false, int NT = 256, typename TIN = float, typename TIN2 = float, int MAXQP = 4>
 struct TileStager {
   static_assert(CIN % 4 == 0, "vector staging needs a multiple of 4 channels");
   static constexpr int Q = CIN / 4;
@@ -213,7 +215,7 @@ struct TileStager {
   // the QP coefficient sets are fetched once per call (Coefs) and element i takes set i mod QP.
   static constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
   static constexpr int QP = (NT % Q == 0) ? 1 : Q / gcd_(NT % Q, Q);
-  static constexpr bool SAMEQ = QP <= 4;            // coefficient sets held in registers for the whole call
+  static constexpr bool SAMEQ = QP <= MAXQP;        // coefficient sets held in registers for the whole call
   static constexpr int NKQ = SAMEQ ? (QP < NPF ? QP : NPF) : 1;
   struct Coef { avaf4 a, b, c; };
   struct Coefs { Coef k[NKQ]; };
@@ -313,9 +315,9 @@ __device__ __forceinline__ void ava_limb_split2(float x, float y, uint32_t& p0, 
 // TileStager for the limb kernels: same loads, prologue and masks; the tile lands in LDS as three limb planes, each
 // [CIN / 8 channel octets][R * C pixels][8 channels] bf16 -- a pixel's octet is one 16-byte slot and the 16 pixels of a
 // matrix-core group are 256 contiguous bytes (conflict-free ds_read_b128 fragments).
-template <int CIN, int PRO, int R, int C, int NT = 256, typename TIN = float, typename TIN2 = float>
-struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2> {
-  using Base = TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2>;
+template <int CIN, int PRO, int R, int C, int NT = 256, typename TIN = float, typename TIN2 = float, int MAXQP = 4>
+struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2, MAXQP> {
+  using Base = TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2, MAXQP>;
   static_assert(CIN % 8 == 0, "limb planes are made of channel octets");
   static constexpr int NPIX = R * C, Q8 = CIN / 8;
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;

@@ -818,7 +818,7 @@ int ava_conv3x3_bwd_fused_launch(const FusedArgs& a_, int Cin, int Cout, int mod
   if (grid <= 0) return AVA_EINVAL;
   if (Cin == 1 || Cout == 1) return ava_thin_bwd_fused_launch(a, grid, Cin, dy_pro, st);
   if (a.dx == nullptr) return AVA_EINVAL;
-  if (fused_limb_on() && a.rcd.G1 == nullptr && ava_conv_fused_limb_has(Cin, Cout, mode)) {
+  if (fused_limb_on() && ava_conv_fused_limb_has(Cin, Cout, mode)) {
     const int rc = ava_conv3x3_bwd_fused_limb_launch(a, grid, Cin, Cout, mode, dy_pro, st);
     if (rc != AVA_EINVAL) return rc;            // AVA_EINVAL: the image does not divide into the limb kernel's tiles
   }

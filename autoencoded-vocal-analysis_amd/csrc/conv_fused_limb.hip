@@ -25,6 +25,7 @@
 #include <type_traits>
 #include "conv_mfma.h"
 #include "conv_fused.h"
+#include "conv_recomp.h"
 
 typedef short ava_s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned char ava_lds_u8;
@@ -70,7 +71,10 @@ template <int LMODE> __host__ __device__ constexpr int wl_units(int cin) { retur
 // NS / ND / NWV: staging, data-gradient and weight-gradient waves of the workgroup (64 * (NS + ND + NWV) threads; waves are dealt
 // to the four SIMDs in turn, so with NS, ND and NWV multiples of 4 every SIMD hosts the same mix of roles).
 // WPS: minimum waves per SIMD for the register allocator (workgroups per CU x waves of a workgroup / 4)
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT>
+// DUREC (convt6's backward): the upstream gradient dy (8 channels, full resolution) does not exist in memory -- it is convt7's
+// data gradient, a 3x3 gather of the 1-channel seed a.dy, formed on the matrix cores by the (four) staging waves as they build
+// the dU tile (conv_recomp.h: DU1to8Stager; its limb-plane store below).
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false>
 __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_limb_kernel(const FusedArgs a) {
   using FG = FGeomL<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
@@ -96,6 +100,15 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   float* cx = reinterpret_cast<float*>(smem_b + 2 * BUF);     // [3][32]
   float* cd = cx + 96;                                         // [3][32]
   float* red = cd + 96;                                        // [ND][32 * MT]: per data-gradient wave {sum g [16 MT], sum g x [16 MT]}
+  // the data-gradient weights' third limb as an LDS table (ClassFragL: W2L) where one wave holds ALL of a class's chunks
+  // (single-class gathers): the role then fits 128 VGPRs with room to spare
+  constexpr bool W2L = BCLS == 1;
+  constexpr int DKG = PAIR ? 12 * (CO / 8) : 9 * (CO / 8);     // k-groups of the (single) data-gradient class
+  constexpr int W2_TILE = W2L ? ((DKG + 3) / 4) * 1024 : 0;    // bytes per dx channel tile
+  constexpr int W2_ALL = W2_TILE * MT;
+  unsigned char* w2tab = reinterpret_cast<unsigned char*>(red + ND * 32 * MT);
+  float* xs = reinterpret_cast<float*>(w2tab + W2_ALL);        // DUREC: the staging waves' private seed windows
+  static_assert(!DUREC || (CO == 8 && DYPRO == PRO_BWD && DR == 9 && NS == 4), "the 1 -> 8 gather feeds a 9-row dU window of 8 channels from four staging waves");
   __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
   __shared__ float ems[64];                 // mean [0..31], invstd [32..63] of x's BatchNorm for the final reduction
 
@@ -122,8 +135,13 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     else { gy = 2 * y0 - 1; gx = 2 * x0 - 1; }
   };
   TileWalk walk(a.ntiles);
-  TileStagerL<CI, PRO_BN, XR, XC, NST, ACT, ACT> sx;          // staging waves only (threadIdx.x 0 .. NST-1)
-  TileStagerL<CO, DYPRO, DR, DC, NST, float, ACT> sd;
+  // (coefficient sets in registers only where a thread's elements share ONE channel quad: three sets of the 24-channel
+  // tensors are 24-36 VGPRs of a role that has to fit beside two others)
+  TileStagerL<CI, PRO_BN, XR, XC, NST, ACT, ACT, 1> sx;       // staging waves only (threadIdx.x 0 .. NST-1)
+  typename std::conditional<DUREC, DU1to8Stager<DC, ACT>, TileStagerL<CO, DYPRO, DR, DC, NST, float, ACT, 1>>::type sd;
+  auto sd_store = [&](unsigned char* dst) __attribute__((always_inline)) {
+    if constexpr (DUREC) sd.store_limb(dst, cd, xs); else sd.store(dst, cd);
+  };
   auto prefetch = [&](int tl) {
     int b, y0, x0, gy, gx;
     origin(tl, b, y0, x0);
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   };
   if (stager) {
     sx.init();
-    sd.init();
+    if constexpr (DUREC) sd.init(a.rcd, xs); else sd.init();
     if (walk.valid()) prefetch(walk.cur);    // tile 0 goes in flight BEFORE the coefficient prologue
   }
   // everything the prologue and the epilogue read from global memory is requested in front of the coefficient finalisation
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     __builtin_amdgcn_s_setprio(3);           // issue priority over the matrix-core waves of the same SIMD (conv_fused.hip)
     if (walk.valid()) {
       sx.store(smem_b, cx);
-      sd.store(smem_b + XBYTES, cd);
+      sd_store(smem_b + XBYTES);
       if (walk.has_next()) prefetch(walk.next());
     }
     __syncthreads();                                            // (A) tile 0 ready
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
       if (walk.has_next()) {                                    // tile it+1 -> the other buffer, tile it+2 in flight
         unsigned char* nb = smem_b + ((it + 1) & 1) * BUF;
         sx.store(nb, cx);
-        sd.store(nb + XBYTES, cd);
+        sd_store(nb + XBYTES);
         const int nn = walk.next() + walk.step;
         if (nn < walk.end) prefetch(nn);
       }
@@ -193,123 +211,174 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 
   if (wave8 < NS + ND) {
     // ---------------- data-gradient waves ----------------
+    // Stride-2 conv layers (dx gathered in four output-parity classes): with four data-gradient waves each wave takes ONE
+    // class for all of the tile's pixel groups and holds only that class's limb weights (1-2 chunks instead of 5: with all
+    // four classes in every wave the role needed > 128 VGPRs, and spill reloads inside a latency-bound loop cost 4x the tile).
+    constexpr bool CSPLIT = BMODE == MODE_UP && ND == 4 && !DSPLIT;
     const int dw = wave8 - NS;
-    const int mtb = DSPLIT ? (dw & 1) : 0;                      // first dx channel tile of this wave
-    const int dgi = DSPLIT ? (dw >> 1) : dw;                    // which share of the pixel groups
-    constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
-    typename std::conditional<PAIR, PairFragL<CO, DC, DNPIX>, ClassFragL<CO, CI, BMODE, 0, DC, DNPIX, MTD>>::type f0;
-    ClassFragL<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC, DNPIX, MTD> f1;
-    ClassFragL<CO, CI, BMODE, (BCLS > 1 ? 2 : 0), DC, DNPIX, MTD> f2;
-    ClassFragL<CO, CI, BMODE, (BCLS > 1 ? 3 : 0), DC, DNPIX, MTD> f3;
-    f0.init(a.Gb, lane, SPB * n, mtb);
-    if (BCLS > 1) { f1.init(a.Gb, lane, n, mtb); f2.init(a.Gb, lane, n, mtb); f3.init(a.Gb, lane, n, mtb); }
-    const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
-    const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
-    float s1[MTD][4], s2[MTD][4];
+    auto d_role = [&](auto dcls_c) __attribute__((always_inline)) {
+      constexpr int DCLS = decltype(dcls_c)::value;               // CSPLIT: this wave's class; otherwise 0
+      const int mtb = DSPLIT ? (dw & 1) : 0;                      // first dx channel tile of this wave
+      const int dgi = CSPLIT ? 0 : (DSPLIT ? (dw >> 1) : dw);     // which share of the pixel groups
+      constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
+      typename std::conditional<PAIR, PairFragL<CO, DC, DNPIX, W2L>, ClassFragL<CO, CI, BMODE, (CSPLIT ? DCLS : 0), DC, DNPIX, MTD, W2L>>::type f0;
+      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 1 : 0), DC, DNPIX, MTD> f1;
+      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 2 : 0), DC, DNPIX, MTD> f2;
+      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 3 : 0), DC, DNPIX, MTD> f3;
+      f0.init(a.Gb, lane, SPB * n, mtb, w2tab + mtb * W2_TILE);
+      if (BCLS > 1 && !CSPLIT) { f1.init(a.Gb, lane, n, mtb); f2.init(a.Gb, lane, n, mtb); f3.init(a.Gb, lane, n, mtb); }
+      const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
+      const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
+      float s1[MTD][4], s2[MTD][4];
 #pragma unroll
-    for (int mt = 0; mt < MTD; ++mt)
+      for (int mt = 0; mt < MTD; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s1[mt][r] = s2[mt][r] = 0.f;
+        for (int r = 0; r < 4; ++r) s1[mt][r] = s2[mt][r] = 0.f;
 
-    // pixel groups of the dx region: 16 consecutive pixels of a row (UP pattern: of one parity class)
-    constexpr int CB = FG::OW / (BMODE == MODE_UP ? 32 : 16);          // column blocks
-    constexpr int GROUPS = PAIR ? (FG::OH / 2) * CB : (BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB);
-    constexpr int GPW = GROUPS / NDG;
-    static_assert(GROUPS % NDG == 0 && (BMODE != MODE_UP || GPW % 4 == 0), "tile must split evenly over the data-gradient waves");
-    const int g0 = dgi * GPW;
-    auto group_out = [&](int g) -> int {
-      if (BMODE == MODE_UP) {
-        const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
-        return ((2 * r + (cls >> 1)) * a.Wi + 32 * cb + (cls & 1)) * CI;
-      }
-      return (((PAIR ? 2 : 1) * (g / CB)) * a.Wi + 16 * (g % CB)) * CI;
-    };
-    // raw x at this lane's dx pixels (BatchNorm-backward sums), loaded one tile ahead (conv_fused.hip)
-    avaf4 ex[GPW * MTD];
-    auto load_ex = [&](int tl) {
-      int b, y0, x0;
-      origin(tl, b, y0, x0);
-      const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
-      const ACT* __restrict__ xb = ava_as<ACT>(a.x) + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
-#pragma unroll
-      for (int gi = 0; gi < GPW; ++gi)
+      // pixel groups of the dx region: 16 consecutive pixels of a row (UP pattern: of one parity class)
+      constexpr int CB = FG::OW / (BMODE == MODE_UP ? 32 : 16);          // column blocks
+      constexpr int GROUPS = PAIR ? (FG::OH / 2) * CB : (BMODE == MODE_UP ? 4 * (FG::OH / 2) * CB : FG::OH * CB);
+      constexpr int GPW = CSPLIT ? GROUPS / 4 : GROUPS / NDG;
+      static_assert(GROUPS % NDG == 0 && (BMODE != MODE_UP || CSPLIT || GPW % 4 == 0), "tile must split evenly over the data-gradient waves");
+      // the gi-th group of this wave
+      auto group_of = [&](int gi) -> int { return CSPLIT ? 4 * gi + DCLS : dgi * GPW + gi; };
+      auto group_out = [&](int g) -> int {
+        if (BMODE == MODE_UP) {
+          const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
+          return ((2 * r + (cls >> 1)) * a.Wi + 32 * cb + (cls & 1)) * CI;
+        }
+        return (((PAIR ? 2 : 1) * (g / CB)) * a.Wi + 16 * (g % CB)) * CI;
+      };
+      // raw x at this lane's dx pixels (BatchNorm-backward sums): a ring of LA groups in flight -- group gi's values are
+      // requested LA groups ahead of their use (the lines were fetched by the staging waves a tile or two earlier: L2 hits),
+      // running on into the first groups of the next tile.
+      constexpr int LA = GPW < 3 ? GPW : 3;
+      // the group loop stays rolled where a wave has many groups (unrolled 8 times the register allocator spilled 200
+      // values inside the loop); the class of a group must be a compile-time constant unless the wave owns one class.
+      // Four groups: measured per shape -- rolled wins where the wave also carries the runtime channel-tile offset of
+      // DSPLIT (convt3 49.4 -> 42.6 us), unrolled elsewhere (conv4 45.5 vs 55.7, convt5 61.7 vs 69.2 us)
+      constexpr bool ROLLED = (GPW > 4 || (GPW > 2 && DSPLIT)) && (BMODE != MODE_UP || CSPLIT);
+      avaf4 ring[LA][MTD];
+      auto load_ex_group = [&](const ACT* __restrict__ xb, int gi, avaf4 (&dst)[MTD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < MTD; ++mt) {
           const int cb4 = 16 * (mtb + mt) + cq;
           // lanes whose 4-channel slot lies beyond CI re-read slot 0: stays in bounds
-          ex[gi * MTD + mt] = ava_ld4<ACT>(xb + group_out(g0 + gi) + (cb4 < CI ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
+          dst[mt] = ava_ld4<ACT>(xb + group_out(group_of(gi)) + (cb4 < CI ? lane_out + 16 * (mtb + mt) : lane_out - 4 * kg));
         }
-    };
-    if (walk.valid()) load_ex(walk.cur);
-    __syncthreads();                                              // (A)
-    int it = 0;
-    for (; walk.valid(); walk.advance(), ++it) {
-      int b, y0, x0;
-      origin(walk.cur, b, y0, x0);
-      const unsigned char* dut = smem_b + (it & 1) * BUF + XBYTES;
-      const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
-      const size_t tile_pix = ((size_t)b * a.Hi + oy0) * a.Wi + ox0;
-      float* __restrict__ obase = a.dx + tile_pix * CI;
+      };
+      auto ex_base = [&](int tl) -> const ACT* {
+        int b, y0, x0;
+        origin(tl, b, y0, x0);
+        const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+        return ava_as<ACT>(a.x) + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
+      };
+      if (walk.valid()) {
+        const ACT* __restrict__ xb = ex_base(walk.cur);
 #pragma unroll
-      for (int gi = 0; gi < GPW; ++gi) {
-        const int g = g0 + gi;
-        f32x4 acc[2][MTD];
+        for (int gi = 0; gi < LA; ++gi) load_ex_group(xb, gi, ring[gi]);
+      }
+      __syncthreads();                                              // (A)
+      int it = 0;
+      for (; walk.valid(); walk.advance(), ++it) {
+        int b, y0, x0;
+        origin(walk.cur, b, y0, x0);
+        const unsigned char* dut = smem_b + (it & 1) * BUF + XBYTES;
+        const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
+        const size_t tile_pix = ((size_t)b * a.Hi + oy0) * a.Wi + ox0;
+        float* __restrict__ obase = a.dx + tile_pix * CI;
+        const ACT* __restrict__ xcur = ava_as<ACT>(a.x) + tile_pix * CI;
+        const ACT* __restrict__ xnext = walk.has_next() ? ex_base(walk.next()) : xcur;     // (last tile: harmless re-reads)
+        auto do_group = [&](int gi) __attribute__((always_inline)) {
+          const int g = group_of(gi);
+          avaf4 exv[MTD];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+          for (int mt = 0; mt < MTD; ++mt) exv[mt] = ring[0][mt];
 #pragma unroll
-          for (int mt = 0; mt < MTD; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (BMODE == MODE_UP) {
-          const int cls = gi & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;   // GPW % 4 == 0: cls is compile-time
-          const unsigned char* px = dut + (r * DC + 16 * cb) * 16;
-          if (cls == 0) f0.run(px, acc);
-          else if (cls == 1) f1.run(px, acc);
-          else if (cls == 2) f2.run(px, acc);
-          else f3.run(px, acc);
-        } else {
-          constexpr int S = (BMODE == MODE_S1 && !PAIR) ? 1 : 2;        // PAIR: a group is a pair of dx rows
-          constexpr int SX = BMODE == MODE_DOWN ? 2 : 1;
-          f0.run(dut + (S * (g / CB) * DC + SX * 16 * (g % CB)) * 16, acc);
-        }
-        const int gout = group_out(g) + lane_out;
+          for (int k = 0; k + 1 < LA; ++k)
 #pragma unroll
-        for (int mt = 0; mt < MTD; ++mt) {
-          const int cb4 = 16 * (mtb + mt) + cq;
-          if (cb4 < CI) {
-            const f32x4 v = acc[0][mt] + acc[1][mt];
-            const avaf4 xr = ex[gi * MTD + mt];
+            for (int mt = 0; mt < MTD; ++mt) ring[k][mt] = ring[k + 1][mt];
+          {
+            const int gn = gi + LA;                                  // the group LA ahead: of this tile or of the next one
+            load_ex_group(gn < GPW ? xcur : xnext, gn < GPW ? gn : gn - GPW, ring[LA - 1]);
+          }
+          f32x4 acc[2][MTD];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s1[mt][r] += v[r];
-              s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (BMODE == MODE_UP) {
+            const int rest = g >> 2, r = rest / CB, cb = rest % CB;
+            const unsigned char* px = dut + (r * DC + 16 * cb) * 16;
+            if constexpr (CSPLIT) {
+              f0.run(px, acc);
+            } else {
+              const int cls = gi & 3;                                // GPW % 4 == 0 and the loop is unrolled: compile-time
+              if (cls == 0) f0.run(px, acc);
+              else if (cls == 1) f1.run(px, acc);
+              else if (cls == 2) f2.run(px, acc);
+              else f3.run(px, acc);
             }
-            *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            constexpr int S = (BMODE == MODE_S1 && !PAIR) ? 1 : 2;        // PAIR: a group is a pair of dx rows
+            constexpr int SX = BMODE == MODE_DOWN ? 2 : 1;
+            f0.run(dut + (S * (g / CB) * DC + SX * 16 * (g % CB)) * 16, acc);
+          }
+          const int gout = group_out(g) + lane_out;
+#pragma unroll
+          for (int mt = 0; mt < MTD; ++mt) {
+            const int cb4 = 16 * (mtb + mt) + cq;
+            if (cb4 < CI) {
+              const f32x4 v = acc[0][mt] + acc[1][mt];
+              const avaf4 xr = exv[mt];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                s1[mt][r] += v[r];
+                s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
+              }
+              *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        };
+        if constexpr (ROLLED) {
+#pragma unroll 1
+          for (int gi = 0; gi < GPW; ++gi) do_group(gi);
+        } else {
+#pragma unroll
+          for (int gi = 0; gi < GPW; ++gi) do_group(gi);
+        }
+        __syncthreads();                                            // (B)
+      }
+      // ---- BatchNorm-backward partial sums: over the 16 pixel lanes, then over the data-gradient waves (fixed order) ----
+#pragma unroll
+      for (int mt = 0; mt < MTD; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v1 = s1[mt][r], v2 = s2[mt][r];
+          {
+            // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here
+            const int cc = 16 * (mtb + mt) + cq + r;
+            const float mu = ems[cc & 31], is = ems[32 + (cc & 31)];  // requested in the prologue (zero beyond CI)
+            v2 = fmaf(-mu, v1, v2) * is;
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+          if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair
+          if (n == 0 && (!PAIR || kg < 2)) {
+            const int ci = 16 * (mtb + mt) + cq + r;
+            red[dw * 32 * MT + ci] = v1;
+            red[dw * 32 * MT + 16 * MT + ci] = v2;
           }
         }
-      }
-      if (walk.has_next()) load_ex(walk.next());
-      __syncthreads();                                            // (B)
+    };
+    if constexpr (CSPLIT) {
+      if (dw == 0) d_role(ava_ic<0>{});
+      else if (dw == 1) d_role(ava_ic<1>{});
+      else if (dw == 2) d_role(ava_ic<2>{});
+      else d_role(ava_ic<3>{});
+    } else {
+      d_role(ava_ic<0>{});
     }
-    // ---- BatchNorm-backward partial sums: over the 16 pixel lanes, then over the data-gradient waves (fixed order) ----
-#pragma unroll
-    for (int mt = 0; mt < MTD; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v1 = s1[mt][r], v2 = s2[mt][r];
-        {
-          // the hot loop accumulates sum g*x on RAW x; centred and scaled once per lane here
-          const int cc = 16 * (mtb + mt) + cq + r;
-          const float mu = ems[cc & 31], is = ems[32 + (cc & 31)];  // requested in the prologue (zero beyond CI)
-          v2 = fmaf(-mu, v1, v2) * is;
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
-        if (PAIR) { v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); }   // the two rows of a pair
-        if (n == 0 && (!PAIR || kg < 2)) {
-          const int ci = 16 * (mtb + mt) + cq + r;
-          red[dw * 32 * MT + ci] = v1;
-          red[dw * 32 * MT + 16 * MT + ci] = v2;
-        }
-      }
     __syncthreads();                                              // (E)
     const int tc = t - NST;                                       // first data-gradient wave: 2 * CI <= 64 lanes
     if (tc < 2 * CI) {
@@ -481,15 +550,17 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT>
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false>
 static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   using FG = FGeomL<LMODE, TW, TH>;
   constexpr int MT = (CI + 15) / 16;
   constexpr size_t buf = (size_t)3 * 16 * ((CI / 8) * FG::XR * FG::XC + (CO / 8) * FG::DR * FG::DC);
-  constexpr size_t lds = 2 * buf + (192 + ND * 32 * MT) * sizeof(float);
+  constexpr bool PAIRL = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
+  constexpr int W2_ALL = LMODE == MODE_DOWN ? 0 : (((PAIRL ? 12 : 9) * (CO / 8) + 3) / 4) * 1024 * MT;   // the kernel's third-limb table
+  constexpr size_t lds = 2 * buf + (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL;
   constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
   static_assert(WG_PER_CU >= 1 && (lds + 1024) * WG_PER_CU <= 160 * 1024, "the resident workgroups' tile buffers must fit 160 KB of LDS");
-  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT>);
+  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC>);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVA_ELAUNCH;
@@ -502,13 +573,21 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   b.tiles_x = wl / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
-  hipLaunchKernelGGL((conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT>), dim3(grid), dim3(64 * (NS + ND + NWV)), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC>), dim3(grid), dim3(64 * (NS + ND + NWV)), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
 template <int CI, int CO, int LMODE, int TW, int TH, int NS, int ND, int NWV, int WPS>
 static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream_t st) {
+  if constexpr (CI == 8 && CO == 8 && LMODE == MODE_UP && TH == 4 && NS == 4) {
+    if (a.rcd.G1 != nullptr) {            // convt6's backward with convt7's data gradient formed in the staging waves
+      if (dy_pro != PRO_BWD) return AVA_EINVAL;
+      if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, ava_bf16, true>(a, grid, st);
+      return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, float, true>(a, grid, st);
+    }
+  }
+  if (a.rcd.G1 != nullptr) return AVA_EINVAL;
   if (dy_pro == PRO_BWD) {
     if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, ava_bf16>(a, grid, st);
     return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, float>(a, grid, st);
@@ -532,24 +611,48 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 // window is gathered from the 1-channel seed by the staging waves (conv_recomp.h).
 // (lab experiments: -DAVA_FL_CFG="th, ns, nd, nwv, wps" overrides conv3's row: tools/lab/build_variant.sh)
 #ifndef AVA_FL_CFG
-#define AVA_FL_CFG 4, 8, 4, 4, 4
+#define AVA_FL_CFG 32, 4, 8, 4, 4, 4          // conv3
 #endif
 #ifndef AVA_FL_CFG2
-#define AVA_FL_CFG2 8, 4, 4, 4, 3
+#define AVA_FL_CFG2 32, 8, 8, 4, 4, 4         // convt5
 #endif
-#define AVA_FL_ROW(X, ci, co, md, tww, ...) X(ci, co, md, tww, __VA_ARGS__)
-#ifdef AVA_FL_ALL
-#define AVA_FL_EXTRA(X) X(16, 16, MODE_DOWN, 16, 4, 8, 4, 4, 4) X(8, 8, MODE_DOWN, 16, 4, 8, 4, 4, 4)
+#ifndef AVA_FL_C2
+#define AVA_FL_C2 32, 4, 8, 4, 4, 4           // conv2
+#endif
+#ifndef AVA_FL_C4
+#define AVA_FL_C4 16, 4, 8, 4, 4, 4           // conv4
+#endif
+#ifndef AVA_FL_C5
+#define AVA_FL_C5 32, 4, 8, 4, 4, 4           // conv5
+#endif
+#define AVA_FL_ROW(X, ci, co, md, ...) X(ci, co, md, __VA_ARGS__)
+// the 8 <-> 8 stride-2 layers at full resolution lose in limb form (same box: conv2 105.6 -> 112 .. 124 us, convt6 with
+// convt7's data gradient gathered in its staging waves 90.2 -> 105 us: half-empty 16-row tiles either way, and the split costs
+// the staging waves more than the matrix time it saves): they stay on the fp32 kernel.  -DAVA_FL_WITH88 builds them.
+#ifdef AVA_FL_WITH88
+#define AVA_FL_88(X) X(8, 8, MODE_UP, 32, 4, 4, 4, 4, 3) AVA_FL_ROW(X, 8, 8, MODE_DOWN, AVA_FL_C2)
 #else
-#define AVA_FL_EXTRA(X)
+#define AVA_FL_88(X)
 #endif
-#define AVA_FUSED_LIMB_SHAPES(X)                    \
-  AVA_FL_ROW(X, 8, 16, MODE_S1, 32, AVA_FL_CFG)     \
-  AVA_FL_ROW(X, 16, 8, MODE_S1, 32, AVA_FL_CFG2)    \
-  X(16, 16, MODE_UP, 16, 4, 8, 4, 4, 4)             \
-  X(24, 16, MODE_S1, 32, 4, 8, 4, 4, 4)             \
-  X(16, 24, MODE_S1, 32, 4, 4, 4, 4, 3)             \
-  AVA_FL_EXTRA(X)
+#ifdef AVA_FL_EXP_ONLY                          // lab: only the rows under experiment (fast variant builds)
+#ifdef AVA_FL_NONE
+#define AVA_FUSED_LIMB_SHAPES(X)
+#else
+#define AVA_FUSED_LIMB_SHAPES(X)                \
+  X(8, 8, MODE_UP, 32, 4, 4, 4, 4, 3)           \
+  AVA_FL_ROW(X, 8, 8, MODE_DOWN, AVA_FL_C2)     \
+  AVA_FL_ROW(X, 16, 16, MODE_DOWN, AVA_FL_C4)
+#endif
+#else
+#define AVA_FUSED_LIMB_SHAPES(X)                \
+  AVA_FL_ROW(X, 8, 16, MODE_S1, AVA_FL_CFG)     \
+  AVA_FL_ROW(X, 16, 8, MODE_S1, AVA_FL_CFG2)    \
+  X(16, 16, MODE_UP, 16, 4, 8, 4, 4, 4)         \
+  X(24, 16, MODE_S1, 32, 4, 8, 4, 4, 4)         \
+  AVA_FL_ROW(X, 16, 24, MODE_S1, AVA_FL_C5)     \
+  AVA_FL_ROW(X, 16, 16, MODE_DOWN, AVA_FL_C4)   \
+  AVA_FL_88(X)
+#endif
 
 bool ava_conv_fused_limb_has(int Cin, int Cout, int mode) {
 #define X(ci, co, md, tww, thh, ns, nd, nwv, wps) if (Cin == ci && Cout == co && mode == md) return true;
@@ -570,7 +673,7 @@ int ava_conv_fused_limb_cap(int Cin, int Cout, int mode, int* tw, int* th) {
 
 // AVA_EINVAL when the shape has no limb instantiation (the caller then runs the fp32 kernel)
 int ava_conv3x3_bwd_fused_limb_launch(const FusedArgs& a, int grid, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
-  if (a.rcd.G1 != nullptr || a.rc.G1 != nullptr || a.dx == nullptr) return AVA_EINVAL;
+  if (a.rc.G1 != nullptr || a.dx == nullptr) return AVA_EINVAL;
 #define X(ci, co, md, tww, thh, ns, nd, nwv, wps) \
   if (Cin == ci && Cout == co && mode == md) return launch_fused_limb<ci, co, md, tww, thh, ns, nd, nwv, wps>(a, grid, dy_pro, st);
   AVA_FUSED_LIMB_SHAPES(X)

@@ -281,7 +281,10 @@ struct PairFrag {
 // K = (tap, channel octet): lane (m / n, kg) of v_mfma_f32_16x16x32_bf16 holds 8 consecutive k = the 8 channels of one
 // octet at one tap; a chunk of 4 k-groups is one MFMA per limb pair.  Weights: three bf16x8 limbs per (chunk, cout tile)
 // in registers; activations: one 16-byte LDS read per limb and chunk (TileStagerL planes).
-template <int CIN, int COUT, int MODE, int CLS, int IC, int NPIX, int MTO = 0>
+// W2L: the weights' THIRD limb (used by one of the six products) lives in an LDS table instead of 4 registers per chunk and
+// tile: one more ds_read_b128 per chunk buys NCH x MT x 4 VGPRs (the role-split fused backward, conv_fused_limb.hip).  A
+// lane reads back exactly the slot it wrote itself, so waves that build the same fragments may share one table.
+template <int CIN, int COUT, int MODE, int CLS, int IC, int NPIX, int MTO = 0, bool W2L = false>
 struct ClassFragL {
   static_assert(CIN % 8 == 0, "channel octets");
   static constexpr int Q8 = CIN / 8;
@@ -289,11 +292,14 @@ struct ClassFragL {
   static constexpr int NCH = (KG + 3) / 4;
   static constexpr int MT = MTO > 0 ? MTO : (COUT + 15) / 16;
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
+  static constexpr int W2_BYTES = NCH * MT * 1024;      // W2L: size of the third-limb table
   int off[NCH];                         // byte offset of this lane's 16-byte slot relative to the group's first pixel, plane 0
-  ava_bf16x8 w[NCH][3][MT];
+  ava_bf16x8 w[NCH][W2L ? 2 : 3][MT];
+  const unsigned char* w2p;             // W2L: this lane's slot of (chunk 0, tile 0); slot (c, mt) is (c * MT + mt) KB further
 
   // lane_pix: pixel offset of this lane's pixel inside a 16-pixel group (n * stride)
-  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_pix, int mtb = 0) {
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_pix, int mtb = 0, unsigned char* w2tab = nullptr) {
+    w2p = w2tab + lane * 16;
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -326,9 +332,14 @@ struct ClassFragL {
         asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));      // weights final before the tile loop (see ClassFrag::init)
         w[c][0][mt] = __builtin_bit_cast(ava_bf16x8, p0);
         w[c][1][mt] = __builtin_bit_cast(ava_bf16x8, p1);
-        w[c][2][mt] = __builtin_bit_cast(ava_bf16x8, p2);
+        if constexpr (W2L) *reinterpret_cast<ava_u32x4*>(w2tab + ((c * MT + mt) * 64 + lane) * 16) = p2;
+        else w[c][2][mt] = __builtin_bit_cast(ava_bf16x8, p2);
       }
     }
+  }
+  __device__ __forceinline__ ava_bf16x8 w2(int c, int mt) const {
+    if constexpr (W2L) return *reinterpret_cast<const ava_bf16x8*>(w2p + (c * MT + mt) * 1024);
+    else return w[c][2][mt];
   }
 
   // px: LDS byte address of the group's first pixel (channel octet 0, limb plane 0)
@@ -341,7 +352,7 @@ struct ClassFragL {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         f32x4 a = acc[c & 1][mt];                // smallest terms first
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][2][mt], b0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2(c, mt), b0, a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b2, a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b1, a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b0, a, 0, 0, 0);
@@ -354,7 +365,7 @@ struct ClassFragL {
 };
 
 // two output rows in one tile (stride 1, 8 output channels), limb form: K walks 4 input rows x 3 taps x channel octets
-template <int CIN, int IC, int NPIX>
+template <int CIN, int IC, int NPIX, bool W2L = false>
 struct PairFragL {
   static_assert(CIN % 8 == 0, "channel octets");
   static constexpr int Q8 = CIN / 8;
@@ -362,10 +373,13 @@ struct PairFragL {
   static constexpr int NCH = (KG + 3) / 4;
   static constexpr int MT = 1;
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
+  static constexpr int W2_BYTES = NCH * 1024;           // W2L: size of the third-limb table (see ClassFragL)
   int off[NCH];
-  ava_bf16x8 w[NCH][3][1];
+  ava_bf16x8 w[NCH][W2L ? 2 : 3][1];
+  const unsigned char* w2p;
 
-  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_pix, int /*mtb*/ = 0) {
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_pix, int /*mtb*/ = 0, unsigned char* w2tab = nullptr) {
+    w2p = w2tab + lane * 16;
     const int m = lane & 15, kg = lane >> 4;
     const int half = m >> 3, co = m & 7;
 #pragma unroll
@@ -391,8 +405,13 @@ struct PairFragL {
       asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
       w[c][0][0] = __builtin_bit_cast(ava_bf16x8, p0);
       w[c][1][0] = __builtin_bit_cast(ava_bf16x8, p1);
-      w[c][2][0] = __builtin_bit_cast(ava_bf16x8, p2);
+      if constexpr (W2L) *reinterpret_cast<ava_u32x4*>(w2tab + (c * 64 + lane) * 16) = p2;
+      else w[c][2][0] = __builtin_bit_cast(ava_bf16x8, p2);
     }
+  }
+  __device__ __forceinline__ ava_bf16x8 w2(int c) const {
+    if constexpr (W2L) return *reinterpret_cast<const ava_bf16x8*>(w2p + c * 1024);
+    else return w[c][2][0];
   }
 
   __device__ __forceinline__ void run(const unsigned char* __restrict__ px, f32x4 (&acc)[2][1]) const {
@@ -402,7 +421,7 @@ struct PairFragL {
       const ava_bf16x8 b1 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + PLANE_BYTES);
       const ava_bf16x8 b2 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + 2 * PLANE_BYTES);
       f32x4 a = acc[c & 1][0];
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][2][0], b0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2(c), b0, a, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b2, a, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b1, a, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b0, a, 0, 0, 0);

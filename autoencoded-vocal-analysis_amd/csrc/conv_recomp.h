@@ -271,6 +271,40 @@ struct DU1to8Stager {
       if (v) *reinterpret_cast<avaf4*>(lds + (row * C + col) * 8 + 4 * quad) = o;
     }
   }
+
+  // the same tile as three bf16 limb planes ([limb][9 * C pixels][8 channels]: TileStagerL's layout for 8 channels) for the
+  // limb form of the fused backward (conv_fused_limb.hip); same values, split exactly (x = x0 + x1 + x2)
+  __device__ __forceinline__ void store_limb(unsigned char* __restrict__ lds, const float* __restrict__ coef, float* __restrict__ xs_all) {
+    constexpr int PLANE_BYTES = 9 * C * 16;
+    core.stage(xs_all, [](float v) { return v; });               // PRO_ID on the seed
+    const float* ca = coef + 4 * ((core.lane >> 4) & 1);
+    const avaf4 kA = {ca[0], ca[1], ca[2], ca[3]}, kB = {ca[32], ca[33], ca[34], ca[35]}, kC = {ca[64], ca[65], ca[66], ca[67]};
+#pragma unroll
+    for (int u = 0; u < Core::NUW; ++u) {
+      int row, col, quad, pb, g;
+      const bool v = core.unit(u, row, col, quad, pb, g);
+      if (u >= Core::NG && core.wave + 4 * (u - Core::NG) >= Core::NG) continue;      // wave-uniform: no such group
+      const f32x4 acc = core.mma(xs_all, pb, g);
+      const bool in = (yin >> u) & 1u;
+      avaf4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = y2[u][r];
+        const float du = fmaf(kA[r], acc[r], fmaf(kB[r], y, kC[r]));
+        o[r] = (in && y > 0.f) ? du : 0.f;
+      }
+      ava_u32x2 p0, p1, p2;
+      uint32_t a, b, c;
+      ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
+      ava_limb_split2(o[2], o[3], a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
+      unsigned char* d = lds + (row * C + col) * 16 + quad * 8;
+      if (v) {
+        *reinterpret_cast<ava_u32x2*>(d) = p0;
+        *reinterpret_cast<ava_u32x2*>(d + PLANE_BYTES) = p1;
+        *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
+      }
+    }
+  }
 };
 
 // y1 = relu(conv1(bn1 x)) windows on the matrix cores (Conv1to8Core): the form of Y1Stager that costs a third of the vector

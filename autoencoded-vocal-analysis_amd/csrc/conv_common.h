@@ -344,6 +344,16 @@ struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2, MAXQP> {
 #pragma unroll
     for (int i = 0; i < Base::NPF; ++i) store_one(i, lds, coef, kq);
   }
+  // store() with the elements kept apart in the schedule: interleaving the conversions of all NPF elements costs a role-split
+  // kernel's staging waves registers they do not have (conv_fused_limb.hip)
+  __device__ __forceinline__ void store_tight(unsigned char* __restrict__ lds, const float* __restrict__ coef) {
+    const Coefs kq = this->coefs_of(coef);
+#pragma unroll
+    for (int i = 0; i < Base::NPF; ++i) {
+      store_one(i, lds, coef, kq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   // see TileStager::store_load
   __device__ __forceinline__ void store_load(unsigned char* __restrict__ lds, const float* __restrict__ coef,
                                              const float* __restrict__ in, const float* __restrict__ in2, int b, int Hi,

@@ -64,6 +64,11 @@ struct FGeomL {
 
 template <int N> using ava_ic = std::integral_constant<int, N>;
 
+// lab: compile a wave role out (register-pressure / ablation experiments; results are wrong): 1 staging, 2 data gradient, 4 weight gradient
+#ifndef AVA_FL_CUT
+#define AVA_FL_CUT 0
+#endif
+
 // number of M tiles (units) of the weight gradient over all tap classes
 template <int LMODE> __host__ __device__ constexpr int wl_units(int cin) { return wsplit_base<LMODE>(n_classes<LMODE>(), cin); }
 
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   constexpr bool PAIR = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
   // two dx channel tiles: the data-gradient waves are dealt one tile each (half the limb weights), odd and even waves
   // sharing the pixel groups
-  constexpr bool DSPLIT = MT == 2 && ND % 2 == 0;
+  // (not where the four waves each own a parity class of a stride-2 gather -- CSPLIT below: those hold both tiles)
+  constexpr bool DSPLIT = MT == 2 && ND % 2 == 0 && !(BMODE == MODE_UP && ND == 4);
   constexpr int NDG = DSPLIT ? ND / 2 : ND;     // waves that share the pixel groups of a tile
   constexpr int MTD = DSPLIT ? 1 : MT;
   constexpr int XNPIX = XR * XC, DNPIX = DR * DC;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   TileStagerL<CI, PRO_BN, XR, XC, NST, ACT, ACT, 1> sx;       // staging waves only (threadIdx.x 0 .. NST-1)
   typename std::conditional<DUREC, DU1to8Stager<DC, ACT>, TileStagerL<CO, DYPRO, DR, DC, NST, float, ACT, 1>>::type sd;
   auto sd_store = [&](unsigned char* dst) __attribute__((always_inline)) {
-    if constexpr (DUREC) sd.store_limb(dst, cd, xs); else sd.store(dst, cd);
+    if constexpr (DUREC) sd.store_limb(dst, cd, xs); else sd.store_tight(dst, cd);
   };
   auto prefetch = [&](int tl) {
     int b, y0, x0, gy, gx;
@@ -185,11 +191,12 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   __syncthreads();                           // cx / cd visible
   if (!stager) asm volatile("" ::"v"(wpf));
 
+  if (stager && (AVA_FL_CUT & 1)) return;
   if (stager) {
     // ---------------- staging waves ----------------
     __builtin_amdgcn_s_setprio(3);           // issue priority over the matrix-core waves of the same SIMD (conv_fused.hip)
     if (walk.valid()) {
-      sx.store(smem_b, cx);
+      sx.store_tight(smem_b, cx);
       sd_store(smem_b + XBYTES);
       if (walk.has_next()) prefetch(walk.next());
     }
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     for (; walk.valid(); walk.advance(), ++it) {
       if (walk.has_next()) {                                    // tile it+1 -> the other buffer, tile it+2 in flight
         unsigned char* nb = smem_b + ((it + 1) & 1) * BUF;
-        sx.store(nb, cx);
+        sx.store_tight(nb, cx);
         sd_store(nb + XBYTES);
         const int nn = walk.next() + walk.step;
         if (nn < walk.end) prefetch(nn);
@@ -209,12 +216,13 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     return;
   }
 
+  if (wave8 < NS + ND && (AVA_FL_CUT & 2)) return;
   if (wave8 < NS + ND) {
     // ---------------- data-gradient waves ----------------
     // Stride-2 conv layers (dx gathered in four output-parity classes): with four data-gradient waves each wave takes ONE
     // class for all of the tile's pixel groups and holds only that class's limb weights (1-2 chunks instead of 5: with all
     // four classes in every wave the role needed > 128 VGPRs, and spill reloads inside a latency-bound loop cost 4x the tile).
-    constexpr bool CSPLIT = BMODE == MODE_UP && ND == 4 && !DSPLIT;
+    constexpr bool CSPLIT = BMODE == MODE_UP && ND == 4;
     const int dw = wave8 - NS;
     auto d_role = [&](auto dcls_c) __attribute__((always_inline)) {
       constexpr int DCLS = decltype(dcls_c)::value;               // CSPLIT: this wave's class; otherwise 0
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   }
 
   // ---------------- weight-gradient waves ----------------
+  if (AVA_FL_CUT & 4) return;
   // Units: the M tiles (16 rows of (tap, ci)) of every tap class, numbered class by class, plus the bias row as unit NU.
   // Unit u belongs to wave u % NWV, slot u / NWV.  K = 32 pixels per step: KW consecutive pixels of 32 / KW rows.
   constexpr int NU = wl_units<LMODE>(CI);
@@ -625,7 +634,29 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #ifndef AVA_FL_C5
 #define AVA_FL_C5 32, 4, 8, 4, 4, 4           // conv5
 #endif
+// The four layers at 16 x 16 (conv6, conv7, convt1, convt2) instantiate and pass the kernel tests, but do not win yet: with
+// 24 / 32 channels on both sides the three roles together spill 100-350 registers although each fits alone (-DAVA_FL_CUT),
+// and a spill reload inside these latency-bound loops is a dependent memory round trip.  Same box, fused limb kernel against
+// data-gradient launch + half a pair launch: conv7 34.4 vs 33.9 us, convt1 30.9 vs 33.6, conv6 74.3 vs 45.5, convt2 51.5 vs
+// 45.4 (768 threads; 1024 threads: 33.7 / 41.5 / 84.4 / 65.3).  -DAVA_FL_WITH16 builds them.
+#ifndef AVA_FL_C7
+#define AVA_FL_C7 16, 8, 4, 4, 4, 3
+#endif
+#ifndef AVA_FL_T1
+#define AVA_FL_T1 16, 8, 4, 4, 4, 3
+#endif
+#ifndef AVA_FL_C6
+#define AVA_FL_C6 16, 4, 4, 4, 4, 3
+#endif
+#ifndef AVA_FL_T2
+#define AVA_FL_T2 16, 4, 4, 4, 4, 3
+#endif
 #define AVA_FL_ROW(X, ci, co, md, ...) X(ci, co, md, __VA_ARGS__)
+#ifdef AVA_FL_WITH16
+#define AVA_FL_16(X) AVA_FL_ROW(X, 24, 32, MODE_S1, AVA_FL_C7) AVA_FL_ROW(X, 32, 24, MODE_S1, AVA_FL_T1) AVA_FL_ROW(X, 24, 24, MODE_DOWN, AVA_FL_C6) AVA_FL_ROW(X, 24, 24, MODE_UP, AVA_FL_T2)
+#else
+#define AVA_FL_16(X)
+#endif
 // the 8 <-> 8 stride-2 layers at full resolution lose in limb form (same box: conv2 105.6 -> 112 .. 124 us, convt6 with
 // convt7's data gradient gathered in its staging waves 90.2 -> 105 us: half-empty 16-row tiles either way, and the split costs
 // the staging waves more than the matrix time it saves): they stay on the fp32 kernel.  -DAVA_FL_WITH88 builds them.
@@ -634,7 +665,13 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #else
 #define AVA_FL_88(X)
 #endif
-#ifdef AVA_FL_EXP_ONLY                          // lab: only the rows under experiment (fast variant builds)
+#ifdef AVA_FL_ONLY16                            // lab: only the four 16 x 16 layers
+#define AVA_FUSED_LIMB_SHAPES(X)                \
+  AVA_FL_ROW(X, 24, 32, MODE_S1, AVA_FL_C7)     \
+  AVA_FL_ROW(X, 32, 24, MODE_S1, AVA_FL_T1)     \
+  AVA_FL_ROW(X, 24, 24, MODE_DOWN, AVA_FL_C6)   \
+  AVA_FL_ROW(X, 24, 24, MODE_UP, AVA_FL_T2)
+#elif defined(AVA_FL_EXP_ONLY)                  // lab: only the rows under experiment (fast variant builds)
 #ifdef AVA_FL_NONE
 #define AVA_FUSED_LIMB_SHAPES(X)
 #else
@@ -651,6 +688,7 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
   X(24, 16, MODE_S1, 32, 4, 8, 4, 4, 4)         \
   AVA_FL_ROW(X, 16, 24, MODE_S1, AVA_FL_C5)     \
   AVA_FL_ROW(X, 16, 16, MODE_DOWN, AVA_FL_C4)   \
+  AVA_FL_16(X)                                  \
   AVA_FL_88(X)
 #endif
 

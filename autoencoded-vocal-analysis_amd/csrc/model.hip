@@ -44,6 +44,31 @@ int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_EXP = 2 };
 
+// fc_mid.hip: fc31|32|33 -> heads -> rsample -> fc5 -> fc6 (and the mirror data-gradient chain) as one launch each
+struct FcMidFwdArgs {
+  const float* h3_in;
+  const float *W3, *b3;
+  const float *W41, *b41, *W42, *b42, *W43, *b43;
+  const float *W5, *b5, *W6, *b6;
+  const float *eps_w, *eps_d;
+  float *h3, *mu, *u, *logd, *d, *z, *lat_sums, *h5, *h6;
+  int* status;
+  int B, zdim;
+  unsigned long long* stamps;
+};
+struct FcMidBwdArgs {
+  const float* dh6;
+  const float *W6, *W5, *W41, *W42, *W43, *W3;
+  const float *h5, *h3, *h2;
+  const float *z, *u, *d, *eps_w, *eps_d;
+  const float* scale;
+  float *dh5, *dz, *dmu, *du, *dlogd, *dh3, *dh2;
+  int B, zdim;
+  unsigned long long* stamps;
+};
+int ava_fc_mid_fwd(const FcMidFwdArgs& a, hipStream_t st);
+int ava_fc_mid_bwd(const FcMidBwdArgs& a, hipStream_t st);
+
 #define NCONV 14
 #define NPARAM 80
 #define ALIGN_F 64
@@ -807,8 +832,15 @@ extern "C" int ava_debug_materialize(ava_model* m, const float* x, int B, ava_st
   return materialize_y1(m, x, B, to_stream(s));
 }
 
+// the small fully connected middle as one launch per direction (fc_mid.hip); lab: AVA_FC_MID=0 keeps the separate launches
+static bool fc_mid_on() {
+  static const bool on = [] { const char* e = ava_env("AVA_FC_MID"); return e == nullptr || atoi(e) != 0; }();
+  return on;
+}
+
+// stop_at_fc2 (historic name): stop behind fc31|32|33, the caller continues with the fused middle (forward_impl)
 static int encoder_forward(ava_model* m, const float* x, int B, int train, float* mu, float* u, float* logd_or_d,
-                           int last_act, hipStream_t st, int pre_nparts = 0) {
+                           int last_act, hipStream_t st, int pre_nparts = 0, bool stop_at_fc2 = false) {
   const int z = m->z;
   int nparts = pre_nparts;                 // > 0: pack_stats_kernel already wrote the input statistics' partial rows
   if (train) {
@@ -849,6 +881,7 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
   TRY(gemm(m, m->h1, 0, PP(m, FC2), 0, PP(m, FC2 + 1), m->h2, 0, nullptr, nullptr, B, 256, 1024, 1, 1, ACT_RELU, st));
   // fc31|fc32|fc33 as one [192,256] layer (arena keeps the three weights, then the three biases, contiguous)
   TRY(gemm(m, m->h2, 0, PP(m, FC31), 0, PP(m, FC31 + 1), m->h3, 0, nullptr, nullptr, B, 192, 256, 1, 1, ACT_RELU, st));
+  if (stop_at_fc2) return AVA_OK;               // the caller continues with the fused middle (heads .. fc6)
   // the three 64 -> z heads (mu, u, log d) on the 64-wide slices of h3: one grouped launch
   const AvaGemmProblem heads[3] = {
       {m->h3 + 0, 192, PP(m, FC41), 0, PP(m, FC41 + 1), mu, 0, nullptr, nullptr, B, z, 64, ACT_NONE},
@@ -858,11 +891,14 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
   return AVA_OK;
 }
 
+// from_fc7: h6 already exists (the fused middle wrote it)
 static int decoder_forward(ava_model* m, const float* zin, const float* x_target, int B, int train, float* xrec,
-                           hipStream_t st) {
+                           hipStream_t st, bool from_fc7 = false) {
   const int z = m->z;
-  TRY(gemm(m, zin, 0, PP(m, FC5), 0, PP(m, FC5 + 1), m->h5, 0, nullptr, nullptr, B, 64, z, 1, 1, ACT_RELU, st));
-  TRY(gemm(m, m->h5, 0, PP(m, FC6), 0, PP(m, FC6 + 1), m->h6, 0, nullptr, nullptr, B, 256, 64, 1, 1, ACT_RELU, st));
+  if (!from_fc7) {
+    TRY(gemm(m, zin, 0, PP(m, FC5), 0, PP(m, FC5 + 1), m->h5, 0, nullptr, nullptr, B, 64, z, 1, 1, ACT_RELU, st));
+    TRY(gemm(m, m->h5, 0, PP(m, FC6), 0, PP(m, FC6 + 1), m->h6, 0, nullptr, nullptr, B, 256, 64, 1, 1, ACT_RELU, st));
+  }
   TRY(gemm(m, m->h6, 0, PP(m, FC7), 0, PP(m, FC7 + 1), m->h7, 0, nullptr, nullptr, B, 1024, 256, 1, 1, ACT_RELU, st));
   // fc8: when the product runs as two split-K slabs, the layout kernel behind it sums them (+ bias, ReLU) on the way in and
   // writes f8 as well -- one launch and one pass over the tensor fewer
@@ -907,13 +943,27 @@ static int forward_impl(ava_model* m, const float* x, int B, const float* eps_w,
   const int z = m->z;
   int pre = 0;
   TRY(pack_weights(m, true, st, bn_train ? x : nullptr, (int64_t)B * m->H * m->W, &pre, ng));
-  TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st, pre));
+  const bool mid = fc_mid_on();
+  TRY(encoder_forward(m, x, B, bn_train, m->mu, m->u, m->logd, ACT_NONE, st, pre, mid));
   mark(m, CAT_LAYOUT, st);
-  TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
+  if (mid) {
+    // the three heads, rsample + entropy, fc5 and fc6: one launch (16 batch rows per workgroup, fc_mid.hip)
+    FcMidFwdArgs fa;
+    fa.h3_in = nullptr; fa.W3 = nullptr; fa.b3 = nullptr;
+    fa.W41 = PP(m, FC41); fa.b41 = PP(m, FC41 + 1); fa.W42 = PP(m, FC42); fa.b42 = PP(m, FC42 + 1);
+    fa.W43 = PP(m, FC43); fa.b43 = PP(m, FC43 + 1);
+    fa.W5 = PP(m, FC5); fa.b5 = PP(m, FC5 + 1); fa.W6 = PP(m, FC6); fa.b6 = PP(m, FC6 + 1);
+    fa.eps_w = eps_w; fa.eps_d = eps_d;
+    fa.h3 = m->h3; fa.mu = m->mu; fa.u = m->u; fa.logd = m->logd; fa.d = m->d; fa.z = m->zs; fa.lat_sums = m->lat_sums;
+    fa.h5 = m->h5; fa.h6 = m->h6; fa.status = status_out; fa.B = B; fa.zdim = z;
+    TRY(ava_fc_mid_fwd(fa, st));
+  } else {
+    TRY(ava_latent_fwd(m->mu, m->u, m->logd, eps_w, eps_d, m->d, m->zs, m->lat_sums, status_out, B, z, st));
+  }
   m->eps_w_last = eps_w;          // backward reads the same noise: the caller keeps it alive until then
   m->eps_d_last = eps_d;
   mark(m, CAT_LATENT_LOSS, st);
-  TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st));
+  TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st, mid));
   TRY(ava_elbo_finalize_strided(m->lat_sums, B, m->bn_part, m->sse_parts, 2, z, m->prec, m->H * m->W,
                                 loss_out != nullptr ? loss_out : m->loss_dev, loss_accum, st));
   mark(m, CAT_LATENT_LOSS, st);
@@ -1158,6 +1208,18 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
   // issued in place and the eight small ones are collected into ONE grouped launch at the end. ----
   TRY(gemm(m, m->dF8, 0, PP(m, FC8), 0, nullptr, m->dh7, 0, m->h7, nullptr, B, 1024, m->F, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh7, 0, PP(m, FC7), 0, nullptr, m->dh6, 0, m->h6, nullptr, B, 256, 1024, 1, 0, ACT_NONE, st));
+  if (fc_mid_on()) {
+    // dh6 -> dh5 -> dz -> latent backward -> dh3 in one launch (fc_mid.hip); fc31|32|33's data gradient stays a launch
+    FcMidBwdArgs ba;
+    ba.dh6 = m->dh6; ba.W6 = PP(m, FC6); ba.W5 = PP(m, FC5); ba.W41 = PP(m, FC41); ba.W42 = PP(m, FC42); ba.W43 = PP(m, FC43);
+    ba.W3 = PP(m, FC31); ba.h5 = m->h5; ba.h3 = m->h3; ba.h2 = m->h2;
+    ba.z = m->zs; ba.u = m->u; ba.d = m->d; ba.eps_w = m->eps_w_last; ba.eps_d = m->eps_d_last; ba.scale = m->bwd_scale;
+    ba.dh5 = m->dh5; ba.dz = m->dz; ba.dmu = m->dmu; ba.du = m->du; ba.dlogd = m->dlogd; ba.dh3 = m->dh3; ba.dh2 = m->dh2;
+    ba.B = B; ba.zdim = z;
+    TRY(ava_fc_mid_bwd(ba, st));
+    mark(m, CAT_LATENT_LOSS, st);
+    TRY(gemm(m, m->dh3, 0, PP(m, FC31), 0, nullptr, m->dh2, 0, m->h2, nullptr, B, 256, 192, 1, 0, ACT_NONE, st));
+  } else {
   TRY(gemm(m, m->dh6, 0, PP(m, FC6), 0, nullptr, m->dh5, 0, m->h5, nullptr, B, 64, 256, 1, 0, ACT_NONE, st));
   TRY(gemm(m, m->dh5, 0, PP(m, FC5), 0, nullptr, m->dz, 0, nullptr, nullptr, B, z, 64, 1, 0, ACT_NONE, st));
   // ---- latent block ----
@@ -1171,6 +1233,7 @@ static int backward_part1(ava_model* m, const float* x, int B, hipStream_t st) {
       {m->dlogd, 0, PP(m, FC43), 0, nullptr, m->dh3 + 128, 192, m->h3 + 128, nullptr, B, 64, z, ACT_NONE}};
   TRY(gemm_group(m, hdx, 3, 1, 0, st));
   TRY(gemm(m, m->dh3, 0, PP(m, FC31), 0, nullptr, m->dh2, 0, m->h2, nullptr, B, 256, 192, 1, 0, ACT_NONE, st));
+  }
   TRY(gemm(m, m->dh2, 0, PP(m, FC2), 0, nullptr, m->dh1, 0, m->h1, nullptr, B, 1024, 256, 1, 0, ACT_NONE, st));
   // fc1's weight gradient (its bias gradient -- the column sums -- is written by the same launch but belongs to bucket 2:
   // nothing reads it before part 2 is complete)

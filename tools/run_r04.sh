@@ -23,6 +23,14 @@ case $pass in
     python3 tools/kstats.py $out/step_kernel_stats.csv 25 | head -40
     head -c 300 $out/bench.json
     ;;
+  step)
+    timeout 2000 python -m pytest tests/test_gpu_step.py tests/test_gpu_autograd_semantics.py tests/test_gpu_callers.py tests/test_gpu_graph.py -x -q > $out/pytest_step.log 2>&1; echo "pytest rc $?" >> $out/pytest_step.log
+    tail -n 8 $out/pytest_step.log
+    prof step
+    timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-loader-path --global-batch 0 > $out/bench.json 2> $out/bench.err
+    python3 tools/kstats.py $out/step_kernel_stats.csv 65 | grep -E "fc_mid|skinny|latent|total"
+    head -c 300 $out/bench.json
+    ;;
   full)
     timeout 2400 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc $?" >> $out/pytest.log
     tail -n 15 $out/pytest.log

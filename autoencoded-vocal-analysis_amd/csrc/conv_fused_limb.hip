@@ -615,9 +615,8 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 //   conv5  16 -> 24 S1  65.7 -> 43.8 us   768 threads: the data-gradient waves hold 84 VGPRs of limb weights
 //   convt3 24 -> 16 S1  63.8 -> 46.2 us   the two dx channel tiles dealt to odd / even data-gradient waves
 //   convt4 16 -> 16 UP  43.8 -> 41.3 us
-// Not (yet) here: conv4 16 -> 16 DOWN (50.7 -> 63.8 us) and conv2 8 -> 8 DOWN (106.6 -> 122.4 us) on 16 x 4 tiles -- one
-// workgroup per CU keeps ONE small tile in flight where the fp32 kernel's two workgroups keep two -- and convt6, whose dU
-// window is gathered from the 1-channel seed by the staging waves (conv_recomp.h).
+//   conv4  16 -> 16 DOWN 49.4 -> 45.5 us  (16 x 4 tiles; each data-gradient wave owns one output-parity class)
+//   conv2 / convt6: below
 // (lab experiments: -DAVA_FL_CFG="th, ns, nd, nwv, wps" overrides conv3's row: tools/lab/build_variant.sh)
 #ifndef AVA_FL_CFG
 #define AVA_FL_CFG 32, 4, 8, 4, 4, 4          // conv3
@@ -625,8 +624,11 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #ifndef AVA_FL_CFG2
 #define AVA_FL_CFG2 32, 8, 8, 4, 4, 4         // convt5
 #endif
+#ifndef AVA_FL_T6
+#define AVA_FL_T6 16, 4, 4, 2, 2, 4           // convt6
+#endif
 #ifndef AVA_FL_C2
-#define AVA_FL_C2 32, 4, 8, 4, 4, 4           // conv2
+#define AVA_FL_C2 16, 4, 4, 2, 2, 4           // conv2
 #endif
 #ifndef AVA_FL_C4
 #define AVA_FL_C4 16, 4, 8, 4, 4, 4           // conv4
@@ -657,14 +659,11 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #else
 #define AVA_FL_16(X)
 #endif
-// the 8 <-> 8 stride-2 layers at full resolution lose in limb form (same box: conv2 105.6 -> 112 .. 124 us, convt6 with
-// convt7's data gradient gathered in its staging waves 90.2 -> 105 us: half-empty 16-row tiles either way, and the split costs
-// the staging waves more than the matrix time it saves): they stay on the fp32 kernel.  -DAVA_FL_WITH88 builds them.
-#ifdef AVA_FL_WITH88
-#define AVA_FL_88(X) X(8, 8, MODE_UP, 32, 4, 4, 4, 4, 3) AVA_FL_ROW(X, 8, 8, MODE_DOWN, AVA_FL_C2)
-#else
-#define AVA_FL_88(X)
-#endif
+// The 8 <-> 8 stride-2 layers at full resolution (conv2, and convt6 with convt7's data gradient gathered in its staging
+// waves) run 512-thread workgroups, two per CU like the fp32 kernel they replace (4 staging + 2 + 2 matrix-core waves: every
+// role fits 128 VGPRs there): same box conv2 106.0 -> 99.5 us, convt6 90.1 -> 87.1 us.  As ONE workgroup per CU they lost
+// (1024 threads: 112 .. 124 / 105 us; 768 threads: 99 / 124 us): a CU then has one small tile in flight instead of two.
+#define AVA_FL_88(X) AVA_FL_ROW(X, 8, 8, MODE_UP, AVA_FL_T6) AVA_FL_ROW(X, 8, 8, MODE_DOWN, AVA_FL_C2)
 #ifdef AVA_FL_ONLY16                            // lab: only the four 16 x 16 layers
 #define AVA_FUSED_LIMB_SHAPES(X)                \
   AVA_FL_ROW(X, 24, 32, MODE_S1, AVA_FL_C7)     \
@@ -676,9 +675,8 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #define AVA_FUSED_LIMB_SHAPES(X)
 #else
 #define AVA_FUSED_LIMB_SHAPES(X)                \
-  X(8, 8, MODE_UP, 32, 4, 4, 4, 4, 3)           \
-  AVA_FL_ROW(X, 8, 8, MODE_DOWN, AVA_FL_C2)     \
-  AVA_FL_ROW(X, 16, 16, MODE_DOWN, AVA_FL_C4)
+  AVA_FL_ROW(X, 8, 8, MODE_UP, AVA_FL_T6)       \
+  AVA_FL_ROW(X, 8, 8, MODE_DOWN, AVA_FL_C2)
 #endif
 #else
 #define AVA_FUSED_LIMB_SHAPES(X)                \

@@ -232,7 +232,10 @@ def _bucket_adam_worker(rank, world, port, q, backend="gloo"):
             res[mode] = (model._grads.clone(), model._params.clone(), model._exp_avg.clone(), model._exp_avg_sq.clone())
         same = [bool(torch.equal(a, b)) for a, b in zip(res["deferred"], res["flat"])]
         bk = model._buckets()
-        q.put((rank, same, float(res["deferred"][1].double().sum().item()), bk, int(model._params.numel())))
+        # (diagnostics for a failure: largest difference per array and gradient bucket)
+        diffs = [[float((a[o:o + c].double() - b[o:o + c].double()).abs().max()) for o, c in bk]
+                 for a, b in zip(res["deferred"], res["flat"])]
+        q.put((rank, same, float(res["deferred"][1].double().sum().item()), bk, int(model._params.numel()), diffs))
     finally:
         td.destroy_process_group()
 
@@ -257,8 +260,8 @@ def test_per_bucket_adam_behind_its_own_allreduce_equals_flat_adam():
     as ITS all-reduce has completed.  Bit-identical gradients, parameters and moments to "wait for everything, one flat
     launch", on both ranks, over two steps; the buckets tile the arena."""
     res = _run_two(_bucket_adam_worker, 35500)
-    for rank, same, psum, bk, total in res:
-        assert all(same), same
+    for rank, same, psum, bk, total, diffs in res:
+        assert all(same), (same, diffs)
         assert len(bk) == 4 and sorted(o for o, _ in bk)[0] == 0 and sum(c for _, c in bk) == total
         ends = sorted((o, o + c) for o, c in bk)
         assert all(ends[i][1] == ends[i + 1][0] for i in range(3))

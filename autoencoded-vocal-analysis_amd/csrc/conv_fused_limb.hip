@@ -636,25 +636,27 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #ifndef AVA_FL_C5
 #define AVA_FL_C5 32, 4, 8, 4, 4, 4           // conv5
 #endif
-// The four layers at 16 x 16 (conv6, conv7, convt1, convt2) instantiate and pass the kernel tests, but do not win yet: with
-// 24 / 32 channels on both sides the three roles together spill 100-350 registers although each fits alone (-DAVA_FL_CUT),
-// and a spill reload inside these latency-bound loops is a dependent memory round trip.  Same box, fused limb kernel against
-// data-gradient launch + half a pair launch: conv7 34.4 vs 33.9 us, convt1 30.9 vs 33.6, conv6 74.3 vs 45.5, convt2 51.5 vs
-// 45.4 (768 threads; 1024 threads: 33.7 / 41.5 / 84.4 / 65.3).  -DAVA_FL_WITH16 builds them.
+// The four layers at 16 x 16 (conv6, conv7, convt1, convt2; until round 4 a data-gradient launch plus half a weight-gradient
+// pair launch each).  With 24 / 32 channels on both sides the three roles together spilled 100-350 registers at 128 or 168
+// VGPRs although each role fits alone (-DAVA_FL_CUT), and a spill reload inside these latency-bound loops is a dependent
+// memory round trip: fused, they LOST (same box, fused against data-gradient launch + half a pair launch: conv7 34.4 vs 33.9 us,
+// convt1 30.9 vs 33.6, conv6 74.3 vs 45.5, convt2 51.5 vs 45.4 at 768 threads; 33.7 / 41.5 / 84.4 / 65.3 at 1024).  ONE
+// 512-thread workgroup per CU (4 staging + 2 + 2 matrix-core waves, 256 VGPRs, no spill) wins: conv6 34.6, convt2 28.8,
+// conv7 24.6, convt1 23.8 us -- 111.8 us for the four against 158.4, and six launches fewer.
 #ifndef AVA_FL_C7
-#define AVA_FL_C7 16, 8, 4, 4, 4, 3
+#define AVA_FL_C7 16, 8, 4, 2, 2, 2
 #endif
 #ifndef AVA_FL_T1
-#define AVA_FL_T1 16, 8, 4, 4, 4, 3
+#define AVA_FL_T1 16, 8, 4, 2, 2, 2
 #endif
 #ifndef AVA_FL_C6
-#define AVA_FL_C6 16, 4, 4, 4, 4, 3
+#define AVA_FL_C6 16, 4, 4, 2, 2, 2
 #endif
 #ifndef AVA_FL_T2
-#define AVA_FL_T2 16, 4, 4, 4, 4, 3
+#define AVA_FL_T2 16, 4, 4, 2, 2, 2
 #endif
 #define AVA_FL_ROW(X, ci, co, md, ...) X(ci, co, md, __VA_ARGS__)
-#ifdef AVA_FL_WITH16
+#ifndef AVA_FL_NO16
 #define AVA_FL_16(X) AVA_FL_ROW(X, 24, 32, MODE_S1, AVA_FL_C7) AVA_FL_ROW(X, 32, 24, MODE_S1, AVA_FL_T1) AVA_FL_ROW(X, 24, 24, MODE_DOWN, AVA_FL_C6) AVA_FL_ROW(X, 24, 24, MODE_UP, AVA_FL_T2)
 #else
 #define AVA_FL_16(X)

@@ -79,7 +79,10 @@ template <int LMODE> __host__ __device__ constexpr int wl_units(int cin) { retur
 // DUREC (convt6's backward): the upstream gradient dy (8 channels, full resolution) does not exist in memory -- it is convt7's
 // data gradient, a 3x3 gather of the 1-channel seed a.dy, formed on the matrix cores by the (four) staging waves as they build
 // the dU tile (conv_recomp.h: DU1to8Stager; its limb-plane store below).
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false>
+// DEEP: the staging waves hold TWO tiles in registers (tile it+2 and it+3 in flight while tile it+1 is converted): per tile the
+// matrix-core waves have ~1 us of work, a tile's loads take 2-3 us under load, so one tile in flight leaves both roles waiting
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false,
+          bool DEEP = false>
 __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_limb_kernel(const FusedArgs a) {
   using FG = FGeomL<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
@@ -156,8 +159,22 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     d_origin(y0, x0, gy, gx);
     sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
   };
+  static_assert(!DEEP || !DUREC, "the seed gather keeps one private window per staging wave");
+  decltype(sx) sx2;                                            // DEEP: the second register set (odd tiles)
+  typename std::conditional<DUREC, int, decltype(sd)>::type sd2;
+  auto prefetch2 = [&](int tl) {
+    if constexpr (DEEP) {
+      int b, y0, x0, gy, gx;
+      origin(tl, b, y0, x0);
+      x_origin(y0, x0, gy, gx);
+      sx2.load(a.x, nullptr, b, a.Hi, a.Wi, gy, gx);
+      d_origin(y0, x0, gy, gx);
+      sd2.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
+    }
+  };
   if (stager) {
     sx.init();
+    if constexpr (DEEP) { sx2.init(); sd2.init(); }
     if constexpr (DUREC) sd.init(a.rcd, xs); else sd.init();
     if (walk.valid()) prefetch(walk.cur);    // tile 0 goes in flight BEFORE the coefficient prologue
   }
@@ -195,6 +212,34 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   if (stager) {
     // ---------------- staging waves ----------------
     __builtin_amdgcn_s_setprio(3);           // issue priority over the matrix-core waves of the same SIMD (conv_fused.hip)
+    if constexpr (DEEP) {
+      // tile k lives in register set k & 1 and goes to LDS buffer k & 1
+      auto tile_k = [&](int k) { return walk.cur + k * walk.step; };
+      if (walk.valid()) {
+        if (tile_k(1) < walk.end) prefetch2(tile_k(1));
+        sx.store_tight(smem_b, cx);
+        sd.store_tight(smem_b + XBYTES, cd);
+        if (tile_k(2) < walk.end) prefetch(tile_k(2));
+      }
+      __syncthreads();                                          // (A) tile 0 ready
+      int it = 0;
+      for (; walk.valid(); walk.advance(), ++it) {              // (tile_k is relative to the advancing walk.cur)
+        if (walk.has_next()) {
+          if ((it & 1) == 0) {
+            sx2.store_tight(smem_b + BUF, cx);
+            sd2.store_tight(smem_b + BUF + XBYTES, cd);
+            if (tile_k(3) < walk.end) prefetch2(tile_k(3));
+          } else {
+            sx.store_tight(smem_b, cx);
+            sd.store_tight(smem_b + XBYTES, cd);
+            if (tile_k(3) < walk.end) prefetch(tile_k(3));
+          }
+        }
+        __syncthreads();                                        // (B)
+      }
+      __syncthreads();                                          // (E)
+      return;
+    }
     if (walk.valid()) {
       sx.store_tight(smem_b, cx);
       sd_store(smem_b + XBYTES);
@@ -559,7 +604,8 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false>
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false,
+          bool DEEP = false>
 static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   using FG = FGeomL<LMODE, TW, TH>;
   constexpr int MT = (CI + 15) / 16;
@@ -569,7 +615,7 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   constexpr size_t lds = 2 * buf + (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL;
   constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
   static_assert(WG_PER_CU >= 1 && (lds + 1024) * WG_PER_CU <= 160 * 1024, "the resident workgroups' tile buffers must fit 160 KB of LDS");
-  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC>);
+  const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVA_ELAUNCH;
@@ -582,13 +628,19 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   b.tiles_x = wl / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;
   if (grid < 1 || grid > b.ntiles) return AVA_EINVAL;
-  hipLaunchKernelGGL((conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC>), dim3(grid), dim3(64 * (NS + ND + NWV)), lds, st, b);
+  hipLaunchKernelGGL((conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>), dim3(grid), dim3(64 * (NS + ND + NWV)), lds, st, b);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
 
+#ifndef AVA_FL_DEEP_MIN_NS
+#define AVA_FL_DEEP_MIN_NS 99         // measured: two tiles in flight LOSE everywhere (same box, one -> two: conv3 61.1 -> 64.3 us,
+                                      // convt4 41.7 -> 45.3 without a spill; convt5 61.5 -> 91, conv5 40.5 -> 62 with the spills the
+                                      // second register set causes); lab: -DAVA_FL_DEEP_MIN_NS=8 builds it for the 8-stager shapes
+#endif
 template <int CI, int CO, int LMODE, int TW, int TH, int NS, int ND, int NWV, int WPS>
 static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream_t st) {
+  constexpr bool DEEP = NS >= AVA_FL_DEEP_MIN_NS;
   if constexpr (CI == 8 && CO == 8 && LMODE == MODE_UP && TH == 4 && NS == 4) {
     if (a.rcd.G1 != nullptr) {            // convt6's backward with convt7's data gradient formed in the staging waves
       if (dy_pro != PRO_BWD) return AVA_EINVAL;
@@ -598,19 +650,19 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
   }
   if (a.rcd.G1 != nullptr) return AVA_EINVAL;
   if (dy_pro == PRO_BWD) {
-    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, ava_bf16>(a, grid, st);
-    return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, float>(a, grid, st);
+    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, ava_bf16, false, DEEP>(a, grid, st);
+    return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, float, false, DEEP>(a, grid, st);
   }
   if (dy_pro == PRO_ID) {
-    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, NS, ND, NWV, WPS, ava_bf16>(a, grid, st);
-    return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, NS, ND, NWV, WPS, float>(a, grid, st);
+    if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, NS, ND, NWV, WPS, ava_bf16, false, DEEP>(a, grid, st);
+    return launch_fused_limb_t<CI, CO, LMODE, PRO_ID, TW, TH, NS, ND, NWV, WPS, float, false, DEEP>(a, grid, st);
   }
   return AVA_EINVAL;
 }
 
 // Shapes with a limb instantiation: (cin, cout, mode) -> low-resolution tile, staging / data-gradient / weight-gradient waves,
 // waves per SIMD.  Measured in the step at batch 256 (tools/run_r04.sh variants; fp32 kernel -> this one):
-//   conv3  8 -> 16 S1   82.5 -> 63.6 us   1024 threads, 32 x 4 tiles (768 threads: 67.8; 32 x 8 tiles: 63.8)
+//   conv3  8 -> 16 S1   82.5 -> 52.4 us   1024 threads, 32 x 8 tiles (32 x 4: 59.3; the halo rows are 33 % instead of 59 % extra)
 //   convt5 16 -> 8 S1   92.3 -> 62.4 us   768 threads (168 VGPRs), 32 x 8 tiles (1024 threads, 32 x 4: 68.6)
 //   conv5  16 -> 24 S1  65.7 -> 43.8 us   768 threads: the data-gradient waves hold 84 VGPRs of limb weights
 //   convt3 24 -> 16 S1  63.8 -> 46.2 us   the two dx channel tiles dealt to odd / even data-gradient waves
@@ -619,10 +671,13 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 //   conv2 / convt6: below
 // (lab experiments: -DAVA_FL_CFG="th, ns, nd, nwv, wps" overrides conv3's row: tools/lab/build_variant.sh)
 #ifndef AVA_FL_CFG
-#define AVA_FL_CFG 32, 4, 8, 4, 4, 4          // conv3
+#define AVA_FL_CFG 32, 8, 8, 4, 4, 4          // conv3
 #endif
 #ifndef AVA_FL_CFG2
 #define AVA_FL_CFG2 32, 8, 8, 4, 4, 4         // convt5
+#endif
+#ifndef AVA_FL_T4
+#define AVA_FL_T4 16, 4, 8, 4, 4, 4           // convt4
 #endif
 #ifndef AVA_FL_T6
 #define AVA_FL_T6 16, 4, 4, 2, 2, 4           // convt6
@@ -684,7 +739,7 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #define AVA_FUSED_LIMB_SHAPES(X)                \
   AVA_FL_ROW(X, 8, 16, MODE_S1, AVA_FL_CFG)     \
   AVA_FL_ROW(X, 16, 8, MODE_S1, AVA_FL_CFG2)    \
-  X(16, 16, MODE_UP, 16, 4, 8, 4, 4, 4)         \
+  AVA_FL_ROW(X, 16, 16, MODE_UP, AVA_FL_T4)     \
   X(24, 16, MODE_S1, 32, 4, 8, 4, 4, 4)         \
   AVA_FL_ROW(X, 16, 24, MODE_S1, AVA_FL_C5)     \
   AVA_FL_ROW(X, 16, 16, MODE_DOWN, AVA_FL_C4)   \

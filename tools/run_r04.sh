@@ -7,7 +7,7 @@ out=gpurun_out/r04_$pass$tag
 mkdir -p $out
 prof() {   # prof <name>: kernel trace of a short bench -> $out/<name>_kernel_stats.csv
   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-  rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loader-path --global-batch 0 > $out/$1_bench_prof.json 2> $out/$1_bench_prof.err
+  timeout 400 rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-loader-path --global-batch 0 > $out/$1_bench_prof.json 2> $out/$1_bench_prof.err
   find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/$1_kernel_stats.csv \;
   rm -rf $out/prof
 }

@@ -81,24 +81,13 @@ template <int LMODE> __host__ __device__ constexpr int wl_units(int cin) { retur
 // the dU tile (conv_recomp.h: DU1to8Stager; its limb-plane store below).
 // DEEP: the staging waves hold TWO tiles in registers (tile it+2 and it+3 in flight while tile it+1 is converted): per tile the
 // matrix-core waves have ~1 us of work, a tile's loads take 2-3 us under load, so one tile in flight leaves both roles waiting
-// ROLE: 0 staging, 1 data gradient, 2 weight gradient.  The three roles are compiled as three SEPARATE (noinline) functions:
-// inlined into one kernel the register allocator spilled 100-350 values for the shapes whose roles each fit their budget
-// alone -- and a spill reload inside these loops is a dependent memory round trip.  A role
-// function gets a pointer to the kernel's argument block and makes every word wave-uniform (readfirstlane: the values end up in
-// SGPRs like a kernel's own arguments).  (__builtin_amdgcn_kernarg_segment_ptr() does not survive a call on this toolchain:
-// tools/lab/noinline_probe.hip faults with it and passes with the pointer.)
-template <int ROLE, int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC,
-          bool DEEP>
-__device__ __attribute__((noinline)) void fl_role(const FusedArgs* __restrict__ ap) {
-  FusedArgs a;
-  {
-    static_assert(sizeof(FusedArgs) % 4 == 0, "argument block is copied word by word");
-    unsigned u[sizeof(FusedArgs) / 4];
-    __builtin_memcpy(u, ap, sizeof(FusedArgs));
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(FusedArgs) / 4; ++i) u[i] = __builtin_amdgcn_readfirstlane(u[i]);
-    __builtin_memcpy(&a, u, sizeof(FusedArgs));
-  }
+// The three roles stay INLINED in one kernel.  Compiled as three noinline functions (tools/lab/noinline_roles.patch) each role gets
+// its own register allocation and the in-loop spills disappear -- but every kernel then carries 156-256 B of scratch per lane (the
+// callee-saved registers of the roles), and on this stack a kernel's time grows with its scratch size: the 16 x 16 layers, spill-free
+// either way, went 24.0 -> 30.6 us, the whole family +90 us (profiles/r04/ab_roles_*.csv).
+template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false,
+          bool DEEP = false>
+__global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_limb_kernel(const FusedArgs a) {
   using FG = FGeomL<LMODE, TW, TH>;
   constexpr int XR = FG::XR, XC = FG::XC, DR = FG::DR, DC = FG::DC, DOFF = FG::DOFF;
   constexpr int BMODE = LMODE == MODE_S1 ? MODE_S1 : (LMODE == MODE_DOWN ? MODE_UP : MODE_DOWN);   // gather pattern of dx
@@ -130,16 +119,15 @@ __device__ __attribute__((noinline)) void fl_role(const FusedArgs* __restrict__ 
   constexpr int DKG = PAIR ? 12 * (CO / 8) : 9 * (CO / 8);     // k-groups of the (single) data-gradient class
   constexpr int W2_TILE = W2L ? ((DKG + 3) / 4) * 1024 : 0;    // bytes per dx channel tile
   constexpr int W2_ALL = W2_TILE * MT;
-  static_assert((2 * BUF + (192 + ND * 32 * MT) * 4) % 8 == 0, "the fp64 scratch behind the tables must be 8-byte aligned");
   unsigned char* w2tab = reinterpret_cast<unsigned char*>(red + ND * 32 * MT);
-  double* accvals = reinterpret_cast<double*>(w2tab + W2_ALL); // [64] consumer prologue scratch (bn_coef_from_acc); W2_ALL is a multiple of 1 KB
-  float* ems = reinterpret_cast<float*>(accvals + 64);         // mean [0..31], invstd [32..63] of x's BatchNorm for the final reduction
-  float* xs = ems + 64;                                        // DUREC: the staging waves' private seed windows
+  float* xs = reinterpret_cast<float*>(w2tab + W2_ALL);        // DUREC: the staging waves' private seed windows
   static_assert(!DUREC || (CO == 8 && DYPRO == PRO_BWD && DR == 9 && NS == 4), "the 1 -> 8 gather feeds a 9-row dU window of 8 channels from four staging waves");
+  __shared__ double accvals[64];            // consumer prologue scratch (bn_coef_from_acc)
+  __shared__ float ems[64];                 // mean [0..31], invstd [32..63] of x's BatchNorm for the final reduction
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
-  constexpr bool stager = ROLE == 0;         // waves 0 .. NS-1 stage tiles, the next ND form the data gradient, the rest the weight gradient
+  const bool stager = wave8 < NS;            // waves 0 .. NS-1 stage tiles, the next ND form the data gradient, the rest the weight gradient
   const int n = lane & 15, kg = lane >> 4;
 
   // tile -> image, low-resolution origin, window origins
@@ -225,7 +213,7 @@ __device__ __attribute__((noinline)) void fl_role(const FusedArgs* __restrict__ 
   if (!stager) asm volatile("" ::"v"(wpf));
 
   if (stager && (AVA_FL_CUT & 1)) return;
-  if constexpr (ROLE == 0) {
+  if (stager) {
     // ---------------- staging waves ----------------
     __builtin_amdgcn_s_setprio(3);           // issue priority over the matrix-core waves of the same SIMD (conv_fused.hip)
     if constexpr (DEEP) {
@@ -277,8 +265,8 @@ __device__ __attribute__((noinline)) void fl_role(const FusedArgs* __restrict__ 
     return;
   }
 
-  if (ROLE == 1 && (AVA_FL_CUT & 2)) return;
-  if constexpr (ROLE == 1) {
+  if (wave8 < NS + ND && (AVA_FL_CUT & 2)) return;
+  if (wave8 < NS + ND) {
     // ---------------- data-gradient waves ----------------
     // Stride-2 conv layers (dx gathered in four output-parity classes): with four data-gradient waves each wave takes ONE
     // class for all of the tile's pixel groups and holds only that class's limb weights (1-2 chunks instead of 5: with all
@@ -464,7 +452,6 @@ __device__ __attribute__((noinline)) void fl_role(const FusedArgs* __restrict__ 
     return;
   }
 
-  if constexpr (ROLE == 2) {
   // ---------------- weight-gradient waves ----------------
   if (AVA_FL_CUT & 4) return;
   // Units: the M tiles (16 rows of (tap, ci)) of every tap class, numbered class by class, plus the bias row as unit NU.
@@ -618,18 +605,6 @@ __device__ __attribute__((noinline)) void fl_role(const FusedArgs* __restrict__ 
   else if (NWV > 1 && ww == 1) w_role(ava_ic<(NWV > 1 ? 1 : 0)>{});
   else if (NWV > 2 && ww == 2) w_role(ava_ic<(NWV > 2 ? 2 : 0)>{});
   else if (NWV > 3) w_role(ava_ic<(NWV > 3 ? 3 : 0)>{});
-  }
-}
-
-// ACT: storage type of the activations x (layer input) and dy2 (saved output); dy and dx are fp32 gradients.
-// NS / ND / NWV: staging, data-gradient and weight-gradient waves of the workgroup; WPS: minimum waves per SIMD (register budget).
-template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false,
-          bool DEEP = false>
-__global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_limb_kernel(const FusedArgs a) {
-  const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  if (wave8 < NS) fl_role<0, CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>(&a);
-  else if (wave8 < NS + ND) fl_role<1, CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>(&a);
-  else fl_role<2, CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>(&a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -641,7 +616,7 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   constexpr size_t buf = (size_t)3 * 16 * ((CI / 8) * FG::XR * FG::XC + (CO / 8) * FG::DR * FG::DC);
   constexpr bool PAIRL = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
   constexpr int W2_ALL = LMODE == MODE_DOWN ? 0 : (((PAIRL ? 12 : 9) * (CO / 8) + 3) / 4) * 1024 * MT;   // the kernel's third-limb table
-  constexpr size_t lds = 2 * buf + (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL + 64 * sizeof(double) + 64 * sizeof(float);
+  constexpr size_t lds = 2 * buf + (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL;
   constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
   static_assert(WG_PER_CU >= 1 && (lds + 1024) * WG_PER_CU <= 160 * 1024, "the resident workgroups' tile buffers must fit 160 KB of LDS");
   const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>);

@@ -684,19 +684,19 @@ static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream
 #define AVA_FL_T3 32, 4, 8, 4, 4, 4           // convt3
 #endif
 #ifndef AVA_FL_T4
-#define AVA_FL_T4 16, 4, 8, 4, 4, 4           // convt4
+#define AVA_FL_T4 16, 4, 10, 4, 2, 4          // convt4 (8+4+4: 41.3 us, 10+4+2: 38.6 us)
 #endif
 #ifndef AVA_FL_T6
 #define AVA_FL_T6 16, 4, 4, 2, 2, 4           // convt6
 #endif
 #ifndef AVA_FL_C2
-#define AVA_FL_C2 16, 4, 4, 2, 2, 4           // conv2
+#define AVA_FL_C2 16, 4, 3, 4, 1, 4           // conv2: one dx parity class per data-gradient wave (99.8 -> 78.3 us; 2+4+2: 80.1)
 #endif
 #ifndef AVA_FL_C4
 #define AVA_FL_C4 16, 4, 8, 4, 4, 4           // conv4
 #endif
 #ifndef AVA_FL_C5
-#define AVA_FL_C5 32, 4, 8, 4, 4, 4           // conv5
+#define AVA_FL_C5 32, 4, 9, 4, 3, 4           // conv5 (8+4+4: 39.7 us, 9+4+3: 38.5 us)
 #endif
 // The four layers at 16 x 16 (conv6, conv7, convt1, convt2; until round 4 a data-gradient launch plus half a weight-gradient
 // pair launch each).  With 24 / 32 channels on both sides the three roles together spilled 100-350 registers at 128 or 168

@@ -354,6 +354,21 @@ struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2, MAXQP> {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // store_tight() that also leaves the RAW values (before the prologue) of the window's interior [RI x CIr] at offset
+  // (ROFF, COFF) in `raw` as fp32 [RI][CIr][CIN]: the fused backward's data-gradient waves take the x of their dx pixels from
+  // there for the BatchNorm-backward sums instead of loading it from global memory a second time (conv_fused_limb.hip)
+  template <int ROFF, int COFF, int RI, int CIr>
+  __device__ __forceinline__ void store_tight_raw(unsigned char* __restrict__ lds, const float* __restrict__ coef, float* __restrict__ raw) {
+    const Coefs kq = this->coefs_of(coef);
+#pragma unroll
+    for (int i = 0; i < Base::NPF; ++i) {
+      store_one(i, lds, coef, kq);
+      const int r = (this->rc[i] >> 16) - ROFF, c = (this->rc[i] & 0xffff) - COFF;
+      if (((this->live >> i) & 1u) && (unsigned)r < (unsigned)RI && (unsigned)c < (unsigned)CIr)
+        *reinterpret_cast<avaf4*>(raw + (r * CIr + c) * CIN + this->q4[i]) = this->v[i];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   // see TileStager::store_load
   __device__ __forceinline__ void store_load(unsigned char* __restrict__ lds, const float* __restrict__ coef,
                                              const float* __restrict__ in, const float* __restrict__ in2, int b, int Hi,

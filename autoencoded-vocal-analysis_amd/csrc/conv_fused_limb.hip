@@ -64,7 +64,34 @@ struct FGeomL {
 
 template <int N> using ava_ic = std::integral_constant<int, N>;
 
+#ifndef AVA_FL_RAWX
+#define AVA_FL_RAWX 1                      // lab: 0 = the data-gradient waves load the raw x of their dx pixels from global memory
+#endif
+// Dynamic LDS of one workgroup (kernel and launcher agree on it here).  RAWX: each tile buffer also holds the raw x of the dx
+// region as fp32 [OH][OW][CI] (TileStagerL::store_tight_raw) wherever the resident workgroups still fit the CU's 160 KB.
+template <int CI, int CO, int LMODE, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC, bool DEEP>
+struct FLds {
+  using FG = FGeomL<LMODE, TW, TH>;
+  static constexpr int MT = (CI + 15) / 16;
+  static constexpr bool PAIRL = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
+  static constexpr int W2_ALL = LMODE == MODE_DOWN ? 0 : (((PAIRL ? 12 : 9) * (CO / 8) + 3) / 4) * 1024 * MT;   // the third-limb table
+  static constexpr size_t planes = (size_t)3 * 16 * ((CI / 8) * FG::XR * FG::XC + (CO / 8) * FG::DR * FG::DC);
+  static constexpr size_t raw = (size_t)FG::OH * FG::OW * CI * sizeof(float);
+  static constexpr size_t rest = (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL;
+  static constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
+  // measured per layer (same box, us): conv2 78.3 -> 70.3, conv4 46.6 -> 40.7, convt3 43.5 -> 37.2, conv6 34.7 -> 31.9, convt5 61.2 -> 59.4,
+  // convt4 / convt2 / convt6 +-1; the stride-1 layers with MORE output than input channels lose (conv3 53.5 -> 60.1, conv5 38.8 -> 45.2:
+  // few x channels to fetch, and their staging waves are the longer role already)
+  static constexpr bool RAWX = AVA_FL_RAWX && !DEEP && !(LMODE == MODE_S1 && CI < CO && AVA_FL_RAWX < 2) &&
+                               (2 * (planes + raw) + rest + 1024) * WG_PER_CU <= 160 * 1024;
+  static constexpr size_t buf = planes + (RAWX ? raw : 0);
+  static constexpr size_t lds = 2 * buf + rest;
+};
+
 // lab: compile a wave role out (register-pressure / ablation experiments; results are wrong): 1 staging, 2 data gradient, 4 weight gradient
+#ifndef AVA_FL_DCUT
+#define AVA_FL_DCUT 0                      // lab, timing only: 1 no raw-x ring loads, 2 no dx stores, 4 no fragment reads / MFMAs
+#endif
 #ifndef AVA_FL_CUT
 #define AVA_FL_CUT 0
 #endif
@@ -108,7 +135,10 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   constexpr int MTD = DSPLIT ? 1 : MT;
   constexpr int XNPIX = XR * XC, DNPIX = DR * DC;
   constexpr int XPLANE = (CI / 8) * XNPIX * 16, DPLANE = (CO / 8) * DNPIX * 16;      // bytes
-  constexpr int XBYTES = 3 * XPLANE, BUF = XBYTES + 3 * DPLANE;
+  using FL = FLds<CI, CO, LMODE, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>;
+  constexpr bool RAWX = FL::RAWX;           // raw x of the dx region behind the planes of each tile buffer
+  constexpr int XBYTES = 3 * XPLANE, RAWOFF = XBYTES + 3 * DPLANE, BUF = (int)FL::buf;
+  static_assert(FL::planes == (size_t)RAWOFF, "kernel and launcher agree on the tile buffer");
   extern __shared__ __align__(16) unsigned char smem_b[];
   float* cx = reinterpret_cast<float*>(smem_b + 2 * BUF);     // [3][32]
   float* cd = cx + 96;                                         // [3][32]
@@ -244,8 +274,13 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
       __syncthreads();                                          // (E)
       return;
     }
+    constexpr int XOFF = LMODE == MODE_UP ? 0 : 1;              // the dx region inside the x window
+    auto sx_store = [&](unsigned char* dst) __attribute__((always_inline)) {
+      if constexpr (RAWX) sx.template store_tight_raw<XOFF, XOFF, FG::OH, FG::OW>(dst, cx, reinterpret_cast<float*>(dst + RAWOFF));
+      else sx.store_tight(dst, cx);
+    };
     if (walk.valid()) {
-      sx.store_tight(smem_b, cx);
+      sx_store(smem_b);
       sd_store(smem_b + XBYTES);
       if (walk.has_next()) prefetch(walk.next());
     }
@@ -254,7 +289,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     for (; walk.valid(); walk.advance(), ++it) {
       if (walk.has_next()) {                                    // tile it+1 -> the other buffer, tile it+2 in flight
         unsigned char* nb = smem_b + ((it + 1) & 1) * BUF;
-        sx.store_tight(nb, cx);
+        sx_store(nb);
         sd_store(nb + XBYTES);
         const int nn = walk.next() + walk.step;
         if (nn < walk.end) prefetch(nn);
@@ -306,6 +341,15 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
         }
         return (((PAIR ? 2 : 1) * (g / CB)) * a.Wi + 16 * (g % CB)) * CI;
       };
+      // RAWX: the raw x of this lane's dx pixels comes from the tile buffer (same index arithmetic with the region's width)
+      const int lane_raw = PAIR ? ((kg >> 1) * FG::OW + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
+      auto group_raw = [&](int g) -> int {
+        if (BMODE == MODE_UP) {
+          const int cls = g & 3, rest = g >> 2, r = rest / CB, cb = rest % CB;
+          return ((2 * r + (cls >> 1)) * FG::OW + 32 * cb + (cls & 1)) * CI;
+        }
+        return (((PAIR ? 2 : 1) * (g / CB)) * FG::OW + 16 * (g % CB)) * CI;
+      };
       // raw x at this lane's dx pixels (BatchNorm-backward sums): a ring of LA groups in flight -- group gi's values are
       // requested LA groups ahead of their use (the lines were fetched by the staging waves a tile or two earlier: L2 hits),
       // running on into the first groups of the next tile.
@@ -330,10 +374,16 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
         const int oy0 = LMODE == MODE_DOWN ? 2 * y0 : y0, ox0 = LMODE == MODE_DOWN ? 2 * x0 : x0;
         return ava_as<ACT>(a.x) + (((size_t)b * a.Hi + oy0) * a.Wi + ox0) * CI;
       };
-      if (walk.valid()) {
+      if (!RAWX && walk.valid()) {
         const ACT* __restrict__ xb = ex_base(walk.cur);
 #pragma unroll
         for (int gi = 0; gi < LA; ++gi) load_ex_group(xb, gi, ring[gi]);
+      }
+      if (AVA_FL_DCUT & 1) {
+#pragma unroll
+        for (int gi = 0; gi < LA; ++gi)
+#pragma unroll
+          for (int mt = 0; mt < MTD; ++mt) ring[gi][mt] = (avaf4){1.f, 1.f, 1.f, 1.f};
       }
       __syncthreads();                                              // (A)
       int it = 0;
@@ -345,26 +395,36 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
         const size_t tile_pix = ((size_t)b * a.Hi + oy0) * a.Wi + ox0;
         float* __restrict__ obase = a.dx + tile_pix * CI;
         const ACT* __restrict__ xcur = ava_as<ACT>(a.x) + tile_pix * CI;
-        const ACT* __restrict__ xnext = walk.has_next() ? ex_base(walk.next()) : xcur;     // (last tile: harmless re-reads)
+        const ACT* __restrict__ xnext = (!RAWX && walk.has_next()) ? ex_base(walk.next()) : xcur;     // (last tile: harmless re-reads)
+        const float* __restrict__ rawt = reinterpret_cast<const float*>(smem_b + (it & 1) * BUF + RAWOFF);
         auto do_group = [&](int gi) __attribute__((always_inline)) {
           const int g = group_of(gi);
           avaf4 exv[MTD];
+          if constexpr (RAWX) {
 #pragma unroll
-          for (int mt = 0; mt < MTD; ++mt) exv[mt] = ring[0][mt];
+            for (int mt = 0; mt < MTD; ++mt) {
+              const int cb4 = 16 * (mtb + mt) + cq;                  // lanes beyond CI re-read slot 0 (their sums are dropped)
+              exv[mt] = *reinterpret_cast<const avaf4*>(rawt + group_raw(g) + (cb4 < CI ? lane_raw + 16 * (mtb + mt) : lane_raw - 4 * kg));
+            }
+          } else {
 #pragma unroll
-          for (int k = 0; k + 1 < LA; ++k)
+            for (int mt = 0; mt < MTD; ++mt) exv[mt] = ring[0][mt];
 #pragma unroll
-            for (int mt = 0; mt < MTD; ++mt) ring[k][mt] = ring[k + 1][mt];
-          {
+            for (int k = 0; k + 1 < LA; ++k)
+#pragma unroll
+              for (int mt = 0; mt < MTD; ++mt) ring[k][mt] = ring[k + 1][mt];
             const int gn = gi + LA;                                  // the group LA ahead: of this tile or of the next one
-            load_ex_group(gn < GPW ? xcur : xnext, gn < GPW ? gn : gn - GPW, ring[LA - 1]);
+            if (!(AVA_FL_DCUT & 1)) load_ex_group(gn < GPW ? xcur : xnext, gn < GPW ? gn : gn - GPW, ring[LA - 1]);
           }
           f32x4 acc[2][MTD];
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int mt = 0; mt < MTD; ++mt) acc[h][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (BMODE == MODE_UP) {
+          if (AVA_FL_DCUT & 4) {
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) acc[0][mt] = (f32x4){exv[mt][0], exv[mt][1], exv[mt][2], exv[mt][3]};
+          } else if (BMODE == MODE_UP) {
             const int rest = g >> 2, r = rest / CB, cb = rest % CB;
             const unsigned char* px = dut + (r * DC + 16 * cb) * 16;
             if constexpr (CSPLIT) {
@@ -393,7 +453,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
                 s1[mt][r] += v[r];
                 s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
               }
-              *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+              if (!(AVA_FL_DCUT & 2)) *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
             }
           }
         };
@@ -611,13 +671,9 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 template <int CI, int CO, int LMODE, int DYPRO, int TW, int TH, int NS, int ND, int NWV, int WPS, typename ACT, bool DUREC = false,
           bool DEEP = false>
 static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
-  using FG = FGeomL<LMODE, TW, TH>;
-  constexpr int MT = (CI + 15) / 16;
-  constexpr size_t buf = (size_t)3 * 16 * ((CI / 8) * FG::XR * FG::XC + (CO / 8) * FG::DR * FG::DC);
-  constexpr bool PAIRL = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
-  constexpr int W2_ALL = LMODE == MODE_DOWN ? 0 : (((PAIRL ? 12 : 9) * (CO / 8) + 3) / 4) * 1024 * MT;   // the kernel's third-limb table
-  constexpr size_t lds = 2 * buf + (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL;
-  constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
+  using FL = FLds<CI, CO, LMODE, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>;
+  constexpr size_t lds = FL::lds;
+  constexpr int WG_PER_CU = FL::WG_PER_CU;
   static_assert(WG_PER_CU >= 1 && (lds + 1024) * WG_PER_CU <= 160 * 1024, "the resident workgroups' tile buffers must fit 160 KB of LDS");
   const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>);
   static bool attr_set = false;

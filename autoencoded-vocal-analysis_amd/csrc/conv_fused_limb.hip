@@ -64,6 +64,9 @@ struct FGeomL {
 
 template <int N> using ava_ic = std::integral_constant<int, N>;
 
+#ifndef AVA_FL_DUNROLL
+#define AVA_FL_DUNROLL 1                   // unroll factor of the data-gradient waves' rolled pixel-group loop
+#endif
 #ifndef AVA_FL_RAWX
 #define AVA_FL_RAWX 1                      // lab: 0 = the data-gradient waves load the raw x of their dx pixels from global memory
 #endif
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
           }
         };
         if constexpr (ROLLED) {
-#pragma unroll 1
+#pragma unroll AVA_FL_DUNROLL
           for (int gi = 0; gi < GPW; ++gi) do_group(gi);
         } else {
 #pragma unroll

@@ -64,6 +64,12 @@ struct FGeomL {
 
 template <int N> using ava_ic = std::integral_constant<int, N>;
 
+#ifndef AVA_FL_NTSTORE
+#define AVA_FL_NTSTORE 0                   // lab: dx written with non-temporal stores
+#endif
+#ifndef AVA_FL_W2L
+#define AVA_FL_W2L 1                       // third weight limb of the single-class data gradients in an LDS table: 1 always, 0 never, 2 where the raw-x ring still takes registers
+#endif
 #ifndef AVA_FL_DUNROLL
 #define AVA_FL_DUNROLL 1                   // unroll factor of the data-gradient waves' rolled pixel-group loop
 #endif
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   float* red = cd + 96;                                        // [ND][32 * MT]: per data-gradient wave {sum g [16 MT], sum g x [16 MT]}
   // the data-gradient weights' third limb as an LDS table (ClassFragL: W2L) where one wave holds ALL of a class's chunks
   // (single-class gathers): the role then fits 128 VGPRs with room to spare
-  constexpr bool W2L = BCLS == 1;
+  constexpr bool W2L = BCLS == 1 && (AVA_FL_W2L == 1 || (AVA_FL_W2L == 2 && !RAWX));
   constexpr int DKG = PAIR ? 12 * (CO / 8) : 9 * (CO / 8);     // k-groups of the (single) data-gradient class
   constexpr int W2_TILE = W2L ? ((DKG + 3) / 4) * 1024 : 0;    // bytes per dx channel tile
   constexpr int W2_ALL = W2_TILE * MT;
@@ -456,7 +462,10 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
                 s1[mt][r] += v[r];
                 s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);          // raw x: centred after the loop
               }
-              if (!(AVA_FL_DCUT & 2)) *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+              if (!(AVA_FL_DCUT & 2)) {
+                if (AVA_FL_NTSTORE) __builtin_nontemporal_store((avaf4){v[0], v[1], v[2], v[3]}, reinterpret_cast<avaf4*>(obase + gout + 16 * (mtb + mt)));
+                else *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+              }
             }
           }
         };

@@ -64,6 +64,9 @@ struct FGeomL {
 
 template <int N> using ava_ic = std::integral_constant<int, N>;
 
+#ifndef AVA_FL_RAWPRE
+#define AVA_FL_RAWPRE 0                    // lab: unrolled group loops request the raw x of every group at the top of the tile
+#endif
 #ifndef AVA_FL_NTSTORE
 #define AVA_FL_NTSTORE 0                   // lab: dx written with non-temporal stores
 #endif
@@ -406,15 +409,28 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
         const ACT* __restrict__ xcur = ava_as<ACT>(a.x) + tile_pix * CI;
         const ACT* __restrict__ xnext = (!RAWX && walk.has_next()) ? ex_base(walk.next()) : xcur;     // (last tile: harmless re-reads)
         const float* __restrict__ rawt = reinterpret_cast<const float*>(smem_b + (it & 1) * BUF + RAWOFF);
+        auto raw_of = [&](int gi, int mt) -> avaf4 {
+          const int cb4 = 16 * (mtb + mt) + cq;                      // lanes beyond CI re-read slot 0 (their sums are dropped)
+          return *reinterpret_cast<const avaf4*>(rawt + group_raw(group_of(gi)) + (cb4 < CI ? lane_raw + 16 * (mtb + mt) : lane_raw - 4 * kg));
+        };
+        // unrolled group loop: the raw x of all of the tile's groups is requested in front of the first fragment read
+        constexpr bool RAWPRE = RAWX && !ROLLED && AVA_FL_RAWPRE;
+        avaf4 rawall[RAWPRE ? GPW : 1][MTD];
+        if constexpr (RAWPRE) {
+#pragma unroll
+          for (int gi = 0; gi < GPW; ++gi)
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) rawall[gi][mt] = raw_of(gi, mt);
+        }
         auto do_group = [&](int gi) __attribute__((always_inline)) {
           const int g = group_of(gi);
           avaf4 exv[MTD];
-          if constexpr (RAWX) {
+          if constexpr (RAWPRE) {
 #pragma unroll
-            for (int mt = 0; mt < MTD; ++mt) {
-              const int cb4 = 16 * (mtb + mt) + cq;                  // lanes beyond CI re-read slot 0 (their sums are dropped)
-              exv[mt] = *reinterpret_cast<const avaf4*>(rawt + group_raw(g) + (cb4 < CI ? lane_raw + 16 * (mtb + mt) : lane_raw - 4 * kg));
-            }
+            for (int mt = 0; mt < MTD; ++mt) exv[mt] = rawall[gi][mt];
+          } else if constexpr (RAWX) {
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) exv[mt] = raw_of(gi, mt);
           } else {
 #pragma unroll
             for (int mt = 0; mt < MTD; ++mt) exv[mt] = ring[0][mt];

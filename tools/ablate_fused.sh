@@ -10,7 +10,7 @@ cp $C/conv_fused.hip /tmp/conv_fused.orig
 patch -p1 -s < tools/lab/fused_ablation.patch
 for b in ${1:-"1 2 4 8 16 12"}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -DAVA_ABL=$b -c $C/conv_fused.hip -o /tmp/cf_abl$b.o
-  ( cd $C && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC conv_dispatch.o conv_mfma.o conv_ws.o /tmp/cf_abl$b.o conv_thin.o gemm.o bn.o misc.o mmd.o feed.o spec.o model.o -o libava_hip_abl$b.so -Wl,-rpath,/opt/rocm/lib -lpthread )
+  ( cd $C && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC conv_dispatch.o conv_mfma.o conv_ws.o /tmp/cf_abl$b.o conv_thin.o conv_thin_perop.o gemm.o bn.o misc.o mmd.o feed.o spec.o model.o -o libava_hip_abl$b.so -Wl,-rpath,/opt/rocm/lib -lpthread )
 done
 cp /tmp/conv_fused.orig $C/conv_fused.hip
 for tag in "" $(for b in ${1:-"1 2 4 8 16 12"}; do echo abl$b; done) ""; do

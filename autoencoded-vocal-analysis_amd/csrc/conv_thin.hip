@@ -18,6 +18,10 @@
 // ava_conv3x3 / ava_conv3x3_wgrad.  Same ConvArgs / WgradArgs / partial-row conventions as conv.hip.
 #include "conv_thin_kernels.h"
 
+#ifndef AVA_THIN_RECY
+#define AVA_THIN_RECY 1     // conv1's backward recomputes y1 from x (thin_bwd_fused_1to8_kernel<.., RECY>); 0: reads the saved tensor
+#endif
+
 // launchers of the kernel forms that only the per-operation entry points reach (conv_thin_perop.hip): the separate data gradients
 // of conv1 / convt7 (the model's backward runs the fused kernels instead) and the separate weight gradients
 int ava_conv3x3_thin_perop(const ConvArgs& a, int grid, int W, int Cin, int pro, hipStream_t st);
@@ -64,6 +68,7 @@ static int thin_fused_grid_w(int nt, int Cin) {
     static const int cap1 = [] {
       const char* e = ava_env("AVA_THIN_GRID1");
       if (e && atoi(e) >= 8) return atoi(e);
+      if (AVA_THIN_RECY) return thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD, float, true>, W, 0);   // 238 VGPRs: two 256-thread workgroups per CU
       if (W == 128) return 768;
       return thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD>, W, 0);
     }();
@@ -100,7 +105,10 @@ static int thin_bwd_fused_launch_w(const FusedArgs& a0, int grid, int Cin, int d
   const dim3 block(2 * W);
   if (Cin == 1) {
     if (a.dx != nullptr) return AVA_EINVAL;              // this layer's data gradient is never formed
-    if (dy_pro == PRO_BWD && a.act_bf16) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD, ava_bf16>), dim3(grid), block, 0, st, a);
+    const bool recy = AVA_THIN_RECY && dy_pro == PRO_BWD && a.rc.G1 != nullptr && a.rc.bias1 != nullptr && a.rc.pa1 != nullptr && a.rc.pb1 != nullptr;
+    if (recy && a.act_bf16) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD, ava_bf16, true>), dim3(grid), block, 0, st, a);
+    else if (recy) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD, float, true>), dim3(grid), block, 0, st, a);
+    else if (dy_pro == PRO_BWD && a.act_bf16) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD, ava_bf16>), dim3(grid), block, 0, st, a);
     else if (dy_pro == PRO_BWD) hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_BWD>), dim3(grid), block, 0, st, a);
     else hipLaunchKernelGGL((thin_bwd_fused_1to8_kernel<W, PRO_ID>), dim3(grid), block, 0, st, a);      // no activation read
     AVA_CHECK_LAUNCH();

@@ -715,9 +715,15 @@ __global__ __launch_bounds__(2 * W, W == 128 ? 2 : 1) void thin_wgrad_8to1_kerne
 // ---------------------------------------------------------------------------------------------------------
 // Thread mapping: lane pair (2x, 2x+1) shares pixel column x; thread (x, h) owns channels 4h..4h+3 of the 8 rows
 // of the tile, so every g / y load is one 16-byte slot per lane, contiguous across the wave.
-template <int W, int DYPRO, typename ACT = float>
+// RECY: the saved activation y1 = relu(conv1(bn1 x)) (a.dy2: the ReLU mask and the y term of bn2's backward) is NOT read -- it
+// is recomputed from the x window the kernel stages anyway, with exactly thin_1to8_kernel's arithmetic (bn1 as one fma, zero
+// outside the image; accumulator from 0, kx outer, ky inner; + bias; ReLU; storage rounding): bit-identical values for 72 more
+// fmas per pixel instead of 32 bytes per pixel from HBM (a.rc: conv1's gather weights, bias, bn1 scale / shift).
+template <int W, int DYPRO, typename ACT = float, bool RECY = false>
 __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedArgs a) {
+  static_assert(!RECY || DYPRO == PRO_BWD, "only the ReLU / BatchNorm-backward prologue reads the activation");
   __shared__ float tile[THIN_IR * THIN_IC];             // xhat0 window
+  __shared__ float tile_n[RECY ? THIN_IR * THIN_IC : 1];       // RECY: bn1(x) window (conv1's input, zero padded)
   __shared__ float red[THIN_NW][2][44];                       // per wave, per channel half: dG' [9][4], T [4], border sums
   __shared__ float tot[2][44];
   __shared__ float ccol[2][2][4], kcor[2][2][2][4];     // [left/right][h], [left/right][top/bottom][h]
@@ -748,6 +754,13 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
   }
   const bool edge_col = x == 0 || x == W - 1;
   const int tiles_y = a.Ho / THIN_TH;
+  __shared__ float w1s[RECY ? 80 : 1];                  // RECY: conv1's gather weights [9][8] and bias [8] (read per use: 36 VGPRs otherwise)
+  float ca1 = 0.f, cb1 = 0.f;
+  if constexpr (RECY) {
+    if (t < 72) w1s[t] = a.rc.G1[t];
+    else if (t < 80) w1s[t] = a.rc.bias1[t - 72];
+    ca1 = ava_uniform(a.rc.pa1[0]); cb1 = ava_uniform(a.rc.pb1[0]);
+  }
   ThinWindow<W, PRO_BN> win;
   TileWalk walk(a.ntiles, a.sweep == 0);
   if (walk.valid()) { const int tl = walk.cur, b0 = tl / tiles_y; win.load(a.x, nullptr, b0, a.Hi, (tl - b0 * tiles_y) * THIN_TH - 1); }
@@ -756,10 +769,51 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     __syncthreads();
     win.store(tile, ha, hb, 0.f);
+    if constexpr (RECY) win.store(tile_n, ca1, cb1, 0.f);
     const size_t o0 = (((size_t)b * a.Ho + oy0) * W + x) * 8 + 4 * h;
     float du[THIN_TH][4];
+    float yrec[RECY ? THIN_TH : 1][4];
+    if constexpr (RECY) {
+      float4 gq[THIN_TH];
 #pragma unroll
-    for (int p = 0; p < THIN_TH; ++p) {
+      for (int p = 0; p < THIN_TH; ++p) gq[p] = *reinterpret_cast<const float4*>(a.dy + o0 + (size_t)p * W * 8);     // in flight over the barrier
+      __syncthreads();                                  // tile_n (and tile) written
+      int hoff = 4 * h;
+      asm volatile("" : "+v"(hoff));                    // keeps the weight reads inside the tile loop (hoisted they cost 36 VGPRs and a resident workgroup)
+#pragma unroll
+      for (int p = 0; p < THIN_TH; ++p)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) yrec[p][c] = 0.f;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float inn[THIN_IR];
+#pragma unroll
+        for (int j = 0; j < THIN_IR; ++j) inn[j] = tile_n[j * THIN_IC + x + kx];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const avaf4 wq = *reinterpret_cast<const avaf4*>(w1s + (ky * 3 + kx) * 8 + hoff);
+#pragma unroll
+          for (int p = 0; p < THIN_TH; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) yrec[p][c] = fmaf(inn[p + ky], wq[c], yrec[p][c]);
+        }
+      }
+      const avaf4 bq = *reinterpret_cast<const avaf4*>(w1s + 72 + hoff);
+#pragma unroll
+      for (int p = 0; p < THIN_TH; ++p) {
+        float yv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) yv[c] = ava_stored<ACT>(fmaxf(yrec[p][c] + bq[c], 0.f));
+        const float gv[4] = {gq[p].x, gq[p].y, gq[p].z, gq[p].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          du[p][c] = prologue<DYPRO>(gv[c], yv[c], da[c], db[c], dc[c]);
+          T[c] += du[p][c];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < (RECY ? 0 : THIN_TH); ++p) {
       const float4 g = *reinterpret_cast<const float4*>(a.dy + o0 + (size_t)p * W * 8);
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (DYPRO == PRO_BWD) {
@@ -791,7 +845,7 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
         Cc[c] += s;
       }
     }
-    __syncthreads();
+    if constexpr (!RECY) __syncthreads();
     if (walk.has_next()) { const int tn = walk.next(), bn = tn / tiles_y; win.load(a.x, nullptr, bn, a.Hi, (tn - bn * tiles_y) * THIN_TH - 1); }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {

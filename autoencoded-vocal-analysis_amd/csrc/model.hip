@@ -1058,6 +1058,8 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
       if (l == 13) a.skip_dx = 1;
       if (l == 12) { a.dy = m->seed; a.rcd.G1 = m->Gb[13]; }
     }
+    // conv1's backward recomputes y1 from the x window it stages instead of reading it (conv_thin_kernels.h: RECY)
+    if (l == 0 && pro == PRO_BWD) a.rc = recomp_args(m);
     TRY(ava_conv3x3_bwd_fused_launch(a, L.cin, L.cout, L.mode, pro, st));
     mark(m, CAT_CONV_BWD_DATA, st);
     if (a.acc_out != nullptr) return AVA_OK;                  // finalised by the next backward kernel

@@ -367,7 +367,8 @@ def main():
         for r in (0, 16, 32):
             os.environ["AVA_CU_RESERVE"] = str(r)
             reserve_sweep[str(r)] = round(1e3 * timed(pool, ssteps, max(3, args.warmup // 2)) / ssteps, 4)
-        best_r = min(reserve_sweep, key=lambda k: reserve_sweep[k])
+        # every rank holds the same (MAX-reduced) times, so every rank takes the same decision; ties go to the smaller reserve
+        best_r = min(reserve_sweep, key=lambda k: (reserve_sweep[k], int(k)))
         os.environ["AVA_CU_RESERVE"] = best_r
         reserve_sweep = {"ms_per_step": reserve_sweep, "steps_each": ssteps, "chosen": int(best_r)}
     dt = timed(pool, args.steps, args.warmup)

@@ -84,7 +84,9 @@ __device__ __forceinline__ double bn_acc_read(const long long* slot, int idx) {
 // so reads queued behind a tile prefetch would wait for it): its 64 lanes read the 64 values, lanes 0..31 finalise with
 // the upper half's value handed over by a shuffle.  The per-channel parameters are requested BEFORE the counters, so the
 // chain is one memory latency long.  `vals` is unused (kept for the callers' scratch declarations).
-__device__ __forceinline__ void bn_coef_from_acc(float* coef, double* vals, const BnFin& f, int t0 = 0) {
+// `ext` (LDS [64], forward only, may be null): also hands the caller {mean [32], invstd [32]} of the layer (a forward kernel
+// that needs xhat itself: convt7's forward forms its own weight gradient, conv_thin_kernels.h FOLD).
+__device__ __forceinline__ void bn_coef_from_acc(float* coef, double* vals, const BnFin& f, int t0 = 0, float* ext = nullptr) {
   (void)vals;
   const int t = (int)threadIdx.x - t0;
   if (t >= 0 && t < 64) {
@@ -113,6 +115,7 @@ __device__ __forceinline__ void bn_coef_from_acc(float* coef, double* vals, cons
           const float sc = p0 * invstd;
           k0 = sc;
           k1 = p1 - meanf * sc;
+          if (ext != nullptr) { ext[c] = meanf; ext[32 + c] = invstd; }
           if (pub) {
             f.save[c] = meanf; f.save[32 + c] = invstd; f.save[64 + c] = k0; f.save[96 + c] = k1;
             if (f.running_mean != nullptr) {
@@ -136,6 +139,7 @@ __device__ __forceinline__ void bn_coef_from_acc(float* coef, double* vals, cons
         }
       }
       coef[c] = k0; coef[32 + c] = k1; coef[64 + c] = k2;
+      if (ext != nullptr && !live) { ext[c] = 0.f; ext[32 + c] = 0.f; }
       if (c == 0 && pub && !f.backward && f.num_batches != nullptr) *f.num_batches += 1;
     }
   }

@@ -17,6 +17,16 @@ struct RecompArgs {
   const float* pb1 = nullptr;
 };
 
+// convt7's forward also forms convt7's weight / bias gradient partials and the BatchNorm-backward sums of its input (they need
+// only the input windows and the seed prec * (xhat - x), both in registers there): conv_thin_kernels.h, FOLD
+struct ThinFold {
+  float* wg_partials = nullptr;    // [part_rows][73]; null: no fold
+  long long* acc_out = nullptr;    // BatchNorm-backward sums {sum dx, sum dx * xhat} of the layer input (bn_acc.h slot); null: bn_partials
+  float* bn_partials = nullptr;    // [part_rows][16] when acc_out is null
+  const float* mean = nullptr;     // batch statistics of the layer input when the prologue reads coefficient arrays (fin.acc null)
+  const float* invstd = nullptr;
+};
+
 struct ConvArgs {
   const float* in;
   const float* in2;
@@ -40,6 +50,7 @@ struct ConvArgs {
   long long* acc_out;  // != null: the per-channel sums of the epilogue are accumulated here (bn_acc.h) instead of partial rows
   BnFin fin;     // fin.acc != null: the prologue coefficients are derived from accumulated sums instead of pa / pb / pc
   RecompArgs rc; // rc.G1 != null: `in` is the raw spectrogram batch x and the kernel recomputes y1 = relu(conv1(bn1 x)) from it
+  ThinFold fold; // fold.wg_partials != null (convt7's training forward): the launch also leaves the layer's weight-gradient partials behind
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
 };
 
@@ -433,6 +444,7 @@ struct ConvAcc {
   long long* acc_out;    // producer side (null: partial rows)
   BnFin fin;             // consumer side (fin.acc null: coefficient arrays)
   RecompArgs rc;         // conv2's forward: y1 recomputed from x (conv_recomp.h)
+  ThinFold fold;         // convt7's training forward: weight-gradient partials + BatchNorm-backward sums from the same launch
 };
 
 struct WgradArgs {

@@ -182,6 +182,7 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
                    ava_stream_t s) {
   ConvArgs a;
   a.rc = acc != nullptr ? acc->rc : RecompArgs{};
+  a.fold = acc != nullptr ? acc->fold : ThinFold{};
   a.act_bf16 = act_bf16;
   a.acc_out = acc != nullptr ? acc->acc_out : nullptr;
   if (acc != nullptr) a.fin = acc->fin;

@@ -704,11 +704,11 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
   constexpr int WG_PER_CU = FL::WG_PER_CU;
   static_assert(WG_PER_CU >= 1 && (lds + 1024) * WG_PER_CU <= 160 * 1024, "the resident workgroups' tile buffers must fit 160 KB of LDS");
   const void* kfn = reinterpret_cast<const void*>(&conv3x3_bwd_fused_limb_kernel<CI, CO, LMODE, DYPRO, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AVA_ELAUNCH;
-    attr_set = true;
-  }
+  // (the kernel also carries < 1 KB of static LDS -- accvals, ems: the same allowance as the static_assert above; one attempt
+  // per instantiation, thread-safe, its result remembered)
+  static const bool attr_ok = (lds + 1024 <= 64 * 1024) ||
+                              hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  if (!attr_ok) return AVA_ELAUNCH;
   FusedArgs b = a;
   const int hl = LMODE == MODE_DOWN ? a.Ho : a.Hi, wl = LMODE == MODE_DOWN ? a.Wo : a.Wi;   // low-resolution side
   if (hl % TH != 0 || wl % TW != 0) return AVA_EINVAL;

@@ -68,7 +68,12 @@ static int thin_fused_grid_w(int nt, int Cin) {
     static const int cap1 = [] {
       const char* e = ava_env("AVA_THIN_GRID1");
       if (e && atoi(e) >= 8) return atoi(e);
-      if (AVA_THIN_RECY) return thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD, float, true>, W, 0);   // 238 VGPRs: two 256-thread workgroups per CU
+      if (AVA_THIN_RECY) {   // 238 VGPRs: two 256-thread workgroups per CU.  The grid is also the partial-row count, so it must not
+                             // depend on the activation type: the smaller residency of the two instantiations serves both
+        const int rf = thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD, float, true>, W, 0);
+        const int rb = thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD, ava_bf16, true>, W, 0);
+        return rf < rb ? rf : rb;
+      }
       if (W == 128) return 768;
       return thin_resident(&thin_bwd_fused_1to8_kernel<W, PRO_BWD>, W, 0);
     }();
@@ -226,7 +231,15 @@ static int conv3x3_thin_w(const ConvArgs& a0, int grid, int Cin, int Cout, int p
       if (g > ava_scale_grid(512)) g = ava_scale_grid(512);                               // in-step A/B: 512 / 768 / 1023 workgroups -> 34.1 / 34.7 / 37.0 us
       { const char* e = ava_env("AVA_THIN_FWD_GRID"); if (e && atoi(e) >= 8 && atoi(e) < a.part_rows) g = atoi(e); }
       if (g > a.ntiles) g = a.ntiles;
-      if (a.act_bf16) hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE, ava_bf16>), dim3(g), block, 0, st, a);
+      if (a.fold.wg_partials != nullptr) {
+        // the training forward that also leaves convt7's weight-gradient partials and BatchNorm-backward sums behind (FOLD)
+        if (a.epi_x == nullptr || a.out2 == nullptr || (a.fin.acc == nullptr && (a.fold.mean == nullptr || a.fold.invstd == nullptr)) ||
+            (a.fold.acc_out == nullptr && a.fold.bn_partials == nullptr))
+          return AVA_EINVAL;
+        if (a.act_bf16) hipLaunchKernelGGL((thin_8to1_direct_fold_kernel<W, ava_bf16>), dim3(g), block, 0, st, a);
+        else hipLaunchKernelGGL((thin_8to1_direct_fold_kernel<W, float>), dim3(g), block, 0, st, a);
+      }
+      else if (a.act_bf16) hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE, ava_bf16>), dim3(g), block, 0, st, a);
       else hipLaunchKernelGGL((thin_8to1_direct_kernel<W, PRO_BN, EPI_SSE>), dim3(g), block, 0, st, a);
     }
     else if (a.act_bf16) return AVA_EINVAL;

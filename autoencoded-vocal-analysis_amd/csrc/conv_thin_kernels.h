@@ -466,27 +466,59 @@ __global__ __launch_bounds__(NS + 256) void thin_8to1_ws_kernel(const ConvArgs a
 //   y[r][x] = bias + sum_h sum_kx u_h[r][kx] at column x + kx - 1.
 // No staging role, three workgroups per CU resident, ten independent 16-byte loads per thread in flight; the
 // LDS-staged wave-specialised form kept one 41.6 KB window per workgroup in flight.
-template <int W, int PRO, int EPI, typename ACT = float>
-__global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs a) {
-  static_assert(PRO == PRO_BN && EPI == EPI_SSE, "only convt7's forward uses this form");
+// FOLD (convt7's TRAINING forward, a.fold): the same launch also leaves behind what convt7's backward needs besides the data
+// gradient -- the weight / bias gradient partials and the BatchNorm-backward sums of the layer input (reference: autograd's
+// convolution backward behind loss.backward(), ava/models/vae.py:352).  Both are correlations of the input windows with the
+// seed dU = prec * (xhat - x), and the thread that owns an input pixel column has its ten input rows in registers the moment
+// the tile's seed exists; the seed takes one more trip through a 4 KB LDS tile (zero border columns):
+//     dG'[ky][kx][c] += xhat0[r + ky][c] (own column x) * dU[r][x - kx + 1]          r = 0..7: the tile's own output rows
+// (xhat0 = (v - mean) * invstd, zero outside the image), indexed by the OUTPUT pixel, so no seed row of another tile is needed.
+// The rest is thin_wgrad_stats_8to1_direct_kernel's algebra (S[tap] from the nine border sums of dU; dG = gamma dG' + beta S;
+// sum dx = sum_tap G S, sum dx xhat = sum_tap G dG').  That kernel -- a 34 us launch that re-read the 134 MB input and the seed
+// -- is gone from the training step; 144 more packed FMAs per thread and tile in a kernel whose VALU was idle.  The partials
+// are those of loss scale 1: a backward with another scale runs the separate kernel (model.hip).
+template <int W, typename ACT, bool FOLD>
+__device__ __forceinline__ void thin_8to1_direct_body(const ConvArgs& a) {
   __shared__ float U[2][3][THIN_TH][THIN_IC];           // [half][kx][row][column + 1]; columns 0 and 129 stay zero
   __shared__ float red[THIN_NW][2];
+  __shared__ float coef[96];
+  __shared__ double accvals[64];
+  __shared__ float ems[64];                             // FOLD: mean [0..31], invstd [32..63] of the input's BatchNorm
+  __shared__ float dUt[FOLD ? THIN_TH * THIN_IC : 1];   // FOLD: the tile's seed, [row][column + 1], zero border columns
+  __shared__ float fred[FOLD ? THIN_NW : 1][2][36];     // FOLD: per wave, per channel half: dG' [9][4]
+  __shared__ float fsc[FOLD ? THIN_NW : 1][9];          // per wave: T, Rt, Rb, Cl, Cr, Ktl, Ktr, Kbl, Kbr
+  __shared__ float ftot[FOLD ? 2 : 1][36];
+  __shared__ float fstot[9];
+  __shared__ float fscratch[FOLD ? 2 : 1][72];
   const int t = threadIdx.x, h = t & 1, x = t >> 1, lane = t & 63, wave = t >> 6;
   if (t < 2 * 3 * THIN_TH) {                            // zero borders, once
     float* row = &U[0][0][0][0] + t * THIN_IC;
     row[0] = 0.f;
     row[THIN_IC - 1] = 0.f;
   }
+  if constexpr (FOLD) {
+    if (t < THIN_TH) { dUt[t * THIN_IC] = 0.f; dUt[t * THIN_IC + THIN_IC - 1] = 0.f; }
+  }
   float ca[4], cb[4];
   if (a.fin.acc != nullptr) {               // BatchNorm of the input: sums accumulated by the producer (bn_acc.h), finalised here
-    __shared__ float coef[96];
-    __shared__ double accvals[64];
-    bn_coef_from_acc(coef, accvals, a.fin, 0);
+    bn_coef_from_acc(coef, accvals, a.fin, 0, FOLD ? ems : nullptr);
 #pragma unroll
     for (int c = 0; c < 4; ++c) { ca[c] = coef[4 * h + c]; cb[c] = coef[32 + 4 * h + c]; }
   } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { ca[c] = a.pa[4 * h + c]; cb[c] = a.pb[4 * h + c]; }
+    if (FOLD) {
+      if (t < 64) { const int c = t & 31; ems[t] = c < 8 ? (t < 32 ? a.fold.mean[c] : a.fold.invstd[c]) : 0.f; }
+      if (t < 16) coef[(t >> 3) * 32 + (t & 7)] = t < 8 ? a.pa[t] : a.pb[t & 7];
+      __syncthreads();
+    }
+  }
+  float ha[4], hb[4];                                   // FOLD: xhat = ha * v + hb for this half's channels
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float is = FOLD ? ems[32 + 4 * h + c] : 0.f;
+    ha[c] = is;
+    hb[c] = FOLD ? -ems[4 * h + c] * is : 0.f;
   }
   avaf2 w2[9][2];                                       // [tap][channel pair of this half], G is [9][8][1]
 #pragma unroll
@@ -500,6 +532,11 @@ __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs 
   const float bias0 = a.bias[0];
   const int xo = t % W, r0 = (t / W) * 4;            // phase 2: output pixels (r0 + p, xo)
   float s1 = 0.f;
+  avaf2 facc[FOLD ? 9 : 1][2];
+#pragma unroll
+  for (int k = 0; k < (FOLD ? 9 : 1); ++k) facc[k][0] = facc[k][1] = avaf2{0.f, 0.f};
+  float T = 0.f, Rt = 0.f, Rb = 0.f, Cl = 0.f, Cr = 0.f, Ktl = 0.f, Ktr = 0.f, Kbl = 0.f, Kbr = 0.f;
+  const float own = h == 0 ? 1.f : 0.f;                 // the scalar sums of dU are taken by one lane of each pair
   const int tiles_y = a.Ho / THIN_TH;
   for (TileWalk walk(a.ntiles); walk.valid(); walk.advance()) {
     const int tl = walk.cur;
@@ -507,6 +544,7 @@ __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs 
     // ---- phase 1: own pixel column, 10 rows ----
     const ACT* __restrict__ xin = ava_as<ACT>(a.in) + ((size_t)b * a.Hi * W + x) * 8 + 4 * h;
     avaf2 xn[THIN_IR][2];
+    avaf2 xh[FOLD ? THIN_IR : 1][2];
 #pragma unroll
     for (int j = 0; j < THIN_IR; ++j) {
       const int gy = oy0 - 1 + j;
@@ -514,6 +552,10 @@ __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs 
       const avaf4 v = ava_ld4<ACT>(xin + (size_t)min(max(gy, 0), a.Hi - 1) * W * 8);
       xn[j][0] = ok ? avaf2{fmaf(ca[0], v[0], cb[0]), fmaf(ca[1], v[1], cb[1])} : avaf2{0.f, 0.f};
       xn[j][1] = ok ? avaf2{fmaf(ca[2], v[2], cb[2]), fmaf(ca[3], v[3], cb[3])} : avaf2{0.f, 0.f};
+      if constexpr (FOLD) {
+        xh[j][0] = ok ? avaf2{fmaf(ha[0], v[0], hb[0]), fmaf(ha[1], v[1], hb[1])} : avaf2{0.f, 0.f};
+        xh[j][1] = ok ? avaf2{fmaf(ha[2], v[2], hb[2]), fmaf(ha[3], v[3], hb[3])} : avaf2{0.f, 0.f};
+      }
     }
     const size_t opix0 = ((size_t)b * a.Ho + oy0 + r0) * W + xo;
     float ex[4] = {0.f, 0.f, 0.f, 0.f};                 // epilogue operand of this thread's output pixels
@@ -533,7 +575,7 @@ __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs 
           for (int q = 0; q < 2; ++q) sacc = __builtin_elementwise_fma(xn[r + ky][q], w2[ky * 3 + kx][q], sacc);
         u[r][kx] = sacc[0] + sacc[1];
       }
-    __syncthreads();                                    // the previous tile's phase 2 has read U
+    __syncthreads();                                    // the previous tile's phase 2 has read U (FOLD: its phase 3 has read dUt)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -548,18 +590,122 @@ __global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs 
       const size_t opix = opix0 + (size_t)p * W;
       if (a.epi_x != nullptr) {
         const float r = v - ex[p];
-        a.out2[opix] = a.prec * r;
+        const float sd = a.prec * r;
+        a.out2[opix] = sd;
+        if constexpr (FOLD) dUt[(r0 + p) * THIN_IC + xo + 1] = sd;
         s1 = fmaf(r, r, s1);
       }
       if (a.out != nullptr) a.out[opix] = v;
     }
+    if constexpr (FOLD) {
+      // ---- phase 3: correlations of the own input column with the tile's seed ----
+      __syncthreads();
+      {
+        float col = 0.f;
+#pragma unroll
+        for (int r = 0; r < THIN_TH; ++r) col += dUt[r * THIN_IC + x + 1];
+        const float top = oy0 == 0 ? dUt[x + 1] : 0.f;
+        const float bot = oy0 + THIN_TH == a.Ho ? dUt[(THIN_TH - 1) * THIN_IC + x + 1] : 0.f;
+        T += own * col;
+        Rt += own * top;
+        Rb += own * bot;
+        if (x == 0) { Cl += own * col; Ktl += own * top; Kbl += own * bot; }
+        if (x == W - 1) { Cr += own * col; Ktr += own * top; Kbr += own * bot; }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float d[THIN_TH];
+#pragma unroll
+        for (int r = 0; r < THIN_TH; ++r) d[r] = dUt[r * THIN_IC + x + 2 - kx];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int r = 0; r < THIN_TH; ++r) {
+            const avaf2 dv = {d[r], d[r]};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) facc[ky * 3 + kx][q] = __builtin_elementwise_fma(xh[r + ky][q], dv, facc[ky * 3 + kx][q]);
+          }
+      }
+    }
   }
   const float r1 = wave_sum(s1);
   if (lane == 0) { red[wave][0] = r1; red[wave][1] = 0.f; }
+  if constexpr (FOLD) {
+    // ---- workgroup totals: dG' per channel half over lanes of equal parity, the nine scalar sums over all lanes ----
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float v = facc[k][q][e];
+#pragma unroll
+          for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+          if (lane < 2) fred[wave][lane][k * 4 + 2 * q + e] = v;
+        }
+    const float sv[9] = {T, Rt, Rb, Cl, Cr, Ktl, Ktr, Kbl, Kbr};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float r = wave_sum(sv[i]);
+      if (lane == 0) fsc[wave][i] = r;
+    }
+  }
   __syncthreads();
   if (t < 2 && a.partials != nullptr)
     a.partials[(size_t)blockIdx.x * 2 + t] = thin_sum_waves<THIN_NW>([&](int w) { return red[w][t]; });
   thin_zero_rows<2>(a.partials, a.part_rows);
+  if constexpr (FOLD) {
+    if (t < 72) {
+      const int hh = t / 36, i = t - 36 * hh;
+      ftot[hh][i] = thin_sum_waves<THIN_NW>([&](int w) { return fred[w][hh][i]; });
+    } else if (t < 81) {
+      const int i = t - 72;
+      fstot[i] = thin_sum_waves<THIN_NW>([&](int w) { return fsc[w][i]; });
+    }
+    __syncthreads();
+    if (t < 72) {
+      const int tap = t >> 3, ci = t & 7, hh = ci >> 2, c = ci & 3, ky = tap / 3, kx = tap - 3 * ky;
+      float S = fstot[0];
+      if (ky == 0) S -= fstot[1];
+      if (ky == 2) S -= fstot[2];
+      if (kx == 0) S -= fstot[3];
+      if (kx == 2) S -= fstot[4];
+      if (ky == 0 && kx == 0) S += fstot[5];
+      if (ky == 0 && kx == 2) S += fstot[6];
+      if (ky == 2 && kx == 0) S += fstot[7];
+      if (ky == 2 && kx == 2) S += fstot[8];
+      const float xa = coef[ci], xb = coef[32 + ci], mean = ems[ci], invstd = ems[32 + ci];
+      const float gamma = xa / invstd, beta = fmaf(mean, xa, xb);
+      const float dgp = ftot[hh][tap * 4 + c];
+      a.fold.wg_partials[(size_t)blockIdx.x * 73 + t] = fmaf(gamma, dgp, beta * S);
+      const float w = a.G[tap * 8 + ci];                // forward gather weight G[tap][ci]
+      fscratch[0][t] = w * S;
+      fscratch[1][t] = w * dgp;
+    } else if (t == 72) {
+      a.fold.wg_partials[(size_t)blockIdx.x * 73 + 72] = fstot[0];                    // bias gradient = T
+    }
+    __syncthreads();
+    if (t < 16) {
+      const int which = t >> 3, ci = t & 7;
+      float s = 0.f;
+      for (int tap = 0; tap < 9; ++tap) s += fscratch[which][tap * 8 + ci];
+      if (a.fold.acc_out != nullptr) bn_acc_add(a.fold.acc_out, which * 32 + ci, s);     // accumulated for the consumer's prologue
+      else a.fold.bn_partials[(size_t)blockIdx.x * 16 + t] = s;
+    }
+    thin_zero_rows<73>(a.fold.wg_partials, a.part_rows);
+    if (a.fold.acc_out == nullptr) thin_zero_rows<16>(a.fold.bn_partials, a.part_rows);
+  }
+}
+
+template <int W, int PRO, int EPI, typename ACT = float>
+__global__ __launch_bounds__(2 * W) void thin_8to1_direct_kernel(const ConvArgs a) {
+  static_assert(PRO == PRO_BN && EPI == EPI_SSE, "only convt7's forward uses this form");
+  thin_8to1_direct_body<W, ACT, false>(a);
+}
+// the launch is two workgroups per CU at W = 128, one at W = 256 (conv_thin.hip): 256 VGPRs are there to use
+template <int W, typename ACT = float>
+__global__ __launch_bounds__(2 * W, 2) void thin_8to1_direct_fold_kernel(const ConvArgs a) {
+  thin_8to1_direct_body<W, ACT, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -195,6 +195,9 @@ struct ava_model {
   int last_train;           // BatchNorm mode of that forward: backward uses the matching BatchNorm derivative
   int* status_last;         // status word of that forward (ava_adam_step skips the update when it is set)
   const float* bwd_scale;   // device scalar d(result)/d(loss) for the next backward (ava_set_backward_scale); null = 1
+  int fold13;               // the last forward left convt7's weight-gradient partials (wg13_rows rows of wg_part[13]) and the
+                            // BatchNorm-backward sums of its input behind (conv_thin_kernels.h: FOLD), for loss scale 1
+  int wg13_rows;            // rows of wg_part[13] the weight-gradient reduction has to sum
   Prof prof;
   std::map<std::string, std::pair<const float*, int64_t>> dbg;
 };
@@ -255,6 +258,10 @@ static size_t wgrad_part_floats(const ava_model* m, int B, int l) {
   int grid = ava_conv_wgrad_grid(B, D.ho, D.wo, L.mode);
   const int fg = ava_conv_fused_grid_for(B, D.hi, D.wi, L.cin, L.cout, L.mode);     // fused backward kernel's rows
   if (fg > grid) grid = fg;
+  if (l == NCONV - 1) {            // convt7: its training forward writes the partial rows (one per row of its SSE partials)
+    const int fw = ava_conv_grid(B, D.ho, D.wo, L.mode);
+    if (fw > grid) grid = fw;
+  }
   return (size_t)grid * (9 * L.cin * L.cout + L.cout);
 }
 
@@ -425,6 +432,8 @@ extern "C" int ava_model_create_ex(ava_model** out, int z_dim, int H, int W, int
   m->status_last = nullptr;
   m->bwd_scale = nullptr;
   m->sse_parts = 0;
+  m->fold13 = 0;
+  m->wg13_rows = 0;
   const size_t B = max_batch;
   const int64_t F = m->F, XD = (int64_t)H * W;
   for (int l = 1; l < NCONV; ++l) {
@@ -892,8 +901,18 @@ static int encoder_forward(ava_model* m, const float* x, int B, int train, float
 }
 
 // from_fc7: h6 already exists (the fused middle wrote it)
+static bool dd6_fused(const ava_model* m);
+static bool acc_pair_bwd(const ava_model* m, int j);
+// convt7's TRAINING forward also forms its weight-gradient partials and the BatchNorm-backward sums of its input
+// (conv_thin_kernels.h: FOLD).  Lab build: AVA_FOLD13=0 keeps the separate kernel in the backward.
+static bool fold13_on(const ava_model* m) {
+  static const bool on = [] { const char* e = ava_env("AVA_FOLD13"); return e == nullptr || atoi(e) != 0; }();
+  return on && m->G != nullptr && acc_pair_bwd(m, 13) && m->lay[13].hi % 8 == 0;
+}
+
+// `fold`: the caller is a training forward a backward may follow (forward_impl)
 static int decoder_forward(ava_model* m, const float* zin, const float* x_target, int B, int train, float* xrec,
-                           hipStream_t st, bool from_fc7 = false) {
+                           hipStream_t st, bool from_fc7 = false, bool fold = false) {
   const int z = m->z;
   if (!from_fc7) {
     TRY(gemm(m, zin, 0, PP(m, FC5), 0, PP(m, FC5 + 1), m->h5, 0, nullptr, nullptr, B, 64, z, 1, 1, ACT_RELU, st));
@@ -923,6 +942,13 @@ static int decoder_forward(ava_model* m, const float* zin, const float* x_target
     ConvAcc acc;
     acc.fin = (train && acc_pair_fwd(m, l)) ? fin_fwd(m, l, B) : fin_none();
     acc.acc_out = (train && !last && acc_pair_fwd(m, l + 1)) ? acc_slot(m, l + 1) : nullptr;
+    if (last && fold && train && x_target != nullptr && fold13_on(m)) {
+      acc.fold.wg_partials = m->wg_part[l];
+      acc.fold.acc_out = acc_slot(m, 14 + l);
+      acc.fold.mean = bn_mean(m, l); acc.fold.invstd = bn_invstd(m, l);
+      m->fold13 = 1;
+      m->wg13_rows = ava_conv_grid(B, D.ho, D.wo, L.mode);
+    }
     TRY(ava_conv3x3_ex(m->X[l], nullptr, bn_scale(m, l), bn_shift(m, l), nullptr, m->Gf[l], PP(m, L.pb), out,
                        last ? m->seed : nullptr, last ? x_target : nullptr, nullptr, nullptr, m->bn_part, B, D.hi, D.wi,
                        L.cin, L.cout, L.mode, PRO_BN, last ? EPI_SSE : EPI_FWD, 1, m->prec, m->act_bf16, &acc,
@@ -963,7 +989,8 @@ static int forward_impl(ava_model* m, const float* x, int B, const float* eps_w,
   m->eps_w_last = eps_w;          // backward reads the same noise: the caller keeps it alive until then
   m->eps_d_last = eps_d;
   mark(m, CAT_LATENT_LOSS, st);
-  TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st, mid));
+  m->fold13 = 0;
+  TRY(decoder_forward(m, m->zs, x, B, bn_train, m->xrec, st, mid, true));
   TRY(ava_elbo_finalize_strided(m->lat_sums, B, m->bn_part, m->sse_parts, 2, z, m->prec, m->H * m->W,
                                 loss_out != nullptr ? loss_out : m->loss_dev, loss_accum, st));
   mark(m, CAT_LATENT_LOSS, st);
@@ -995,6 +1022,7 @@ extern "C" int ava_encode(ava_model* m, const float* x, int B, int bn_train, flo
   const ReserveScope rs(m);
   hipStream_t st = to_stream(s);
   m->lastB = 0;                       // the saved activations of the last ava_forward are overwritten
+  m->fold13 = 0;
   TRY(pack_weights(m, false, st));
   return encoder_forward(m, x, B, bn_train, mu, u, d, ACT_EXP, st);
 }
@@ -1004,6 +1032,7 @@ extern "C" int ava_decode(ava_model* m, const float* z, int B, int bn_train, flo
   const ReserveScope rs(m);
   hipStream_t st = to_stream(s);
   m->lastB = 0;
+  m->fold13 = 0;
   TRY(pack_weights(m, false, st));
   if (!bn_train) TRY(bn_eval_all(m, st));
   return decoder_forward(m, z, nullptr, B, bn_train, x_rec, st);
@@ -1037,6 +1066,18 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   const float* X = l == 0 ? x0 : m->X[l];
   // layers with a fused kernel: data gradient, BatchNorm-backward sums and weight/bias partials from one pass
   const int fgrid = fused_grid(m, l, B);
+  if (l == 13) {
+    // convt7: the training forward has already left this layer's weight-gradient partials and BatchNorm-backward sums behind
+    // (FOLD) and convt6's kernel forms its data gradient itself -- nothing to launch.  They are those of loss scale 1: with
+    // another scale (ava_set_backward_scale) the layer's accumulator slot is cleared and the separate kernel runs on the
+    // scaled seed, as it does after a forward that did not fold.
+    if (m->fold13 && m->bwd_scale == nullptr && dd6_fused(m)) return AVA_OK;
+    if (m->fold13) {
+      if (hipMemsetAsync(acc_slot(m, 14 + l), 0, (size_t)AVA_ACC_SLOT_LL * sizeof(long long), st) != hipSuccess) return AVA_ELAUNCH;
+      m->fold13 = 0;
+    }
+    m->wg13_rows = fgrid;
+  }
   if (fgrid > 0 && (gout != nullptr || l == 0)) {
     FusedArgs a = {};
     a.x = X; a.xa = bn_scale(m, l); a.xb = bn_shift(m, l);
@@ -1097,7 +1138,7 @@ static int reduce_wgrads(ava_model* m, int l0, int l1, int B, hipStream_t st) {
     tab.e[n].partials = m->wg_part[l];
     tab.e[n].dw = GG(m, L.pw);
     tab.e[n].dbias = GG(m, L.pb);
-    const int fg = fused_grid(m, l, B);
+    const int fg = l == 13 && m->wg13_rows > 0 ? m->wg13_rows : fused_grid(m, l, B);
     tab.e[n].nparts = fg > 0 ? fg : ava_conv_wgrad_rows_ex(B, m->lay[l].hi, m->lay[l].wi, L.cin, L.cout, L.mode, l == 13 || l == 6 ? PRO_ID : PRO_BWD, m->act_bf16);
     tab.e[n].cin = L.cin; tab.e[n].cout = L.cout;
     tab.e[n].kind = !L.transposed ? 0 : (L.mode == MODE_S1 ? 1 : 2);

@@ -47,7 +47,11 @@ def apply_cu_reserve(lib, handle, collectives_in_flight=True):
     """Size the persistent grids of the model ``handle`` for the kernels about to be launched (the C entry points read the
     model's setting once, at their start).  The reservation is only worth its price while a collective IS in flight:
     ``VAE._backward_kernels`` applies it to the backward parts that run beside the gradient buckets' all-reduces (parts 1..3)
-    and launches everything else -- the forward, backward part 0 -- on grids sized for the whole chip.  No-op in a
+    and launches everything else -- the forward, backward part 0 -- on grids sized for the whole chip.  The per-bucket Adam
+    launches that ``FlatAdam.step`` issues while later buckets are still on the wire are deliberately NOT covered: the
+    reserve exists for launches that are ONE resident wave over a static tile partition (a workgroup that finds no slot
+    becomes a second wave), whereas ``adam_flat_kernel`` is a grid-stride launch of 4096 small blocks that simply fill
+    the slots a collective leaves free (``bench.py`` says so under ``dist.cu_reserve_applies_to``).  No-op in a
     single-process run and with the default reserve of 0."""
     if handle is None or not active():
         return 0

@@ -48,6 +48,8 @@ class FlatAdam(torch.optim.Adam):
         with no gradient since the last ``zero_grad()`` does nothing -- exactly what ``torch.optim.Adam`` does with
         ``p.grad is None`` parameters.  ``p.grad`` itself keeps pointing at its arena view (stale values until the
         next backward) instead of becoming ``None``; with ``set_to_none=False`` the arena is zeroed."""
+        if getattr(self._model, "_pending_comm", None):
+            self._model._finish_comm()          # a deferred all-reduce nobody consumed must not land in a cleared arena
         self._model._grad_state = "none"
         if not set_to_none:
             self._model._grads.zero_()

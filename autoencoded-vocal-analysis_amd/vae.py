@@ -458,7 +458,7 @@ class VAE(nn.Module):
         # vae.py:312, and never reaches ``optimizer.step()``).  What is NOT rolled back: the forwards that ran in the
         # meantime (at most the polling lag, two steps) have moved the BatchNorm running statistics.
         skipped = int(self._status[1].item())
-        if _dist.active():
+        if self._handle is not None and _dist.active():
             skipped //= len(self._buckets())         # data parallel: one guarded launch per bucket (slice) and step
         opt = getattr(self, "optimizer", None)
         if opt is not None and skipped > 0:

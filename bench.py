@@ -383,7 +383,8 @@ def main():
                  "buckets": _lib.load().ava_backward_num_parts() if world > 1 else 0,
                  # CUs every persistent grid leaves free for the collective's workgroups (dist.cu_reserve); sharded optimizer?
                  "cu_reserve": adist.cu_reserve() if world > 1 else 0, "reserve_sweep": reserve_sweep,
-                 "cu_reserve_applies_to": "backward parts 1..3 (beside the bucket all-reduces)" if world > 1 else None,
+                 "cu_reserve_applies_to": ("backward parts 1..3 (beside the bucket all-reduces); NOT the per-bucket Adam launches: "
+                                           "grid-stride blocks without a static tile partition, they fill whatever slots are free") if world > 1 else None,
                  "adam": "per bucket, each behind its own all-reduce" if world > 1 else "one flat launch",
                  "sharded_adam": bool(model._sharded_adam()) if world > 1 else False}
     if world > 1:

@@ -119,8 +119,10 @@ int ava_grad_bucket(ava_model* m, int bucket, int64_t* offset, int64_t* count);
  * usec microseconds (<= 20 ms): a stand-in for such a collective in tests. */
 int ava_set_cu_reserve(int cus);
 int ava_get_cu_reserve(void);
-/* The same per model: the grids of THIS model's entry points (forward, backward parts, Adam, encode, decode) are sized for
- * (256 - cus) CUs from the next call on; -1 (the default) follows the process-wide setting.  Each entry point reads the
+/* The same per model: the persistent grids of THIS model's entry points (forward, backward parts, encode, decode) are sized
+ * for (256 - cus) CUs from the next call on; -1 (the default) follows the process-wide setting.  Adam is not affected: its
+ * kernel is a grid-stride launch of small blocks with no static tile partition, which fills whatever wave slots a collective
+ * leaves free and needs no co-residency.  Each entry point reads the
  * value once, at its start, so launches that hand partial rows to each other inside one call always agree on the grid. */
 int ava_model_set_cu_reserve(ava_model* m, int cus);
 int ava_model_get_cu_reserve(const ava_model* m);

@@ -581,7 +581,8 @@ class VAE(nn.Module):
         self._check_status()
         train_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, batch_idx + 1, self.x_dim)
         train_loss /= _dist.global_dataset_len(len(train_loader.dataset))
-        print('Epoch: {} Average loss: {:.4f}'.format(self.epoch, train_loss))
+        if _dist.rank() == 0:
+            print('Epoch: {} Average loss: {:.4f}'.format(self.epoch, train_loss))
         self.epoch += 1
         return train_loss
 
@@ -589,22 +590,32 @@ class VAE(nn.Module):
         """Mean -ELBO per sample with BatchNorm on running statistics (vae.py:361-385)."""
         self.eval()
         self._loss_acc.zero_()
+        i = -1
         with torch.no_grad():
             for i, data in enumerate(self._feed(test_loader)):
                 data = self._prep_x(data)
                 self._forward_device(data, need_grad=False, accumulate=True)
         self._check_status()
-        test_loss = float(self._loss_acc.item()) / len(test_loader.dataset)
-        print('Test loss: {:.4f}'.format(test_loss))
+        # data parallel: every rank iterates its own shard; the value returned is that of the GLOBAL test set on every rank,
+        # like train_epoch's (eval mode has no per-rank BatchNorm statistics, so it equals the single-process value on the
+        # concatenated data up to summation order).  Single process: the reference's expression unchanged.
+        test_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, i + 1, self.x_dim)
+        test_loss /= _dist.global_dataset_len(len(test_loader.dataset))
+        if _dist.rank() == 0:
+            print('Test loss: {:.4f}'.format(test_loss))
         return test_loss
 
     def train_loop(self, loaders, epochs=100, test_freq=2, save_freq=10, vis_freq=1):
         """Epoch scheduler (vae.py:388-430)."""
-        print("=" * 40)
-        print("Training: epochs", self.epoch, "to", self.epoch + epochs - 1)
-        print("Training set:", len(loaders['train'].dataset))
-        print("Test set:", len(loaders['test'].dataset))
-        print("=" * 40)
+        if _dist.rank() == 0:               # data parallel: one banner, one PDF (rank 0's shard); single process: as the reference
+            print("=" * 40)
+            print("Training: epochs", self.epoch, "to", self.epoch + epochs - 1)
+            print("Training set:", _dist.global_dataset_len(len(loaders['train'].dataset)) if _dist.active() else len(loaders['train'].dataset))
+            print("Test set:", _dist.global_dataset_len(len(loaders['test'].dataset)) if _dist.active() else len(loaders['test'].dataset))
+            print("=" * 40)
+        elif _dist.active():                # (the two dataset lengths are collectives: every rank enters them)
+            _dist.global_dataset_len(len(loaders['train'].dataset))
+            _dist.global_dataset_len(len(loaders['test'].dataset))
         for epoch in range(self.epoch, self.epoch + epochs):
             loss = self.train_epoch(loaders['train'])
             self.loss['train'][epoch] = loss
@@ -617,7 +628,7 @@ class VAE(nn.Module):
                 if _dist.rank() == 0:
                     self.save_state(filename)
             if (vis_freq is not None) and (epoch % vis_freq == 0):
-                self.visualize(loaders['test'])
+                self.visualize(loaders['test'])         # data parallel: every rank runs the forward, rank 0 writes the PDF
 
     def save_state(self, filename):
         """Checkpoint with the reference's dict layout (vae.py:433-446)."""
@@ -657,7 +668,8 @@ class VAE(nn.Module):
         specs = specs.detach().cpu().numpy()
         all_specs = np.stack([specs, rec_specs])
         save_filename = os.path.join(self.save_dir, save_filename)
-        grid_plot(all_specs, gap=gap, filename=save_filename)
+        if _dist.rank() == 0:       # data parallel: forward() above holds a collective (the status word's MAX), so every rank
+            grid_plot(all_specs, gap=gap, filename=save_filename)     # calls visualize; only rank 0 writes the one PDF
         return specs, rec_specs
 
     def get_latent(self, loader, bn_mode=None):

@@ -268,6 +268,62 @@ def test_per_bucket_adam_behind_its_own_allreduce_equals_flat_adam():
     assert res[0][2] == res[1][2]
 
 
+def _test_epoch_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    from torch.utils.data import DataLoader, Subset
+    from ava_amd import dist as adist, synthetic as syn
+    from gpu_util import build_model
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z, B, n = 32, 4, 24
+        ds = syn.SyntheticSpecDataset(n, 2002)
+        model = build_model(z)
+        adist.broadcast_parameters(model)
+        # move the running statistics off their initial values first (train mode, per-rank batches), then make them
+        # identical again: eval mode must then be a pure function of the weights and the data
+        shard = DataLoader(Subset(ds, list(range(rank * n // 2, (rank + 1) * n // 2))), batch_size=B, shuffle=False)
+        model.train_epoch(shard)
+        td.broadcast(model._bn_running, src=0)
+        td.broadcast(model._bn_batches, src=0)
+        # test_epoch samples z like the reference (vae.py:313 inside forward): zero noise makes the loss a function of the data
+        model.noise_source = lambda b, zz: (np.zeros(b, np.float32), np.zeros((b, zz), np.float32))
+        got = model.test_epoch(shard)                       # this rank's half; returns the GLOBAL mean
+        torch.cuda.synchronize()
+        q.put((rank, got, model._params.cpu().numpy(), model._bn_running.cpu().numpy(), model._bn_batches.cpu().numpy()))
+    finally:
+        td.destroy_process_group()
+
+
+def test_test_epoch_is_global_under_data_parallelism(tmp_path):
+    """`test_epoch` under data parallelism returns the loss of the GLOBAL test set on every rank (it
+    used to divide the LOCAL sum by the local length), and -- eval mode has no per-rank BatchNorm statistics -- equals the
+    single-process value on the concatenated data up to summation order (reference: ava/models/vae.py:361-385)."""
+    res = _run_two(_test_epoch_worker, 39500)
+    (r0, l0, p0, bn0, nb0), (r1, l1, p1, bn1, nb1) = res
+    assert l0 == l1                                          # one all-reduced sum: the same number on both ranks
+    assert np.array_equal(p0, p1) and np.array_equal(bn0, bn1)
+    # the same weights and running statistics in ONE process over the concatenated data
+    from torch.utils.data import DataLoader
+    from ava_amd import synthetic as syn
+    from gpu_util import build_model
+    model = build_model(32)
+    with torch.no_grad():
+        model._params.copy_(torch.from_numpy(p0).cuda())
+        model._bn_running.copy_(torch.from_numpy(bn0).cuda())
+        model._bn_batches.copy_(torch.from_numpy(nb0).cuda())
+    # (global batch = the two ranks' batches of 4: the reference adds its per-call constants once per forward call,
+    # vae.py:316,318, and dist.global_loss counts one call per GLOBAL batch)
+    whole = DataLoader(syn.SyntheticSpecDataset(24, 2002), batch_size=8, shuffle=False)
+    model.noise_source = lambda b, zz: (np.zeros(b, np.float32), np.zeros((b, zz), np.float32))
+    want = model.test_epoch(whole)
+    assert abs(l0 - want) <= 1e-6 * abs(want), (l0, want)
+
+
 def _nccl_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

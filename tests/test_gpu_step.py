@@ -31,7 +31,7 @@ from oracle import vae_oracle as O
 # 5e-5: against the fp32 goldens the bound is therefore the goldens' own distance from fp64 -- 1e-4 at B=8 outside
 # conv1/bn1 (whose B=8 golden carries one ReLU flip: 9e-3), 1e-2 at B=64 (same values as tests/test_oracle_golden.py).
 FLIP_TOL = 2e-2
-GTOL = {8: 1e-4, 64: 1e-2}
+GTOL = {8: 1e-4}          # (B = 64: no gradient comparison against the flip-carrying golden any more, see the test)
 
 
 def _oracle_grads(fp, x, ew, ed, dtype):
@@ -140,7 +140,13 @@ def test_train_step_matches_reference_golden(B, z):
         assert rel(1.0 / bn_save[i - 1, 1, :c] ** 2 - 1e-5, G["s1.bn%d.var" % i]) < 1e-4
     loss.backward()
     named = dict(model.named_parameters())
-    for s in param_specs(z):
+    # Gradients, B = 64: this golden's gradients carry ReLU flips of the reference's own fp32
+    # evaluation (it is 1e-2 away from fp64), so a comparison against them could only be held to 1e-2 -- no evidence
+    # beyond what test_flip_free_reference_golden[64] (the REAL reference at B = 64, 1e-4 per tensor, nothing masked) and
+    # the mask-imposed fp64 suite assert.  The gradient / Adam-moment part therefore runs at B = 8 only; at B = 64 the
+    # forward quantities above, the running statistics and the size of the first Adam step below are what is checked.
+    check_grads = B == 8
+    for s in (param_specs(z) if check_grads else ()):
         g = named[s.name].grad.cpu().numpy().ravel()
         sens = s.layer in ("conv1", "bn1")
         tol = FLIP_TOL if sens else GTOL[B]
@@ -160,13 +166,14 @@ def test_train_step_matches_reference_golden(B, z):
     for s in param_specs(z):
         idx = sample_idx(s.numel, s.index)
         sens = s.layer in ("conv1", "bn1")
-        tol = FLIP_TOL if sens else GTOL[B]
+        tol = FLIP_TOL if sens else GTOL.get(B, 0.0)
         gs = float(G["s1.gradnorm.conv1.bias"]) if sens else 0.0
         m = st[s.index]["exp_avg"].cpu().numpy().ravel()
         v = st[s.index]["exp_avg_sq"].cpu().numpy().ravel()
-        np.testing.assert_allclose(m[idx], G["s1.exp_avg." + s.name], rtol=20 * tol, atol=tol * max(np.abs(m).max(), 0.1 * gs))
-        np.testing.assert_allclose(v[idx], G["s1.exp_avg_sq." + s.name], rtol=40 * tol,
-                                   atol=tol * max(np.abs(v).max(), 1e-3 * gs * gs))
+        if check_grads:
+            np.testing.assert_allclose(m[idx], G["s1.exp_avg." + s.name], rtol=20 * tol, atol=tol * max(np.abs(m).max(), 0.1 * gs))
+            np.testing.assert_allclose(v[idx], G["s1.exp_avg_sq." + s.name], rtol=40 * tol,
+                                       atol=tol * max(np.abs(v).max(), 1e-3 * gs * gs))
         pv = named[s.name].detach().cpu().numpy().ravel()
         # Adam's first step moves every entry by ~lr = 1e-3: most sampled entries must land on the reference's value
         # (a model Adam never touched fails this), the rest (gradient entries near zero whose sign a ReLU-mask flip
@@ -195,6 +202,10 @@ def test_three_steps_then_eval_matches_golden():
         assert rel(getattr(model, "bn%d" % i).running_var.cpu(), G["final.bn%d.running_var" % i]) < 1e-4
     model.eval()
     with torch.no_grad():
+        # behind three Adam steps: the first steps are sign-like (g / sqrt(g^2)), so rounding noise in near-zero gradient
+        # entries is an O(lr) parameter difference and two fp32 trajectories separate (tools/traj.py: 2e-5 at step 3 on the
+        # training loss, more on the eval loss, which also sees the running statistics of all three steps); the freshly
+        # built model below pins the eval-mode forward itself to 1e-5
         assert rel(float(model.forward(x).item()), G["eval.loss"]) < 1e-3
     fresh = build_model(z, train=False)
     fixed_noise(fresh, B, z)

@@ -1,5 +1,6 @@
 // Shared pieces of the VALU (conv.hip) and matrix-core (conv_mfma.hip) 3x3 gather convolutions.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "bn_fuse.h"
 #include "bn_acc.h"
@@ -170,6 +171,8 @@ struct TileStager {
   static constexpr int NV = R * C * Q;
   static constexpr int NPF = (NV + NT - 1) / NT;
   static_assert(NPF <= 32, "element masks are 32 bits wide");
+  // a BatchNorm prologue on a bfloat16-stored input: the layer computes in bf16 arithmetic (see value_one)
+  static constexpr bool BF16_MATH = PRO == PRO_BN && std::is_same<TIN, ava_bf16>::value;
   avaf4 v[NPF];
   avaf4 v2[PRO == PRO_BWD ? NPF : 1];
   int rc[NPF];          // (r << 16) | c of the owned window element (clamped duplicate for idle lanes)
@@ -255,7 +258,10 @@ struct TileStager {
     avaf4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float p = prologue<PRO>(x[e], y[e], k.a[e], k.b[e], k.c[e]);
+      float p = prologue<PRO>(x[e], y[e], k.a[e], k.b[e], k.c[e]);
+      // bf16 ARITHMETIC of the convolutions (act_dtype = bfloat16, BASELINE configs[4] "bf16 conv"): the BatchNorm output --
+      // the operand of the layer's products, forward and weight gradient -- is rounded to bfloat16 (nearest even)
+      if (BF16_MATH) p = ava_stored<ava_bf16>(p);
       o[e] = ok ? p : 0.f;
     }
     return o;
@@ -326,28 +332,39 @@ __device__ __forceinline__ void ava_limb_split2(float x, float y, uint32_t& p0, 
 // TileStager for the limb kernels: same loads, prologue and masks; the tile lands in LDS as three limb planes, each
 // [CIN / 8 channel octets][R * C pixels][8 channels] bf16 -- a pixel's octet is one 16-byte slot and the 16 pixels of a
 // matrix-core group are 256 contiguous bytes (conflict-free ds_read_b128 fragments).
+// NL: limb planes written.  3: fp32 values, split exactly.  1: the values are bfloat16 already (the rounded BatchNorm output of
+// the bf16-arithmetic mode, TileStager::BF16_MATH): one plane, no split.
+template <typename TIN, int PRO> constexpr int ava_stager_limbs() { return (PRO == PRO_BN && std::is_same<TIN, ava_bf16>::value) ? 1 : 3; }
 template <int CIN, int PRO, int R, int C, int NT = 256, typename TIN = float, typename TIN2 = float, int MAXQP = 4>
 struct TileStagerL : TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2, MAXQP> {
   using Base = TileStager<CIN, PRO, R, C, false, NT, TIN, TIN2, MAXQP>;
   static_assert(CIN % 8 == 0, "limb planes are made of channel octets");
+  static constexpr int NL = ava_stager_limbs<TIN, PRO>();
   static constexpr int NPIX = R * C, Q8 = CIN / 8;
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
-  static constexpr int TILE_BYTES = 3 * PLANE_BYTES;
+  static constexpr int TILE_BYTES = NL * PLANE_BYTES;
   using Coef = typename Base::Coef;
   using Coefs = typename Base::Coefs;
   __device__ __forceinline__ void store_one(int i, unsigned char* __restrict__ lds, const float* __restrict__ coef, const Coefs& kq) {
     const int idx = this->tid + NT * i;
     const avaf4 o = Base::SAMEQ ? this->value_one(i, kq.k[i % Base::NKQ]) : this->value_one(i, this->coef_of(i, coef));
-    ava_u32x2 p0, p1, p2;
-    uint32_t a, b, c;
-    ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
-    ava_limb_split2(o[2], o[3], a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
     const int q = idx % Base::Q, pix = idx / Base::Q;
     unsigned char* d = lds + ((q >> 1) * NPIX + pix) * 16 + (q & 1) * 8;
-    if ((this->live >> i) & 1u) {
-      *reinterpret_cast<ava_u32x2*>(d) = p0;
-      *reinterpret_cast<ava_u32x2*>(d + PLANE_BYTES) = p1;
-      *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
+    if constexpr (NL == 1) {
+      ava_u32x2 p0;                                    // exact: value_one has rounded the values to bfloat16
+      p0[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector((ava_f32x2v){o[0], o[1]}, ava_bf16x2v));
+      p0[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((ava_f32x2v){o[2], o[3]}, ava_bf16x2v));
+      if ((this->live >> i) & 1u) *reinterpret_cast<ava_u32x2*>(d) = p0;
+    } else {
+      ava_u32x2 p0, p1, p2;
+      uint32_t a, b, c;
+      ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
+      ava_limb_split2(o[2], o[3], a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
+      if ((this->live >> i) & 1u) {
+        *reinterpret_cast<ava_u32x2*>(d) = p0;
+        *reinterpret_cast<ava_u32x2*>(d + PLANE_BYTES) = p1;
+        *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
+      }
     }
   }
   __device__ __forceinline__ void store(unsigned char* __restrict__ lds, const float* __restrict__ coef) {

@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_bwd_fused_kernel(const Fuse
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC> f1;
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 2 : 0), DC> f2;
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 3 : 0), DC> f3;
-  f0.init(a.Gb, lane, SPB * n * CO);
-  if (BCLS > 1) { f1.init(a.Gb, lane, n * CO); f2.init(a.Gb, lane, n * CO); f3.init(a.Gb, lane, n * CO); }
+  constexpr bool BF16M = std::is_same<ACT, ava_bf16>::value;     // bf16 arithmetic: weights rounded to bfloat16
+  f0.init(a.Gb, lane, SPB * n * CO, 0, BF16M);
+  if (BCLS > 1) { f1.init(a.Gb, lane, n * CO, 0, BF16M); f2.init(a.Gb, lane, n * CO, 0, BF16M); f3.init(a.Gb, lane, n * CO, 0, BF16M); }
   const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
   const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
   float s1[MT][4], s2[MT][4];
@@ -449,8 +450,9 @@ __global__ __launch_bounds__(512, (CI * CO > 256 || (CI == 16 && CO == 16 && LMO
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 1 : 0), DC> f1;
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 2 : 0), DC> f2;
   ClassFrag<CO, CI, BMODE, (BCLS > 1 ? 3 : 0), DC> f3;
-  f0.init(a.Gb, lane, SPB * n * CO);
-  if (BCLS > 1) { f1.init(a.Gb, lane, n * CO); f2.init(a.Gb, lane, n * CO); f3.init(a.Gb, lane, n * CO); }
+  constexpr bool BF16M = std::is_same<ACT, ava_bf16>::value;     // bf16 arithmetic: weights rounded to bfloat16
+  f0.init(a.Gb, lane, SPB * n * CO, 0, BF16M);
+  if (BCLS > 1) { f1.init(a.Gb, lane, n * CO, 0, BF16M); f2.init(a.Gb, lane, n * CO, 0, BF16M); f3.init(a.Gb, lane, n * CO, 0, BF16M); }
   const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
   const int cq = PAIR ? 4 * (kg & 1) : 4 * kg;    // first dx channel of this lane inside its channel tile
   float s1[MT][4], s2[MT][4];

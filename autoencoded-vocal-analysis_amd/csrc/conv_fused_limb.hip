@@ -86,8 +86,12 @@ struct FLds {
   using FG = FGeomL<LMODE, TW, TH>;
   static constexpr int MT = (CI + 15) / 16;
   static constexpr bool PAIRL = LMODE == MODE_S1 && CI == 8 && TH % 2 == 0;
-  static constexpr int W2_ALL = LMODE == MODE_DOWN ? 0 : (((PAIRL ? 12 : 9) * (CO / 8) + 3) / 4) * 1024 * MT;   // the third-limb table
-  static constexpr size_t planes = (size_t)3 * 16 * ((CI / 8) * FG::XR * FG::XC + (CO / 8) * FG::DR * FG::DC);
+  // bf16 arithmetic (ACT = bfloat16): the layer input's planes hold the ROUNDED BatchNorm output -- one limb -- and the weights are
+  // rounded to bfloat16 (no third-limb table); the gradient dU keeps three limbs
+  static constexpr bool BF16M = std::is_same<ACT, ava_bf16>::value;
+  static constexpr int NLX = BF16M ? 1 : 3;
+  static constexpr int W2_ALL = (LMODE == MODE_DOWN || BF16M) ? 0 : (((PAIRL ? 12 : 9) * (CO / 8) + 3) / 4) * 1024 * MT;   // the third-limb table
+  static constexpr size_t planes = (size_t)16 * (NLX * (CI / 8) * FG::XR * FG::XC + 3 * (CO / 8) * FG::DR * FG::DC);
   static constexpr size_t raw = (size_t)FG::OH * FG::OW * CI * sizeof(float);
   static constexpr size_t rest = (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL;
   static constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
@@ -149,7 +153,11 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   constexpr int XPLANE = (CI / 8) * XNPIX * 16, DPLANE = (CO / 8) * DNPIX * 16;      // bytes
   using FL = FLds<CI, CO, LMODE, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>;
   constexpr bool RAWX = FL::RAWX;           // raw x of the dx region behind the planes of each tile buffer
-  constexpr int XBYTES = 3 * XPLANE, RAWOFF = XBYTES + 3 * DPLANE, BUF = (int)FL::buf;
+  // bf16 arithmetic: one limb of the (rounded) layer input and of the (rounded) weights; three of the gradient.  Both products
+  // are then three MFMAs instead of six, and they are the exact derivative of the forward that rounded the same operands
+  constexpr bool BF16M = FL::BF16M;
+  constexpr int NLX = FL::NLX, NLW = BF16M ? 1 : 3;
+  constexpr int XBYTES = NLX * XPLANE, RAWOFF = XBYTES + 3 * DPLANE, BUF = (int)FL::buf;
   static_assert(FL::planes == (size_t)RAWOFF, "kernel and launcher agree on the tile buffer");
   extern __shared__ __align__(16) unsigned char smem_b[];
   float* cx = reinterpret_cast<float*>(smem_b + 2 * BUF);     // [3][32]
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   float* red = cd + 96;                                        // [ND][32 * MT]: per data-gradient wave {sum g [16 MT], sum g x [16 MT]}
   // the data-gradient weights' third limb as an LDS table (ClassFragL: W2L) where one wave holds ALL of a class's chunks
   // (single-class gathers): the role then fits 128 VGPRs with room to spare
-  constexpr bool W2L = BCLS == 1 && (AVA_FL_W2L == 1 || (AVA_FL_W2L == 2 && !RAWX));
+  constexpr bool W2L = !BF16M && BCLS == 1 && (AVA_FL_W2L == 1 || (AVA_FL_W2L == 2 && !RAWX));
   constexpr int DKG = PAIR ? 12 * (CO / 8) : 9 * (CO / 8);     // k-groups of the (single) data-gradient class
   constexpr int W2_TILE = W2L ? ((DKG + 3) / 4) * 1024 : 0;    // bytes per dx channel tile
   constexpr int W2_ALL = W2_TILE * MT;
@@ -325,10 +333,10 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
       const int mtb = DSPLIT ? (dw & 1) : 0;                      // first dx channel tile of this wave
       const int dgi = CSPLIT ? 0 : (DSPLIT ? (dw >> 1) : dw);     // which share of the pixel groups
       constexpr int SPB = BMODE == MODE_DOWN ? 2 : 1;
-      typename std::conditional<PAIR, PairFragL<CO, DC, DNPIX, W2L>, ClassFragL<CO, CI, BMODE, (CSPLIT ? DCLS : 0), DC, DNPIX, MTD, W2L>>::type f0;
-      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 1 : 0), DC, DNPIX, MTD> f1;
-      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 2 : 0), DC, DNPIX, MTD> f2;
-      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 3 : 0), DC, DNPIX, MTD> f3;
+      typename std::conditional<PAIR, PairFragL<CO, DC, DNPIX, W2L, NLW, 3>, ClassFragL<CO, CI, BMODE, (CSPLIT ? DCLS : 0), DC, DNPIX, MTD, W2L, NLW, 3>>::type f0;
+      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 1 : 0), DC, DNPIX, MTD, false, NLW, 3> f1;
+      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 2 : 0), DC, DNPIX, MTD, false, NLW, 3> f2;
+      ClassFragL<CO, CI, BMODE, (BCLS > 1 && !CSPLIT ? 3 : 0), DC, DNPIX, MTD, false, NLW, 3> f3;
       f0.init(a.Gb, lane, SPB * n, mtb, w2tab + mtb * W2_TILE);
       if (BCLS > 1 && !CSPLIT) { f1.init(a.Gb, lane, n, mtb); f2.init(a.Gb, lane, n, mtb); f3.init(a.Gb, lane, n, mtb); }
       const int lane_out = PAIR ? ((kg >> 1) * a.Wi + n) * CI + 4 * (kg & 1) : (BMODE == MODE_UP ? 2 * n : n) * CI + 4 * kg;
@@ -644,11 +652,20 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
           for (int mt = 0; mt < MTK; ++mt) {
             if ((UB + mt) % NWV == WW) {
               const int sl = (UB + mt) / NWV;
-              ava_bf16x8 afr[3];
+              ava_bf16x8 afr[NLX];
 #pragma unroll
-              for (int L = 0; L < 3; ++L) afr[L] = ava_lds_tr8<4 * SA * 16>(xs + offA[sl] + L * XPLANE);
+              for (int L = 0; L < NLX; ++L) afr[L] = ava_lds_tr8<4 * SA * 16>(xs + offA[sl] + L * XPLANE);
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) acc[sl][nt] = ava_limb_mfma6(afr, bfr[nt], acc[sl][nt]);
+              for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (NLX == 3) acc[sl][nt] = ava_limb_mfma6(afr, bfr[nt], acc[sl][nt]);
+                else {                                           // bf16 arithmetic: the one limb of x against the three of dU
+                  f32x4 c = acc[sl][nt];
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0], bfr[nt][2], c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0], bfr[nt][1], c, 0, 0, 0);
+                  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0], bfr[nt][0], c, 0, 0, 0);
+                  acc[sl][nt] = c;
+                }
+              }
             }
           }
         };

@@ -41,7 +41,8 @@ struct ClassFrag {
   float w[NCH][4][MT];
 
   // lane_base: LDS offset (floats) of this lane's pixel inside a 16-pixel group (n * CIN * stride)
-  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base, int mtb = 0) {
+  // q: bf16 arithmetic (act_dtype = bfloat16): the weights are rounded to bfloat16 once, here
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base, int mtb = 0, bool q = false) {
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -63,7 +64,8 @@ struct ClassFrag {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int co = 16 * (mtb + mt) + m;
-          w[c][j][mt] = (valid && co < COUT) ? G[((ky * 3 + kx) * CIN + ci + j) * COUT + co] : 0.f;
+          const float wv = (valid && co < COUT) ? G[((ky * 3 + kx) * CIN + ci + j) * COUT + co] : 0.f;
+          w[c][j][mt] = q ? ava_stored<ava_bf16>(wv) : wv;
         }
     }
     // Retire the weight loads HERE.  Left pending, their first use sits inside the tile loop and hipcc's
@@ -245,7 +247,7 @@ struct PairFrag {
   float w[NCH][4][1];
 
   // G: gather weights [9][CIN][8]; lane_base: LDS offset of this lane's pixel inside the 16-pixel group
-  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base, int /*mtb*/ = 0) {
+  __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_base, int /*mtb*/ = 0, bool q = false) {
     const int m = lane & 15, kg = lane >> 4;
     const int half = m >> 3, co = m & 7;
 #pragma unroll
@@ -259,7 +261,8 @@ struct PairFrag {
       off[c] = lane_base + (dr * IC + kx) * CIN + ci;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        w[c][j][0] = (valid && ky >= 0 && ky <= 2) ? G[((ky * 3 + kx) * CIN + ci + j) * 8 + co] : 0.f;
+        const float wv = (valid && ky >= 0 && ky <= 2) ? G[((ky * 3 + kx) * CIN + ci + j) * 8 + co] : 0.f;
+        w[c][j][0] = q ? ava_stored<ava_bf16>(wv) : wv;
         asm volatile("" ::"v"(w[c][j][0]));          // retire before the tile loop (see ClassFrag::init)
       }
     }
@@ -284,9 +287,13 @@ struct PairFrag {
 // W2L: the weights' THIRD limb (used by one of the six products) lives in an LDS table instead of 4 registers per chunk and
 // tile: one more ds_read_b128 per chunk buys NCH x MT x 4 VGPRs (the role-split fused backward, conv_fused_limb.hip).  A
 // lane reads back exactly the slot it wrote itself, so waves that build the same fragments may share one table.
-template <int CIN, int COUT, int MODE, int CLS, int IC, int NPIX, int MTO = 0, bool W2L = false>
+// NLW / NLB: limbs of the weights / of the LDS operand.  3 / 3: fp32-faithful (six products).  1 / 1: bf16 arithmetic, forward
+// (weights rounded to bfloat16, one plane of rounded BatchNorm outputs: one product).  1 / 3: bf16 arithmetic, data gradient
+// (rounded weights against an fp32 gradient in three planes: three products -- the exact derivative of the rounded forward).
+template <int CIN, int COUT, int MODE, int CLS, int IC, int NPIX, int MTO = 0, bool W2L = false, int NLW = 3, int NLB = 3>
 struct ClassFragL {
   static_assert(CIN % 8 == 0, "channel octets");
+  static_assert((NLW == 3 && NLB == 3) || (NLW == 1 && !W2L && (NLB == 1 || NLB == 3)), "limb sets: 3 x 3, 1 x 1, 1 x 3");
   static constexpr int Q8 = CIN / 8;
   static constexpr int KG = n_taps<MODE>(CLS) * Q8;
   static constexpr int NCH = (KG + 3) / 4;
@@ -294,7 +301,7 @@ struct ClassFragL {
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
   static constexpr int W2_BYTES = NCH * MT * 1024;      // W2L: size of the third-limb table
   int off[NCH];                         // byte offset of this lane's 16-byte slot relative to the group's first pixel, plane 0
-  ava_bf16x8 w[NCH][W2L ? 2 : 3][MT];
+  ava_bf16x8 w[NCH][NLW == 1 ? 1 : (W2L ? 2 : 3)][MT];
   const unsigned char* w2p;             // W2L: this lane's slot of (chunk 0, tile 0); slot (c, mt) is (c * MT + mt) KB further
 
   // lane_pix: pixel offset of this lane's pixel inside a 16-pixel group (n * stride)
@@ -330,16 +337,18 @@ struct ClassFragL {
           p0[j] = a; p1[j] = b; p2[j] = d;
         }
         asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));      // weights final before the tile loop (see ClassFrag::init)
-        w[c][0][mt] = __builtin_bit_cast(ava_bf16x8, p0);
-        w[c][1][mt] = __builtin_bit_cast(ava_bf16x8, p1);
-        if constexpr (W2L) *reinterpret_cast<ava_u32x4*>(w2tab + ((c * MT + mt) * 64 + lane) * 16) = p2;
-        else w[c][2][mt] = __builtin_bit_cast(ava_bf16x8, p2);
+        w[c][0][mt] = __builtin_bit_cast(ava_bf16x8, p0);      // (limb 0 alone IS the weight rounded to bfloat16: NLW == 1)
+        if constexpr (NLW == 3) {
+          w[c][1][mt] = __builtin_bit_cast(ava_bf16x8, p1);
+          if constexpr (W2L) *reinterpret_cast<ava_u32x4*>(w2tab + ((c * MT + mt) * 64 + lane) * 16) = p2;
+          else w[c][2][mt] = __builtin_bit_cast(ava_bf16x8, p2);
+        }
       }
     }
   }
   __device__ __forceinline__ ava_bf16x8 w2(int c, int mt) const {
     if constexpr (W2L) return *reinterpret_cast<const ava_bf16x8*>(w2p + (c * MT + mt) * 1024);
-    else return w[c][2][mt];
+    else return w[c][NLW == 3 ? 2 : 0][mt];
   }
 
   // px: LDS byte address of the group's first pixel (channel octet 0, limb plane 0)
@@ -347,27 +356,40 @@ struct ClassFragL {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const ava_bf16x8 b0 = *reinterpret_cast<const ava_bf16x8*>(px + off[c]);
-      const ava_bf16x8 b1 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + PLANE_BYTES);
-      const ava_bf16x8 b2 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + 2 * PLANE_BYTES);
+      if constexpr (NLB == 1) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 a = acc[c & 1][mt];                // smallest terms first
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2(c, mt), b0, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b2, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b1, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b0, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b1, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b0, a, 0, 0, 0);
-        acc[c & 1][mt] = a;
+        for (int mt = 0; mt < MT; ++mt)
+          acc[c & 1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b0, acc[c & 1][mt], 0, 0, 0);
+      } else {
+        const ava_bf16x8 b1 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + PLANE_BYTES);
+        const ava_bf16x8 b2 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + 2 * PLANE_BYTES);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 a = acc[c & 1][mt];                // smallest terms first
+          if constexpr (NLW == 1) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b2, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b1, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b0, a, 0, 0, 0);
+          } else {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2(c, mt), b0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b2, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b1, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][mt], b0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b1, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][mt], b0, a, 0, 0, 0);
+          }
+          acc[c & 1][mt] = a;
+        }
       }
     }
   }
 };
 
 // two output rows in one tile (stride 1, 8 output channels), limb form: K walks 4 input rows x 3 taps x channel octets
-template <int CIN, int IC, int NPIX, bool W2L = false>
+template <int CIN, int IC, int NPIX, bool W2L = false, int NLW = 3, int NLB = 3>
 struct PairFragL {
   static_assert(CIN % 8 == 0, "channel octets");
+  static_assert((NLW == 3 && NLB == 3) || (NLW == 1 && !W2L && (NLB == 1 || NLB == 3)), "limb sets: 3 x 3, 1 x 1, 1 x 3");
   static constexpr int Q8 = CIN / 8;
   static constexpr int KG = 12 * Q8;
   static constexpr int NCH = (KG + 3) / 4;
@@ -375,7 +397,7 @@ struct PairFragL {
   static constexpr int PLANE_BYTES = Q8 * NPIX * 16;
   static constexpr int W2_BYTES = NCH * 1024;           // W2L: size of the third-limb table (see ClassFragL)
   int off[NCH];
-  ava_bf16x8 w[NCH][W2L ? 2 : 3][1];
+  ava_bf16x8 w[NCH][NLW == 1 ? 1 : (W2L ? 2 : 3)][1];
   const unsigned char* w2p;
 
   __device__ __forceinline__ void init(const float* __restrict__ G, int lane, int lane_pix, int /*mtb*/ = 0, unsigned char* w2tab = nullptr) {
@@ -404,29 +426,41 @@ struct PairFragL {
       }
       asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
       w[c][0][0] = __builtin_bit_cast(ava_bf16x8, p0);
-      w[c][1][0] = __builtin_bit_cast(ava_bf16x8, p1);
-      if constexpr (W2L) *reinterpret_cast<ava_u32x4*>(w2tab + (c * 64 + lane) * 16) = p2;
-      else w[c][2][0] = __builtin_bit_cast(ava_bf16x8, p2);
+      if constexpr (NLW == 3) {
+        w[c][1][0] = __builtin_bit_cast(ava_bf16x8, p1);
+        if constexpr (W2L) *reinterpret_cast<ava_u32x4*>(w2tab + (c * 64 + lane) * 16) = p2;
+        else w[c][2][0] = __builtin_bit_cast(ava_bf16x8, p2);
+      }
     }
   }
   __device__ __forceinline__ ava_bf16x8 w2(int c) const {
     if constexpr (W2L) return *reinterpret_cast<const ava_bf16x8*>(w2p + c * 1024);
-    else return w[c][2][0];
+    else return w[c][NLW == 3 ? 2 : 0][0];
   }
 
   __device__ __forceinline__ void run(const unsigned char* __restrict__ px, f32x4 (&acc)[2][1]) const {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const ava_bf16x8 b0 = *reinterpret_cast<const ava_bf16x8*>(px + off[c]);
-      const ava_bf16x8 b1 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + PLANE_BYTES);
-      const ava_bf16x8 b2 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + 2 * PLANE_BYTES);
       f32x4 a = acc[c & 1][0];
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2(c), b0, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b2, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b1, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b0, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b1, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b0, a, 0, 0, 0);
+      if constexpr (NLB == 1) {
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b0, a, 0, 0, 0);
+      } else {
+        const ava_bf16x8 b1 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + PLANE_BYTES);
+        const ava_bf16x8 b2 = *reinterpret_cast<const ava_bf16x8*>(px + off[c] + 2 * PLANE_BYTES);
+        if constexpr (NLW == 1) {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b2, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b1, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b0, a, 0, 0, 0);
+        } else {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2(c), b0, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b2, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b1, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][1][0], b0, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b1, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][0][0], b0, a, 0, 0, 0);
+        }
+      }
       acc[c & 1][0] = a;
     }
   }

@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256, (MSPLIT ? 2 : 1)) void conv3x3_mfma_kernel(con
   }
   // Weights and epilogue constants are fetched AFTER the first tile's loads were issued: both round trips to
   // memory overlap instead of following each other at the start of every workgroup.
-  if (!AVA_DBG_BIT(a, 8)) f0.init(a.G, lane, SP * n * CIN, mtb);
-  if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb); f2.init(a.G, lane, n * CIN, mtb); f3.init(a.G, lane, n * CIN, mtb); }
+  constexpr bool BF16M = std::is_same<ACT, ava_bf16>::value;     // bf16 arithmetic: weights rounded to bfloat16 (TileStager rounds the BatchNorm output)
+  if (!AVA_DBG_BIT(a, 8)) f0.init(a.G, lane, SP * n * CIN, mtb, BF16M);
+  if (NCLS > 1) { f1.init(a.G, lane, n * CIN, mtb, BF16M); f2.init(a.G, lane, n * CIN, mtb, BF16M); f3.init(a.G, lane, n * CIN, mtb, BF16M); }
   // epilogue constants for this lane's 4 output channels per cout tile
   float bias[MT][4];
   float s1[MT][4], s2[MT][4];

@@ -542,6 +542,8 @@ __device__ __forceinline__ void thin_8to1_direct_body(const ConvArgs& a) {
     const int tl = walk.cur;
     const int b = tl / tiles_y, oy0 = (tl - b * tiles_y) * THIN_TH;
     // ---- phase 1: own pixel column, 10 rows ----
+    // (FOLD, measured: requesting the NEXT tile's rows here, to travel under phases 2 and 3, costs 256 VGPRs + spills and makes
+    // the kernel slower, 52.7 -> 60.6 us; the second resident workgroup already covers the loads)
     const ACT* __restrict__ xin = ava_as<ACT>(a.in) + ((size_t)b * a.Hi * W + x) * 8 + 4 * h;
     avaf2 xn[THIN_IR][2];
     avaf2 xh[FOLD ? THIN_IR : 1][2];
@@ -1368,7 +1370,9 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
     const int spx = set >> 1, sh = set & 1, ky = r / 16, slot = (r >> 3) & 1, ci = r & 7;
     const int kx = slot == 0 ? (spx ? 2 : 1) : 0;                              // slot 0: column c, slot 1: column c + 1
     const bool exists = slot == 0 || spx == 1;
-    wt[(set * UP88_WSTRIDE + r) * 4 + co4] = exists ? a.G[((ky * 3 + kx) * 8 + ci) * 8 + 4 * sh + co4] : 0.f;
+    // (bf16 arithmetic, ACT = bfloat16: weights and BatchNorm outputs rounded to bfloat16, exact products, fp32 accumulation --
+    // the semantics of the matrix-core layers' one-limb form; ava_stored<float> is the identity)
+    wt[(set * UP88_WSTRIDE + r) * 4 + co4] = exists ? ava_stored<ACT>(a.G[((ky * 3 + kx) * 8 + ci) * 8 + 4 * sh + co4]) : 0.f;
   }
   float sca[8], shf[8];
   if (a.fin.acc != nullptr) {               // BatchNorm of the input: sums accumulated by the producer (bn_acc.h), finalised here
@@ -1406,8 +1410,8 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
         const avaf4 v0 = ava_ld4<ACT>(pp), v1 = ava_ld4<ACT>(pp + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xn[j][e] = ok ? fmaf(sca[e], v0[e], shf[e]) : 0.f;
-          xn[j][4 + e] = ok ? fmaf(sca[4 + e], v1[e], shf[4 + e]) : 0.f;
+          xn[j][e] = ok ? ava_stored<ACT>(fmaf(sca[e], v0[e], shf[e])) : 0.f;
+          xn[j][4 + e] = ok ? ava_stored<ACT>(fmaf(sca[4 + e], v1[e], shf[4 + e])) : 0.f;
         }
       }
 #pragma unroll

@@ -68,7 +68,12 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   static_assert(!PAIR || (MODE == MODE_S1 && COUT == 8 && !MSPLIT && TH % 2 == 0), "PAIR: stride 1, 8 output channels");
   constexpr int NCLS = n_classes<MODE>();
   static_assert(!LIMB || (!RECOMP && CIN % 8 == 0), "limb planes are made of channel octets");
-  constexpr int TILE_F = LIMB ? IR * IC * CIN * 3 / 2 : IR * IC * CIN;      // floats; LIMB: three bf16 planes
+  // bf16 arithmetic (act_dtype = bfloat16: BASELINE configs[4] "bf16 conv"): weights rounded to bfloat16 (one limb), and in a
+  // forward launch the rounded BatchNorm outputs are one plane (TileStager::BF16_MATH) -- one product instead of six; a
+  // data-gradient launch keeps its fp32 gradient in three planes (three products)
+  constexpr bool BF16M = std::is_same<ACT, ava_bf16>::value;
+  constexpr int NLW = BF16M ? 1 : 3, NLB = ava_stager_limbs<TIN, PRO>();
+  constexpr int TILE_F = LIMB ? IR * IC * CIN * NLB / 2 : IR * IC * CIN;      // floats; LIMB: NLB bf16 planes
   extern __shared__ __align__(16) float smem[];
   float* tile0 = smem;                      // two tile buffers
   float* coef = smem + 2 * TILE_F;          // [3][32]
@@ -215,15 +220,19 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   const int mtb = MSPLIT ? (wave & 1) : 0;  // first cout tile of this wave
   const int wp = wave >> 1;                 // MSPLIT: which half of the pixel groups
   constexpr int LCIN = LIMB ? CIN : 8;      // (the limb classes need CIN % 8 == 0 even where they are not used)
-  typename std::conditional<LIMB, typename std::conditional<PAIR, PairFragL<LCIN, IC, IR * IC>, ClassFragL<LCIN, COUT, MODE, 0, IC, IR * IC, MT>>::type,
+  typename std::conditional<LIMB, typename std::conditional<PAIR, PairFragL<LCIN, IC, IR * IC, false, NLW, NLB>, ClassFragL<LCIN, COUT, MODE, 0, IC, IR * IC, MT, false, NLW, NLB>>::type,
                             typename std::conditional<PAIR, PairFrag<CIN, IC>, ClassFrag<CIN, COUT, MODE, 0, IC, MT>>::type>::type f0;
-  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, IR * IC, MT>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT>>::type f1;
-  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, IR * IC, MT>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT>>::type f2;
-  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, IR * IC, MT>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT>>::type f3;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, IR * IC, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT>>::type f1;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, IR * IC, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT>>::type f2;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, IR * IC, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT>>::type f3;
   constexpr int SP = MODE == MODE_DOWN ? 2 : 1;
   constexpr int PIXU = LIMB ? 1 : CIN;      // what one pixel is worth in the fragments' offset unit (16-byte slots / floats)
-  f0.init(a.G, lane, SP * n * PIXU, mtb);
-  if (NCLS > 1) { f1.init(a.G, lane, n * PIXU, mtb); f2.init(a.G, lane, n * PIXU, mtb); f3.init(a.G, lane, n * PIXU, mtb); }
+  // (the limb fragments take the weights' limb count as a template parameter; the fp32 fragments round at run time)
+  auto finit = [&](auto& f, int pixoff) __attribute__((always_inline)) {
+    if constexpr (LIMB) f.init(a.G, lane, pixoff, mtb); else f.init(a.G, lane, pixoff, mtb, BF16M);
+  };
+  finit(f0, SP * n * PIXU);
+  if (NCLS > 1) { finit(f1, n * PIXU); finit(f2, n * PIXU); finit(f3, n * PIXU); }
   // LDS address of pixel `pix` of a tile, in the form the fragments' run() takes
   auto pxp = [&](const float* tile, int pix) __attribute__((always_inline)) {
     if constexpr (LIMB) return reinterpret_cast<const unsigned char*>(tile) + pix * 16;
@@ -384,7 +393,9 @@ int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   constexpr bool MSPLIT = MT == 2 && CIN >= 16;     // same rules as launch_mfma
   constexpr bool PAIR = MODE == MODE_S1 && COUT == 8;
   constexpr int XS_F = RECOMP ? Y1MfmaStager<G::IC, ACT>::LDS_FLOATS : 0;
-  const size_t lds = (size_t)(2 * (LIMB ? G::IR * G::IC * CIN * 3 / 2 : G::IR * G::IC * CIN) + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
+  using TIN = typename std::conditional<PRO == PRO_BN, ACT, float>::type;
+  constexpr int NLB = ava_stager_limbs<TIN, PRO>();                 // limb planes of the staged operand (kernel: TILE_F)
+  const size_t lds = (size_t)(2 * (LIMB ? G::IR * G::IC * CIN * NLB / 2 : G::IR * G::IC * CIN) + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP, LIMB>),

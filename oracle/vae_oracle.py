@@ -135,12 +135,34 @@ def _store(h, act_dtype, name=None, stored=None):
     return h + (h.detach().to(act_dtype).to(h.dtype) - h.detach())
 
 
-def encode(P, x, running=None, train=True, record=None, masks=None, act_dtype=None, stored=None):
+# Convolutions that compute in bf16 ARITHMETIC when this build's activations are bfloat16 (VAE(act_dtype='bfloat16'), BASELINE
+# configs[4] "bf16 conv + fp32 ELBO"; not in the reference): the twelve layers with >= 8 channels on both sides -- the matrix-core
+# layers.  conv1 and convt7 (one channel on one side: packed-FMA kernels bound by HBM, not by arithmetic) keep fp32 products.
+BF16_MATH_LAYERS = frozenset(["conv%d" % i for i in range(2, 8)] + ["convt%d" % i for i in range(1, 7)])
+
+
+def _q_bf16(t):
+    """Round to bfloat16 (nearest even) with a straight-through gradient: the operand rounding of the bf16-arithmetic mode."""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
+def _conv_operands(h, w, layer, bf16_math):
+    """The two operands of a layer's products: as they are (reference arithmetic), or -- bf16 arithmetic -- the BatchNorm output
+    and the weights each rounded to bfloat16; the products of bfloat16 values are exact in fp32 and are accumulated in fp32
+    (here: in the oracle's dtype).  Backward: the rounding has no derivative of its own, so the data gradient is taken against
+    the ROUNDED weights and the weight gradient against the ROUNDED input -- the derivative of the function evaluated."""
+    if bf16_math and layer in BF16_MATH_LAYERS:
+        return _q_bf16(h), _q_bf16(w)
+    return h, w
+
+
+def encode(P, x, running=None, train=True, record=None, masks=None, act_dtype=None, stored=None, bf16_math=False):
     """vae.py:216-233.  ``x`` is ``[B,128,128]``; returns mu [B,z], u [B,z], d [B,z]."""
     h = x.unsqueeze(1)
     for conv, bn, stride in ENC:
         h = batchnorm(h, bn, P, running, train, record)
-        h = _relu(F.conv2d(h, P[conv + ".weight"], P[conv + ".bias"], stride=stride, padding=1), conv, masks)
+        h, w = _conv_operands(h, P[conv + ".weight"], conv, bf16_math)
+        h = _relu(F.conv2d(h, w, P[conv + ".bias"], stride=stride, padding=1), conv, masks)
         if conv != "conv7":
             h = _store(h, act_dtype, conv, stored)               # conv7's output feeds the fp32 fully connected layers
         if record is not None:
@@ -158,7 +180,8 @@ def encode(P, x, running=None, train=True, record=None, masks=None, act_dtype=No
     return mu, u, torch.exp(a)                                   # vae.py:232
 
 
-def decode(P, z, running=None, train=True, record=None, masks=None, x_shape=(128, 128), act_dtype=None, stored=None):
+def decode(P, z, running=None, train=True, record=None, masks=None, x_shape=(128, 128), act_dtype=None, stored=None,
+           bf16_math=False):
     """vae.py:258-270.  Returns x_rec ``[B, H*W]`` (``[B,16384]`` at the reference's X_SHAPE; ``x_shape`` other than
     (128, 128) is this build's size extension: fc8.out = 32 * H/8 * W/8)."""
     h = _relu(F.linear(z, P["fc5.weight"], P["fc5.bias"]), "fc5", masks)
@@ -171,8 +194,8 @@ def decode(P, z, running=None, train=True, record=None, masks=None, x_shape=(128
     h = _store(h, act_dtype, "fc8", stored)                      # the NHWC copy convt1 reads
     for i, (convt, bn, stride) in enumerate(DEC):
         h = batchnorm(h, bn, P, running, train, record)
-        h = F.conv_transpose2d(h, P[convt + ".weight"], P[convt + ".bias"], stride=stride,
-                               padding=1, output_padding=stride - 1)
+        h, w = _conv_operands(h, P[convt + ".weight"], convt, bf16_math)
+        h = F.conv_transpose2d(h, w, P[convt + ".bias"], stride=stride, padding=1, output_padding=stride - 1)
         if i < 6:
             h = _store(_relu(h, convt, masks), act_dtype, convt, stored)   # no ReLU after convt7 (vae.py:269)
         if record is not None:
@@ -213,14 +236,14 @@ def loss_terms(x, x_rec, z, u, d, model_precision=10.0):
 
 
 def forward(P, x, eps_w, eps_d, running=None, train=True, model_precision=10.0, record=None, masks=None,
-            act_dtype=None, stored=None):
+            act_dtype=None, stored=None, bf16_math=False):
     """vae.py:311-327 with the two normal draws injected.  Raises ValueError
     like the reference's argument validation when ``d`` is not positive."""
-    mu, u, d = encode(P, x, running, train, record, masks, act_dtype, stored)
+    mu, u, d = encode(P, x, running, train, record, masks, act_dtype, stored, bf16_math)
     if not bool((d > 0).all()):
         raise ValueError("cov_diag must be positive")
     z = rsample(mu, u, d, eps_w, eps_d)
-    x_rec = decode(P, z, running, train, record, masks, tuple(x.shape[1:]), act_dtype, stored)
+    x_rec = decode(P, z, running, train, record, masks, tuple(x.shape[1:]), act_dtype, stored, bf16_math)
     loss, sum_z2, sse, sum_h = loss_terms(x, x_rec, z, u, d, model_precision)
     out = dict(loss=loss, sum_z2=sum_z2, sse=sse, sum_h=sum_h, mu=mu, u=u, d=d, z=z, x_rec=x_rec)
     return out

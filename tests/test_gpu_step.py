@@ -571,6 +571,56 @@ def test_full_batch_properties(B, z):
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize("act", [None, "bfloat16"], ids=["fp32", "bf16"])
+def test_config5_full_shard_properties(act):
+    """BASELINE configs[4] at its REAL per-GPU size: 256 x 256 spectrograms, z = 128, 64 samples
+    (batch 512 over 8 GPUs), fp32 and `act_dtype='bfloat16'` (bf16 activation storage + bf16 conv arithmetic).  The
+    oracle comparisons of this configuration run at batch 4 (test_256x256_*, test_bf16_activation_storage); here the
+    size-independent properties at full size: finite loss and gradients, run-to-run bit identity, the fused SSE
+    reduction against a torch reduction of the kernel's own output, loss decrease under Adam, and the two modes' ELBO
+    within 5e-3 of each other (the cost of bf16 arithmetic, stated in test_bf16_activation_storage)."""
+    from ava_amd.vae import VAE
+    shape, z, B = (256, 256), 128, 64
+    fp = syn.fixture_parameters(z, shape)
+    x = torch.from_numpy(syn.spectrograms(B, salt=909, shape=shape)).cuda()
+    ew, ed = syn.noise(B, z, 7, 8)
+    runs = []
+    for _ in range(2):
+        kw = {} if act is None else {"act_dtype": act}
+        model = VAE(z_dim=z, device_name="cuda", x_shape=shape, **kw)
+        with torch.no_grad():
+            for name, prm in model.named_parameters():
+                prm.copy_(torch.from_numpy(fp[name]))
+        model.noise_source = lambda b, zz: (ew, ed)
+        model.train()
+        loss = model.forward(x)
+        loss.backward()
+        runs.append((float(loss.item()), model._grads.clone()))
+    assert np.isfinite(runs[0][0]) and bool(torch.isfinite(runs[0][1]).all())
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    xr = model._workspace_tensor("xrec", (B, shape[0] * shape[1]))
+    lb = model._loss_buf.cpu().double().numpy()
+    assert rel(lb[2], float(((x.view(B, -1).double() - xr.double()) ** 2).sum())) < 1e-6
+    if act is not None:
+        ref = VAE(z_dim=z, device_name="cuda", x_shape=shape)
+        with torch.no_grad():
+            for name, prm in ref.named_parameters():
+                prm.copy_(torch.from_numpy(fp[name]))
+        ref.noise_source = lambda b, zz: (ew, ed)
+        ref.train()
+        with torch.no_grad():
+            assert rel(runs[0][0], float(ref.forward(x).item())) < 5e-3
+        del ref
+    losses = []
+    for _ in range(4):
+        model.optimizer.zero_grad()
+        l = model.forward(x)
+        l.backward()
+        model.optimizer.step()
+        losses.append(float(l.item()))
+    assert losses[-1] < losses[0]
+
+
 @pytest.mark.parametrize("B", [8, 64, 256])
 def test_gradients_against_fp64_noise_floor(B):
     """the gradient tolerance is derived from an fp64 evaluation of the oracle instead of being
@@ -727,16 +777,23 @@ def _hip_stored(model, B):
 @pytest.mark.parametrize("shape,B,z", [((128, 128), 8, 32), ((256, 256), 4, 128)], ids=["128x128", "config5_256x256_z128"])
 def test_bf16_activation_storage(shape, B, z):
     """BASELINE configs[4] "bf16 conv + fp32 ELBO": VAE(act_dtype='bfloat16') stores the thirteen activation tensors
-    between the conv layers as bfloat16 (rounded to nearest even by the producing kernel); products accumulate in fp32
-    and BatchNorm statistics / gradients / fully connected layers / ELBO / Adam stay fp32.
+    between the conv layers as bfloat16 (rounded to nearest even by the producing kernel) AND -- round 5 -- computes the
+    twelve convolutions with >= 8 channels on both sides in bf16 ARITHMETIC: weights and BatchNorm outputs rounded to
+    bfloat16, one-limb products on v_mfma_f32_16x16x32_bf16 (three-limb fp32 gradients in the backward), fp32 accumulation;
+    conv1 / convt7, BatchNorm statistics, gradients, fully connected layers, ELBO and Adam stay fp32
+    (oracle.BF16_MATH_LAYERS, oracle._conv_operands).
 
     Tolerances (stated):
     * tight: against the fp64 oracle evaluated ON THE TENSORS THE DEVICE STORED (oracle._store(stored=...): value =
-      the device's bf16 tensor, straight-through gradient) with the device's ReLU masks -- the exact derivative of the
-      function the device evaluated: -ELBO 1e-6 relative, every gradient tensor 1e-4;
+      the device's bf16 tensor, straight-through gradient) with the device's ReLU masks and the SAME operand rounding
+      (bf16_math=True: the rounded weights and rounded BatchNorm outputs enter the products, straight-through) -- the
+      exact derivative of the function the device evaluated: -ELBO 1e-6 relative, every gradient tensor 1e-4 (what is
+      left besides fp32 rounding: a BatchNorm output within ~1e-7 of a bfloat16 rounding boundary may round the other
+      way in the oracle's fp64 arithmetic, one bf16 ulp on ~5e-5 of the elements);
     * the stored tensors themselves: bfloat16, equal to round-to-nearest-even of the fp32 oracle's first activation
       on > 99.8 % of the elements (the rest sit on a rounding boundary within fp32 noise);
-    * what the mode costs against the plain fp32 oracle: -ELBO within 1e-3 relative (measured 2e-5); gradients are
+    * what the mode costs against the plain fp32 oracle: -ELBO within 5e-3 relative (measured 2e-5 with storage alone,
+      ~6e-4 with bf16 arithmetic); gradients are
       NOT comparable tensor by tensor -- any two evaluations of a bf16-rounded network decorrelate to one bf16 ulp
       (0.4 %) per element within a few layers and then disagree on ~0.4 % of the ReLU masks (5-25 % per gradient
       tensor, the same between an fp32 and an fp64 run of the rounded oracle: tools/bf16_probe.py) -- so only the
@@ -761,7 +818,7 @@ def test_bf16_activation_storage(shape, B, z):
     # ---- tight: fp64 oracle on the device's stored tensors and masks ----
     P = O.to_params(fp, dtype=torch.float64, requires_grad=True)
     out = O.forward(P, x.double(), torch.from_numpy(ew).double(), torch.from_numpy(ed).double(), None, True,
-                    masks=_hip_masks(model, B), stored=_hip_stored(model, B))
+                    masks=_hip_masks(model, B), stored=_hip_stored(model, B), bf16_math=True)
     out["loss"].backward()
     assert rel(float(loss.item()), float(out["loss"].detach())) < 1e-6
     cb = float(P["conv1.bias"].grad.norm())
@@ -781,7 +838,7 @@ def test_bf16_activation_storage(shape, B, z):
     want_y1 = rec["conv1.out"].detach().permute(0, 2, 3, 1).bfloat16()
     assert float((y1.cpu() != want_y1).float().mean()) < 2e-3
     # ---- cost of the mode against plain fp32 ----
-    assert rel(float(loss.item()), float(o32["loss"].detach())) < 1e-3
+    assert rel(float(loss.item()), float(o32["loss"].detach())) < 5e-3
     for n, p in P32.items():
         if n.endswith(".weight") and not n.startswith("bn"):
             r = p.grad.double().numpy().ravel()

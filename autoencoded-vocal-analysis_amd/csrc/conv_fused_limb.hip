@@ -98,7 +98,7 @@ struct FLds {
   // measured per layer (same box, us): conv2 78.3 -> 70.3, conv4 46.6 -> 40.7, convt3 43.5 -> 37.2, conv6 34.7 -> 31.9, convt5 61.2 -> 59.4,
   // convt4 / convt2 / convt6 +-1; the stride-1 layers with MORE output than input channels lose (conv3 53.5 -> 60.1, conv5 38.8 -> 45.2:
   // few x channels to fetch, and their staging waves are the longer role already)
-  static constexpr bool RAWX = AVA_FL_RAWX && !DEEP && !(LMODE == MODE_S1 && CI < CO && AVA_FL_RAWX < 2) &&
+  static constexpr bool RAWX = AVA_FL_RAWX && (!DEEP || DUREC) && !(LMODE == MODE_S1 && CI < CO && AVA_FL_RAWX < 2) &&
                                (2 * (planes + raw) + rest + 1024) * WG_PER_CU <= 160 * 1024;
   static constexpr size_t buf = planes + (RAWX ? raw : 0);
   static constexpr size_t lds = 2 * buf + rest;
@@ -213,9 +213,13 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     d_origin(y0, x0, gy, gx);
     sd.load(a.dy, a.dy2, b, a.Ho, a.Wo, gy, gx);
   };
-  static_assert(!DEEP || !DUREC, "the seed gather keeps one private window per staging wave");
+  // (DUREC + DEEP: both register sets of the seed gather pass through the SAME private LDS window of their wave -- it is only
+  // live inside one store_limb call, and a wave's two stores follow each other)
   decltype(sx) sx2;                                            // DEEP: the second register set (odd tiles)
-  typename std::conditional<DUREC, int, decltype(sd)>::type sd2;
+  decltype(sd) sd2;
+  auto sd2_store = [&](unsigned char* dst) __attribute__((always_inline)) {
+    if constexpr (DUREC) sd2.store_limb(dst, cd, xs); else sd2.store_tight(dst, cd);
+  };
   auto prefetch2 = [&](int tl) {
     if constexpr (DEEP) {
       int b, y0, x0, gy, gx;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   };
   if (stager) {
     sx.init();
-    if constexpr (DEEP) { sx2.init(); sd2.init(); }
+    if constexpr (DEEP) { sx2.init(); if constexpr (DUREC) sd2.init(a.rcd, xs); else sd2.init(); }
     if constexpr (DUREC) sd.init(a.rcd, xs); else sd.init();
     if (walk.valid()) prefetch(walk.cur);    // tile 0 goes in flight BEFORE the coefficient prologue
   }
@@ -266,13 +270,18 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   if (stager) {
     // ---------------- staging waves ----------------
     __builtin_amdgcn_s_setprio(3);           // issue priority over the matrix-core waves of the same SIMD (conv_fused.hip)
+    constexpr int XOFF = LMODE == MODE_UP ? 0 : 1;              // the dx region inside the x window
+    auto sx_store_of = [&](auto& stg, unsigned char* dst) __attribute__((always_inline)) {
+      if constexpr (RAWX) stg.template store_tight_raw<XOFF, XOFF, FG::OH, FG::OW>(dst, cx, reinterpret_cast<float*>(dst + RAWOFF));
+      else stg.store_tight(dst, cx);
+    };
     if constexpr (DEEP) {
       // tile k lives in register set k & 1 and goes to LDS buffer k & 1
       auto tile_k = [&](int k) { return walk.cur + k * walk.step; };
       if (walk.valid()) {
         if (tile_k(1) < walk.end) prefetch2(tile_k(1));
-        sx.store_tight(smem_b, cx);
-        sd.store_tight(smem_b + XBYTES, cd);
+        sx_store_of(sx, smem_b);
+        sd_store(smem_b + XBYTES);
         if (tile_k(2) < walk.end) prefetch(tile_k(2));
       }
       __syncthreads();                                          // (A) tile 0 ready
@@ -280,12 +289,12 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
       for (; walk.valid(); walk.advance(), ++it) {              // (tile_k is relative to the advancing walk.cur)
         if (walk.has_next()) {
           if ((it & 1) == 0) {
-            sx2.store_tight(smem_b + BUF, cx);
-            sd2.store_tight(smem_b + BUF + XBYTES, cd);
+            sx_store_of(sx2, smem_b + BUF);
+            sd2_store(smem_b + BUF + XBYTES);
             if (tile_k(3) < walk.end) prefetch2(tile_k(3));
           } else {
-            sx.store_tight(smem_b, cx);
-            sd.store_tight(smem_b + XBYTES, cd);
+            sx_store_of(sx, smem_b);
+            sd_store(smem_b + XBYTES);
             if (tile_k(3) < walk.end) prefetch(tile_k(3));
           }
         }
@@ -294,11 +303,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
       __syncthreads();                                          // (E)
       return;
     }
-    constexpr int XOFF = LMODE == MODE_UP ? 0 : 1;              // the dx region inside the x window
-    auto sx_store = [&](unsigned char* dst) __attribute__((always_inline)) {
-      if constexpr (RAWX) sx.template store_tight_raw<XOFF, XOFF, FG::OH, FG::OW>(dst, cx, reinterpret_cast<float*>(dst + RAWOFF));
-      else sx.store_tight(dst, cx);
-    };
+    auto sx_store = [&](unsigned char* dst) __attribute__((always_inline)) { sx_store_of(sx, dst); };
     if (walk.valid()) {
       sx_store(smem_b);
       sd_store(smem_b + XBYTES);
@@ -743,14 +748,17 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
                                       // convt4 41.7 -> 45.3 without a spill; convt5 61.5 -> 91, conv5 40.5 -> 62 with the spills the
                                       // second register set causes); lab: -DAVA_FL_DEEP_MIN_NS=8 builds it for the 8-stager shapes
 #endif
+#ifndef AVA_FL_T6_DEEP
+#define AVA_FL_T6_DEEP 0              // convt6's backward (seed gather in the staging waves): two tiles in the staging registers
+#endif
 template <int CI, int CO, int LMODE, int TW, int TH, int NS, int ND, int NWV, int WPS>
 static int launch_fused_limb(const FusedArgs& a, int grid, int dy_pro, hipStream_t st) {
   constexpr bool DEEP = NS >= AVA_FL_DEEP_MIN_NS;
   if constexpr (CI == 8 && CO == 8 && LMODE == MODE_UP && TH == 4 && NS == 4) {
     if (a.rcd.G1 != nullptr) {            // convt6's backward with convt7's data gradient formed in the staging waves
       if (dy_pro != PRO_BWD) return AVA_EINVAL;
-      if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, ava_bf16, true>(a, grid, st);
-      return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, float, true>(a, grid, st);
+      if (a.act_bf16) return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, ava_bf16, true, AVA_FL_T6_DEEP != 0>(a, grid, st);
+      return launch_fused_limb_t<CI, CO, LMODE, PRO_BWD, TW, TH, NS, ND, NWV, WPS, float, true, AVA_FL_T6_DEEP != 0>(a, grid, st);
     }
   }
   if (a.rcd.G1 != nullptr) return AVA_EINVAL;

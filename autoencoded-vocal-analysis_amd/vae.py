@@ -86,8 +86,11 @@ class VAE(nn.Module):
         spectrogram size in the module constant ``X_SHAPE = (128, 128)`` and the literal 8192 (vae.py:33,142,153);
         here the layers scale with ``(H, W)`` (width 128 or 256, height a multiple of 128; BASELINE config 5 is
         256 x 256) and ``fc1.in = fc8.out = 32 * H/8 * W/8``; ``act_dtype`` -- ``"float32"`` (the reference) or
-        ``"bfloat16"``: the activations between the 14 conv layers are stored as bf16 (``ava_model_create_ex``), all
-        arithmetic, BatchNorm statistics, the ELBO and Adam stay fp32 (BASELINE config 5: "bf16 conv + fp32 ELBO")."""
+        ``"bfloat16"`` (BASELINE config 5: "bf16 conv + fp32 ELBO"): the activations between the 14 conv layers are stored
+        as bf16 (``ava_model_create_ex``) and the twelve convolutions with >= 8 channels on both sides compute in bf16
+        arithmetic -- weights and BatchNorm outputs rounded to bfloat16, products exact, fp32 accumulation, the backward
+        the exact derivative of that function with fp32 gradients; conv1 / convt7, BatchNorm statistics, the fully
+        connected layers, the ELBO and Adam stay fp32 (``oracle/vae_oracle.py: BF16_MATH_LAYERS``)."""
         super(VAE, self).__init__()
         if act_dtype not in ("float32", "bfloat16"):
             raise ValueError("act_dtype must be 'float32' or 'bfloat16'")

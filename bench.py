@@ -487,11 +487,14 @@ def main():
            "value": round(value, 1), "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": ("f32" if args.dtype == "f32" else "f32 arithmetic, bf16 activation storage")
-                    + " (fc1/fc8 products, the forward convolutions with >= 8 input channels, the 16x16 layers' data gradients and the "
-                      "fused backward kernels (data gradient AND weight gradient): fp32 operands as three bf16 limbs on bf16 MFMA, six "
-                      "limb products, fp32 accumulate; the 1<->8-channel layers, convt6's forward, the 16x16 layers' weight gradients and "
-                      "the small fully connected products on packed fp32 FMA / fp32 MFMA)", "data": "synthetic",
+           "dtype": (("f32 (fc1/fc8 products, the forward convolutions with >= 8 input channels and the fused backward kernels "
+                      "(data gradient AND weight gradient): fp32 operands as three bf16 limbs on bf16 MFMA, six limb products, fp32 "
+                      "accumulate; the 1<->8-channel layers, convt6's forward, conv7's forward and the small fully connected products "
+                      "on packed fp32 FMA / fp32 MFMA)") if args.dtype == "f32" else
+                     ("bf16 conv arithmetic + bf16 activation storage, fp32 everything else (the twelve convolutions with >= 8 "
+                      "channels on both sides: weights and BatchNorm outputs rounded to bf16, ONE bf16 MFMA product per forward "
+                      "term, fp32 accumulate; their backward: fp32 gradients as three bf16 limbs against the rounded operands, "
+                      "three products; conv1 / convt7, BatchNorm statistics, fc layers (three-limb), ELBO and Adam fp32)")), "data": "synthetic",
            "config": {"workload": "configs[%d]: mouse_sylls VAE, batch %d synthetic %dx%d fp32 spectrograms per GPU, z=%d, "
                                   "train step = zero_grad+forward+backward%s+Adam, device-resident batches"
                                   % (4 if (H, W) != (128, 128) else (3 if world > 1 else (2 if args.z_dim == 64 else 1)), B, H, W, args.z_dim,

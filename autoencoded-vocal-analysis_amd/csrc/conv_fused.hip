@@ -17,6 +17,12 @@
 #include "conv_fused.h"
 #include "conv_recomp.h"
 
+// Round 5: the fp32-MFMA kernels of this file are LAB-ONLY (make lab).  Every layer shape has a limb instantiation
+// (conv_fused_limb.hip) whose tiles divide every supported image size (W in {128, 256}, H a multiple of 128: low-resolution
+// sides >= 16 against tiles of at most 32 x 8), so no supported size reached them any more; a size they would have served now
+// reports "no fused kernel" (grid 0) and the caller runs the separate data-gradient and weight-gradient kernels.  What the
+// product library keeps of this file is the dispatch: thin (1 <-> 8-channel) kernels, then the limb kernels.
+#ifdef AVA_LAB
 template <int LMODE, int TW, int TH>
 struct FGeom {
   // x window [XR x XC], dU window [DR x DC], dU interior [DIH x DIW] at offset (DOFF, DOFF), dx region [OH x OW]
@@ -773,11 +779,6 @@ static void fused_defaults(int Cin, int Cout, int mode, bool* ws, int* cap) {
   if (gcap > 0) *cap = gcap;
 }
 
-// both products on bf16 limb MFMA where the shape has that kernel (conv_fused_limb.hip; lab: AVA_FUSED_LIMB=0 keeps fp32 MFMA)
-static bool fused_limb_on() {
-  static const bool limb = [] { const char* e = ava_env("AVA_FUSED_LIMB"); return e == nullptr || atoi(e) != 0; }();
-  return limb;
-}
 
 static int fused_variant() {
   static const int v = [] { const char* e = ava_env("AVA_FUSED_VAR"); return e ? atoi(e) : 0; }();
@@ -790,6 +791,13 @@ static bool fused_tile(int Cin, int Cout, int mode, int* tw, int* th) {
   AVA_FUSED_SHAPES(X)
 #undef X
   return false;
+}
+#endif   // AVA_LAB
+
+// both products on bf16 limb MFMA where the shape has that kernel (conv_fused_limb.hip; lab: AVA_FUSED_LIMB=0 keeps fp32 MFMA)
+static bool fused_limb_on() {
+  static const bool limb = [] { const char* e = ava_env("AVA_FUSED_LIMB"); return e == nullptr || atoi(e) != 0; }();
+  return limb;
 }
 
 // number of workgroups (= partial rows of both outputs) of the fused kernel, 0 when the shape has none
@@ -805,12 +813,16 @@ int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode) 
       return nt < ava_scale_grid(lcap) ? nt : ava_scale_grid(lcap);
     }
   }
+#ifdef AVA_LAB
   if (!fused_tile(Cin, Cout, mode, &tw, &th)) return 0;
   if (hl % th != 0 || wl % tw != 0) return 0;
   const int nt = B * (hl / th) * (wl / tw);
   bool ws; int cap;
   fused_defaults(Cin, Cout, mode, &ws, &cap);   // 512 = two resident 256-thread workgroups per CU (384 / 768 / 1024 are slower)
   return nt < ava_scale_grid(cap) ? nt : ava_scale_grid(cap);
+#else
+  return 0;
+#endif
 }
 
 int ava_conv3x3_bwd_fused_launch(const FusedArgs& a_, int Cin, int Cout, int mode, int dy_pro, hipStream_t st) {
@@ -824,6 +836,7 @@ int ava_conv3x3_bwd_fused_launch(const FusedArgs& a_, int Cin, int Cout, int mod
     const int rc = ava_conv3x3_bwd_fused_limb_launch(a, grid, Cin, Cout, mode, dy_pro, st);
     if (rc != AVA_EINVAL) return rc;            // AVA_EINVAL: the image does not divide into the limb kernel's tiles
   }
+#ifdef AVA_LAB
   const int var = fused_variant();
 #define X(ci, co, md, vr, tww, thh, mw)                                                            \
   if (Cin == ci && Cout == co && mode == md && var == vr) {                                         \
@@ -833,6 +846,7 @@ int ava_conv3x3_bwd_fused_launch(const FusedArgs& a_, int Cin, int Cout, int mod
   }
   AVA_FUSED_SHAPES(X)
 #undef X
+#endif
   return AVA_EINVAL;
 }
 

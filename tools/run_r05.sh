@@ -65,7 +65,9 @@ case $pass in
     timeout 400 python3 bench.py --z-dim 64 --no-cpu-baseline --no-loader-path > $out/bench_z64.json 2> $out/bench_z64.err
     timeout 400 python3 bench.py --per-gpu-batch 128 --global-batch 0 --no-cpu-baseline --no-loader-path > $out/bench_B128.json 2> $out/bench_B128.err
     timeout 400 python3 bench.py --height 256 --width 256 --z-dim 128 --per-gpu-batch 64 --global-batch 0 --steps 50 --no-cpu-baseline --no-loader-path > $out/bench_256x256_z128_B64_fp32.json 2> $out/bench_256_fp32.err
-    timeout 400 python3 bench.py --height 256 --width 256 --z-dim 128 --per-gpu-batch 64 --global-batch 0 --steps 50 --dtype bf16 --no-cpu-baseline --no-loader-path > $out/bench_256x256_z128_B64_bf16act.json 2> $out/bench_256_bf16.err
+    timeout 400 python3 bench.py --height 256 --width 256 --z-dim 128 --per-gpu-batch 64 --global-batch 0 --steps 50 --dtype bf16 --no-cpu-baseline --no-loader-path > $out/bench_256x256_z128_B64_bf16.json 2> $out/bench_256_bf16.err
+    timeout 400 python3 bench.py --dtype bf16 --global-batch 0 --no-cpu-baseline --no-loader-path > $out/bench_128x128_bf16.json 2> $out/bench_128_bf16.err
+    timeout 400 python3 bench.py --per-gpu-batch 1024 --global-batch 0 --steps 30 --no-cpu-baseline --no-loader-path > $out/bench_B1024.json 2> $out/bench_B1024.err
     tail -c 600 $out/bench_final.json
     ;;
   scratchenv)

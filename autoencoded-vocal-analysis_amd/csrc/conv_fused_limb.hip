@@ -91,7 +91,7 @@ struct FLds {
   static constexpr bool BF16M = std::is_same<ACT, ava_bf16>::value;
   static constexpr int NLX = BF16M ? 1 : 3;
   static constexpr int W2_ALL = (LMODE == MODE_DOWN || BF16M) ? 0 : (((PAIRL ? 12 : 9) * (CO / 8) + 3) / 4) * 1024 * MT;   // the third-limb table
-  static constexpr size_t planes = (size_t)16 * (NLX * (CI / 8) * FG::XR * FG::XC + 3 * (CO / 8) * FG::DR * FG::DC);
+  static constexpr size_t planes = (size_t)16 * (NLX * (CI / 8) * ava_plane_pix(FG::XR * FG::XC) + 3 * (CO / 8) * ava_plane_pix(FG::DR * FG::DC));
   static constexpr size_t raw = (size_t)FG::OH * FG::OW * CI * sizeof(float);
   static constexpr size_t rest = (192 + ND * 32 * MT + (DUREC ? DU1to8Stager<FG::DC, ACT>::LDS_FLOATS : 0)) * sizeof(float) + W2_ALL;
   static constexpr int WG_PER_CU = WPS * 4 / (NS + ND + NWV);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   constexpr bool DSPLIT = MT == 2 && ND % 2 == 0 && !(BMODE == MODE_UP && ND == 4);
   constexpr int NDG = DSPLIT ? ND / 2 : ND;     // waves that share the pixel groups of a tile
   constexpr int MTD = DSPLIT ? 1 : MT;
-  constexpr int XNPIX = XR * XC, DNPIX = DR * DC;
+  constexpr int XNPIX = ava_plane_pix(XR * XC), DNPIX = ava_plane_pix(DR * DC);     // octet-plane strides (pixels) of the two limb images
   constexpr int XPLANE = (CI / 8) * XNPIX * 16, DPLANE = (CO / 8) * DNPIX * 16;      // bytes
   using FL = FLds<CI, CO, LMODE, TW, TH, NS, ND, NWV, WPS, ACT, DUREC, DEEP>;
   constexpr bool RAWX = FL::RAWX;           // raw x of the dx region behind the planes of each tile buffer

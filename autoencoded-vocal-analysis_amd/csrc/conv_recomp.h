@@ -278,7 +278,7 @@ struct DU1to8Stager {
   // the same tile as three bf16 limb planes ([limb][9 * C pixels][8 channels]: TileStagerL's layout for 8 channels) for the
   // limb form of the fused backward (conv_fused_limb.hip); same values, split exactly (x = x0 + x1 + x2)
   __device__ __forceinline__ void store_limb(unsigned char* __restrict__ lds, const float* __restrict__ coef, float* __restrict__ xs_all) {
-    constexpr int PLANE_BYTES = 9 * C * 16;
+    constexpr int PLANE_BYTES = ava_plane_pix(9 * C) * 16;      // one octet: the limb-plane stride of TileStagerL<8, .., 9, C>
     core.stage(xs_all, [](float v) { return v; });               // PRO_ID on the seed
     const float* ca = coef + 4 * ((core.lane >> 4) & 1);
     const avaf4 kA = {ca[0], ca[1], ca[2], ca[3]}, kB = {ca[32], ca[33], ca[34], ca[35]}, kC = {ca[64], ca[65], ca[66], ca[67]};

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   // data-gradient launch keeps its fp32 gradient in three planes (three products)
   constexpr bool BF16M = std::is_same<ACT, ava_bf16>::value;
   constexpr int NLW = BF16M ? 1 : 3, NLB = ava_stager_limbs<TIN, PRO>();
-  constexpr int TILE_F = LIMB ? IR * IC * CIN * NLB / 2 : IR * IC * CIN;      // floats; LIMB: NLB bf16 planes
+  constexpr int NPIXP = ava_plane_pix(IR * IC);                               // octet-plane stride of the limb image (pixels)
+  constexpr int TILE_F = LIMB ? NPIXP * CIN * NLB / 2 : IR * IC * CIN;        // floats; LIMB: NLB bf16 planes
   extern __shared__ __align__(16) float smem[];
   float* tile0 = smem;                      // two tile buffers
   float* coef = smem + 2 * TILE_F;          // [3][32]
@@ -220,11 +221,11 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   const int mtb = MSPLIT ? (wave & 1) : 0;  // first cout tile of this wave
   const int wp = wave >> 1;                 // MSPLIT: which half of the pixel groups
   constexpr int LCIN = LIMB ? CIN : 8;      // (the limb classes need CIN % 8 == 0 even where they are not used)
-  typename std::conditional<LIMB, typename std::conditional<PAIR, PairFragL<LCIN, IC, IR * IC, false, NLW, NLB>, ClassFragL<LCIN, COUT, MODE, 0, IC, IR * IC, MT, false, NLW, NLB>>::type,
+  typename std::conditional<LIMB, typename std::conditional<PAIR, PairFragL<LCIN, IC, NPIXP, false, NLW, NLB>, ClassFragL<LCIN, COUT, MODE, 0, IC, NPIXP, MT, false, NLW, NLB>>::type,
                             typename std::conditional<PAIR, PairFrag<CIN, IC>, ClassFrag<CIN, COUT, MODE, 0, IC, MT>>::type>::type f0;
-  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, IR * IC, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT>>::type f1;
-  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, IR * IC, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT>>::type f2;
-  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, IR * IC, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT>>::type f3;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, NPIXP, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 1 : 0), IC, MT>>::type f1;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, NPIXP, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 2 : 0), IC, MT>>::type f2;
+  typename std::conditional<LIMB, ClassFragL<LCIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, NPIXP, MT, false, NLW, NLB>, ClassFrag<CIN, COUT, MODE, (NCLS > 1 ? 3 : 0), IC, MT>>::type f3;
   constexpr int SP = MODE == MODE_DOWN ? 2 : 1;
   constexpr int PIXU = LIMB ? 1 : CIN;      // what one pixel is worth in the fragments' offset unit (16-byte slots / floats)
   // (the limb fragments take the weights' limb count as a template parameter; the fp32 fragments round at run time)
@@ -395,7 +396,7 @@ int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
   constexpr int XS_F = RECOMP ? Y1MfmaStager<G::IC, ACT>::LDS_FLOATS : 0;
   using TIN = typename std::conditional<PRO == PRO_BN, ACT, float>::type;
   constexpr int NLB = ava_stager_limbs<TIN, PRO>();                 // limb planes of the staged operand (kernel: TILE_F)
-  const size_t lds = (size_t)(2 * (LIMB ? G::IR * G::IC * CIN * NLB / 2 : G::IR * G::IC * CIN) + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
+  const size_t lds = (size_t)(2 * (LIMB ? ava_plane_pix(G::IR * G::IC) * CIN * NLB / 2 : G::IR * G::IC * CIN) + 96 + 4 * 32 * MT + XS_F) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_ws_kernel<CIN, COUT, MODE, PRO, EPI, TW, TH, MSPLIT, PAIR, ACT, RECOMP, LIMB>),

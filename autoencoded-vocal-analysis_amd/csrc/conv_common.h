@@ -157,6 +157,22 @@ template <> __device__ __forceinline__ void ava_st4<ava_bf16>(ava_bf16* p, avaf4
   const bf4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
   *reinterpret_cast<bf4*>(p) = b;
 }
+// WRITE-THROUGH form of the 16-byte activation store (sc1): the line goes to memory as it is written instead of staying dirty
+// in the XCD's L2 until the end-of-kernel release writes everything back at once (a dependent kernel boundary costs + dirty
+// bytes / 6 TB/s: MI355X_MICROARCH.md, row "boundary").  Only for stores whose wave instruction writes whole 128-byte lines.
+// lab A/B: -DAVA_WT_STORES=1
+#ifndef AVA_WT_STORES
+#define AVA_WT_STORES 0
+#endif
+template <typename T> __device__ __forceinline__ void ava_st4_wt(T* p, avaf4 v) {
+#if AVA_WT_STORES
+  if constexpr (std::is_same<T, float>::value) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    return;
+  }
+#endif
+  ava_st4<T>(p, v);
+}
 // typed view of an untyped (float*) argument: offsets are in ELEMENTS either way
 template <typename T> __device__ __forceinline__ const T* ava_as(const float* p) { return reinterpret_cast<const T*>(p); }
 template <typename T> __device__ __forceinline__ T* ava_as(float* p) { return reinterpret_cast<T*>(p); }

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(2 * W, W == 128 ? 4 : 2) void thin_1to8_kernel(cons
         s2[0] = __builtin_elementwise_fma(v0, xh0, s2[0]);
         s2[1] = __builtin_elementwise_fma(v1, xh1, s2[1]);
       }
-      if (a.out != nullptr) ava_st4<TOUT>(ava_as<TOUT>(a.out) + off, avaf4{v0[0], v0[1], v1[0], v1[1]});
+      if (a.out != nullptr) ava_st4_wt<TOUT>(ava_as<TOUT>(a.out) + off, avaf4{v0[0], v0[1], v1[0], v1[1]});
     }
   }
   if (EPI == EPI_NONE) return;
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
       s1[0] += v0; s1[1] += v1;
       s2[0] = __builtin_elementwise_fma(v0, v0, s2[0]);
       s2[1] = __builtin_elementwise_fma(v1, v1, s2[1]);
-      ava_st4<ACT>(ava_as<ACT>(a.out) + o0 + (size_t)j * a.Wo * 8, avaf4{v0[0], v0[1], v1[0], v1[1]});
+      ava_st4_wt<ACT>(ava_as<ACT>(a.out) + o0 + (size_t)j * a.Wo * 8, avaf4{v0[0], v0[1], v1[0], v1[1]});
     }
   }
   // ---- per-channel sums: lanes of equal parity hold the same 4 channels; waves, then workgroup, fixed order ----

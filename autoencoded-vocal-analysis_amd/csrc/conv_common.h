@@ -53,7 +53,15 @@ struct ConvArgs {
   RecompArgs rc; // rc.G1 != null: `in` is the raw spectrogram batch x and the kernel recomputes y1 = relu(conv1(bn1 x)) from it
   ThinFold fold; // fold.wg_partials != null (convt7's training forward): the launch also leaves the layer's weight-gradient partials behind
   int dbg;   // AVA_DBG ablation bits (diagnostic builds of the experiments in DESIGN.md): 1 skip MFMA, 2 skip staging, 4 skip stores
+#ifdef AVA_LAB
+  unsigned long long* stamps;   // lab: 16 s_memrealtime stamps of this launch (workgroup 0), tools/lab/conv_stamps.py
+#endif
 };
+#ifdef AVA_LAB
+#define AVA_STAMP(i, cond) do { if (a.stamps != nullptr && blockIdx.x == 0 && (cond)) a.stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AVA_STAMP(i, cond) do { } while (0)
+#endif
 
 template <int MODE, int TW, int TH_ = 256 / TW>
 struct Geom {

@@ -181,6 +181,9 @@ int ava_conv3x3_ex(const float* in, const float* in2, const float* pa, const flo
                    int Cout, int mode, int pro, int epi, int relu, float prec, int act_bf16, const ConvAcc* acc,
                    ava_stream_t s) {
   ConvArgs a;
+#ifdef AVA_LAB
+  a.stamps = nullptr;
+#endif
   a.rc = acc != nullptr ? acc->rc : RecompArgs{};
   a.fold = acc != nullptr ? acc->fold : ThinFold{};
   a.act_bf16 = act_bf16;

@@ -28,7 +28,13 @@ struct FusedArgs {
   RecompArgs rc;         // rc.G1 != null: `x` is the raw spectrogram batch; the layer input y1 is recomputed from it (conv_recomp.h)
   int sweep;             // thin kernels: workgroups sweep the tile list together instead of per-XCD chunks
   int dbg;               // lab build: phase ablation bits of the wave-specialised kernel (AVA_FDBG; timing only)
+#ifdef AVA_LAB
+  unsigned long long* stamps;   // lab: 16 s_memrealtime stamps of this launch (workgroup 0), tools/lab/conv_stamps.py
+#endif
 };
+#ifdef AVA_LAB
+unsigned long long* ava_lab_next_stamps_f();
+#endif
 
 // 0 when (Cin, Cout, mode, size) has no fused instantiation
 int ava_conv_fused_grid_for(int B, int Hi, int Wi, int Cin, int Cout, int mode);

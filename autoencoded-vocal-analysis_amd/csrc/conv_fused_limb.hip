@@ -177,6 +177,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  AVA_STAMP(0, t == 0);
   const bool stager = wave8 < NS;            // waves 0 .. NS-1 stage tiles, the next ND form the data gradient, the rest the weight gradient
   const int n = lane & 15, kg = lane >> 4;
 
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
   }
   __syncthreads();                           // cx / cd visible
   if (!stager) asm volatile("" ::"v"(wpf));
+  AVA_STAMP(1, t == 0);
 
   if (stager && (AVA_FL_CUT & 1)) return;
   if (stager) {
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
     if (walk.valid()) {
       sx_store(smem_b);
       sd_store(smem_b + XBYTES);
+      AVA_STAMP(2, t == 0);
       if (walk.has_next()) prefetch(walk.next());
     }
     __syncthreads();                                            // (A) tile 0 ready
@@ -410,7 +413,9 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 #pragma unroll
           for (int mt = 0; mt < MTD; ++mt) ring[gi][mt] = (avaf4){1.f, 1.f, 1.f, 1.f};
       }
+      AVA_STAMP(3, t == NST);
       __syncthreads();                                              // (A)
+      AVA_STAMP(4, t == NST);
       int it = 0;
       for (; walk.valid(); walk.advance(), ++it) {
         int b, y0, x0;
@@ -505,8 +510,10 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
 #pragma unroll
           for (int gi = 0; gi < GPW; ++gi) do_group(gi);
         }
+        AVA_STAMP(5 + (it < 4 ? it : 4), t == NST);
         __syncthreads();                                            // (B)
       }
+      AVA_STAMP(10, t == NST);
       // ---- BatchNorm-backward partial sums: over the 16 pixel lanes, then over the data-gradient waves (fixed order) ----
 #pragma unroll
       for (int mt = 0; mt < MTD; ++mt)
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
       if (a.acc_out != nullptr) bn_acc_add(a.acc_out, which * 32 + ci, tot);
       else a.bn_partials[(size_t)blockIdx.x * 2 * CI + tc] = tot;
     }
+    AVA_STAMP(12, t == NST);
     return;
   }
 
@@ -621,6 +629,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
       ones = __builtin_bit_cast(ava_bf16x8, vv);
     }
 
+    AVA_STAMP(13, t == 64 * (NS + ND));
     __syncthreads();                                              // (A)
     int it = 0;
     for (; walk.valid(); walk.advance(), ++it) {
@@ -732,6 +741,9 @@ static int launch_fused_limb_t(const FusedArgs& a, int grid, hipStream_t st) {
                               hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
   if (!attr_ok) return AVA_ELAUNCH;
   FusedArgs b = a;
+#ifdef AVA_LAB
+  b.stamps = ava_lab_next_stamps_f();
+#endif
   const int hl = LMODE == MODE_DOWN ? a.Ho : a.Hi, wl = LMODE == MODE_DOWN ? a.Wo : a.Wi;   // low-resolution side
   if (hl % TH != 0 || wl % TW != 0) return AVA_EINVAL;
   b.tiles_y = hl / TH;

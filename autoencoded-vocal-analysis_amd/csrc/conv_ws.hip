@@ -33,6 +33,26 @@
 #define AVA_ABL(bit) false
 #endif
 
+#ifdef AVA_LAB
+// lab: time stamps of the wave-specialised forward kernels (tools/lab/conv_stamps.py): launch i of a step writes 16 stamps at
+// base + 16 i; ava_lab_conv_stamps(base, n) arms it (n launches), the counter restarts with every call
+static unsigned long long* g_ws_stamps = nullptr;
+static int g_ws_stamp_n = 0, g_ws_stamp_i = 0;
+extern "C" int ava_lab_conv_stamps(unsigned long long* base, int n) { g_ws_stamps = base; g_ws_stamp_n = n; g_ws_stamp_i = 0; return 0; }
+unsigned long long* ava_lab_next_stamps_f() {     // the fused backward kernels' slots: behind the forward kernels' (conv_fused_limb.hip)
+  if (g_ws_stamps == nullptr || g_ws_stamp_i >= g_ws_stamp_n) return nullptr;
+  return g_ws_stamps + 16 * (g_ws_stamp_i++);
+}
+static unsigned long long* ava_lab_next_stamps() {
+  if (g_ws_stamps == nullptr || g_ws_stamp_i >= g_ws_stamp_n) return nullptr;
+  return g_ws_stamps + 16 * (g_ws_stamp_i++);
+}
+#endif
+
+#ifndef AVA_EARLY_INIT
+#define AVA_EARLY_INIT 0              // 1 (lab): the staging waves finalise the coefficients, the matrix-core waves build their fragments from the kernel's entry on
+#endif
+
 static bool conv_limb_on(int Cin, int Cout, int mode, int pro) {
   static const int sel = [] { const char* e = ava_env("AVA_CONV_LIMB"); return e ? atoi(e) : 1; }();
   if (sel == 0) return false;
@@ -86,6 +106,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6;
   const bool stager = wave8 < 4;
   const int wave = wave8 & 3;
+  AVA_STAMP(0, t == 0);
   const int n = lane & 15, kg = lane >> 4;
   auto origin = [&](int tl, int& b, int& oy0, int& ox0, int& gy0, int& gx0) {
     b = tl / (a.tiles_y * a.tiles_x);
@@ -117,6 +138,16 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   // stride-2 gathers hold the most staging registers: keeping their first tile in flight across the prologue raised
   // conv2's forward from 70 to 112 VGPRs (3 -> 2 resident workgroups per CU, 42 -> 50 us); they load after it instead
   constexpr bool HOIST = MODE != MODE_DOWN || DEEP;
+  // EARLY (lab, -DAVA_EARLY_INIT=1; round 5, stamps of tools/lab/conv_stamps.py): as shipped, the first matrix-core wave finalises
+  // the BatchNorm coefficients (ready 2.5-3.4 us after the kernel's entry) and only then do the matrix-core waves build their
+  // weight fragments (barrier A at 4.4-7.7 us).  EARLY lets the staging waves finalise the coefficients -- each for itself,
+  // identical values into the same LDS words, no workgroup barrier; counter loads requested in front of the first tile -- and the
+  // matrix-core waves build their fragments from the entry on.  Measured: barrier A moves by -0.8 ... +0.8 us and the step gets
+  // 15 us SLOWER (with or without a pre-split weight table): without the touch-then-barrier the weight loads are first-touch
+  // HBM misses that every workgroup takes at once, and the staging waves carry 50 more registers through the prologue.
+  constexpr bool EARLY = AVA_EARLY_INIT != 0 && PRO == PRO_BN;      // (the forward launches: what the model runs through this kernel)
+  BnAccRegs accr;
+  if (EARLY && stager && a.fin.acc != nullptr) bn_acc_issue(accr, a.fin, lane, wave8 == 0);     // every staging wave, for itself
   if (stager) {
     if constexpr (RECOMP) stg.init(a.rc, xs); else stg.init();
     if constexpr (DEEP) stg2.init();
@@ -142,16 +173,26 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     }
   }
   if (a.fin.acc != nullptr) {
-    // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h), by the first matrix-core wave, under
-    // the staging waves' first tile load
-    bn_coef_from_acc(coef, accvals, a.fin, 256);
+    // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h): by staging wave 0 (EARLY), or by the first
+    // matrix-core wave under the staging waves' first tile load
+    if constexpr (EARLY) { if (stager) bn_coef_finish(coef, accr, a.fin, lane, nullptr, wave8 == 0); }
+    else bn_coef_from_acc(coef, accvals, a.fin, 256);
+  } else if (EARLY) {
+    if (stager)
+      for (int i = lane; i < 96; i += 64) {
+        const int which = i >> 5, c = i & 31;
+        const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
+        coef[i] = (src != nullptr && c < CIN) ? src[c] : 0.f;
+      }
   } else if (t < 96) {
     const int which = t >> 5, c = t & 31;
     const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
     coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
   }
-  __syncthreads();                          // coef[] visible
-  if (!stager) asm volatile("" ::"v"(wpf));
+  // (EARLY: no workgroup barrier -- a staging wave reads back coefficient words it has written itself, in program order)
+  if (!EARLY) __syncthreads();              // coef[] visible
+  if (!EARLY && !stager) asm volatile("" ::"v"(wpf));
+  AVA_STAMP(1, t == 0);
 
   if (stager) {
     // ---------------- staging waves ----------------
@@ -192,6 +233,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         if (!AVA_ABL(4)) stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);
       }
       stg_store(tile0);                                         // tile 0 -> buffer 0
+      AVA_STAMP(2, t == 0);
       if (walk.has_next()) {
         origin(walk.next(), b, oy0, ox0, gy0, gx0);
         if (!AVA_ABL(4)) stg.load(a.in, a.in2, b, a.Hi, a.Wi, gy0, gx0);         // tile 1 in flight
@@ -281,7 +323,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
       }
   };
   if (EPI == EPI_BWD && walk.valid()) load_ex(walk.cur);
+  if constexpr (EARLY) asm volatile("" ::"v"(wpf));
+  AVA_STAMP(3, t == 256);
   __syncthreads();                                              // (A)
+  AVA_STAMP(4, t == 256);
   int it = 0;
   for (; walk.valid(); walk.advance(), ++it) {
     int b, oy0, ox0, gy0, gx0;
@@ -343,8 +388,10 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         }
       }
     }
+    AVA_STAMP(5 + (it < 4 ? it : 4), t == 256);
     __syncthreads();                                            // (B)
   }
+  AVA_STAMP(10, t == 256);
   // ---- per-workgroup partial statistics (matrix-core waves only) ----
   if (MSPLIT) {                              // a wave only fills its own cout tile: the other slots must read as 0
     const int tz = t - 256;
@@ -384,7 +431,9 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
         (red[idx] + red[32 * MTA + idx]) + (red[64 * MTA + idx] + red[96 * MTA + idx]);
     for (int r = gridDim.x + blockIdx.x; r < a.part_rows; r += gridDim.x) a.partials[(size_t)r * 2 * COUT + tc] = 0.f;
   }
+  AVA_STAMP(11, t == 256);
   __syncthreads();
+  AVA_STAMP(12, t == 256);
 }
 
 template <int CIN, int COUT, int MODE, int PRO, int EPI, int TW, int TH, typename ACT, bool RECOMP = false, bool LIMB = false>
@@ -405,6 +454,9 @@ int launch_mfma_ws_t(const ConvArgs& a, int grid, hipStream_t st) {
     attr_set = true;
   }
   ConvArgs b = a;
+#ifdef AVA_LAB
+  b.stamps = ava_lab_next_stamps();
+#endif
   b.tiles_y = a.Ho / TH;
   b.tiles_x = a.Wo / TW;
   b.ntiles = a.B * b.tiles_y * b.tiles_x;

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64 * (NS + ND + NWV), WPS) void conv3x3_bwd_fused_l
               }
               if (!(AVA_FL_DCUT & 2)) {
                 if (AVA_FL_NTSTORE) __builtin_nontemporal_store((avaf4){v[0], v[1], v[2], v[3]}, reinterpret_cast<avaf4*>(obase + gout + 16 * (mtb + mt)));
-                else *reinterpret_cast<float4*>(obase + gout + 16 * (mtb + mt)) = make_float4(v[0], v[1], v[2], v[3]);
+                else ava_st4_wt<float>(obase + gout + 16 * (mtb + mt), avaf4{v[0], v[1], v[2], v[3]});
               }
             }
           }

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
               s2[mt][r] = fmaf(v[r], xr[r], s2[mt][r]);      // raw x: centred after the loop
             }
           }
-          if (obase != nullptr && !AVA_ABL(8)) ava_st4<TOUT>(obase + gout + 16 * (mtb + mt), avaf4{v[0], v[1], v[2], v[3]});
+          if (obase != nullptr && !AVA_ABL(8)) ava_st4_wt<TOUT>(obase + gout + 16 * (mtb + mt), avaf4{v[0], v[1], v[2], v[3]});
         }
       }
     }

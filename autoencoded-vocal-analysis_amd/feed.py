@@ -207,8 +207,11 @@ class PinnedBatchLoader:
         return self._slots
 
     def __del__(self):
+        ring = _RING_SLOTS                     # None once the interpreter is tearing the module down
+        if ring is None:
+            return
         for s in (self._slots or []):
-            _RING_SLOTS.pop(s.host.data_ptr(), None)
+            ring.pop(s.host.data_ptr(), None)
 
     def _fill(self, slot, idx):
         """write items ``idx`` of the dataset into the slot (its own dtype); returns the batch view"""

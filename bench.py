@@ -131,6 +131,7 @@ def loader_path(model, B, z_dim, shape):
     out = {"unit": "spectrograms/s", "batches_per_epoch": nb, "epochs_timed": epochs, "note": "host-resident data, H2D inside the timed region"}
 
     def run(loader, prefetch):
+        nb = len(loader)
         model.prefetch = prefetch
         with contextlib.redirect_stdout(sys.stderr):
             model.train_epoch(loader)                          # warm-up epoch (ring allocation, slots)
@@ -151,6 +152,11 @@ def loader_path(model, B, z_dim, shape):
         def __len__(self): return nb
     out["reference_handover_sync_to_device"] = run(Ref(), False)
     out["pinned_ring_float32"] = run(PinnedBatchLoader(base, batch_size=B, shuffle=True), True)
+    # an epoch boundary (loss read-back, new permutation, first collation + first copy with the GPU idle) costs ~1.4 ms, about one
+    # step: tools/lab/epoch_bubble.py.  The same loader with epochs four times as long shows what is left of it
+    epochs = 1
+    out["pinned_ring_float32_%d_batches_per_epoch" % (4 * nb)] = run(PinnedBatchLoader(np.concatenate([base] * 4), batch_size=B, shuffle=True), True)
+    epochs = 4
     out["pinned_ring_float64_device_cast"] = run(PinnedBatchLoader(base.astype(np.float64), batch_size=B, shuffle=True), True)
     # uint8 items are 0 or 1 here (numpy_to_tensor casts, it does not rescale: 0..255-valued data would drive the loss to 1e9
     # and time Adam on a model being wrecked); the bytes over PCIe and the device-side cast are the same

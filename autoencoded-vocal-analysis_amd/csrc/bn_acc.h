@@ -77,90 +77,6 @@ __device__ __forceinline__ double bn_acc_read(const long long* slot, int idx) {
   return bad ? __builtin_nan("") : s;
 }
 
-// The same consumer prologue in two halves for ONE wave (lanes t = 0..63), without a barrier (round 5): `bn_acc_issue` requests
-// the 64 values' counters and the per-channel parameters, `bn_coef_finish` turns them into coef[3][32] (and publishes from
-// workgroup 0) exactly as bn_coef_from_acc does.  A staging wave calls the first half BEFORE it requests its first tile (a wave's
-// loads return in order: the counters land first) and the second half while the tile is still in flight; the matrix-core
-// waves, which used to finalise the coefficients and only then build their weight fragments, build them meanwhile.
-struct BnAccRegs {
-  long long v0[AVA_ACC_SHARDS], v1[AVA_ACC_SHARDS], v2[AVA_ACC_SHARDS];
-  unsigned long long bad;
-  float p0, p1, p2, r0, r1;
-};
-// `publish`: this wave is the one that writes what later kernels read (workgroup 0 only) -- several waves of a workgroup may each
-// finalise the same coefficients for themselves (identical values into the same LDS words: no workgroup barrier needed)
-__device__ __forceinline__ void bn_acc_issue(BnAccRegs& r, const BnFin& f, int t, bool publish = true) {
-  const int c = t & 31;
-  const bool live = c < f.C, lo = t < 32;
-  const bool pub = blockIdx.x == 0 && publish;
-  r.p0 = r.p1 = r.p2 = r.r0 = r.r1 = 0.f;
-  if (live && lo) {
-    r.p0 = f.gamma[c];
-    if (!f.backward) {
-      r.p1 = f.beta[c];
-      if (pub && f.running_mean != nullptr) { r.r0 = f.running_mean[c]; r.r1 = f.running_var[c]; }
-    } else { r.p1 = f.invstd[c]; r.p2 = f.mean[c]; }
-  }
-  r.bad = 0;
-  const int idx = live ? t : 0;
-#pragma unroll
-  for (int sh = 0; sh < AVA_ACC_SHARDS; ++sh) {
-    const long long* a = f.acc + (size_t)sh * AVA_ACC_SHARD_LL;
-    r.v0[sh] = a[idx]; r.v1[sh] = a[64 + idx]; r.v2[sh] = a[128 + idx];
-    r.bad |= (unsigned long long)a[192];
-  }
-}
-__device__ __forceinline__ void bn_coef_finish(float* coef, const BnAccRegs& r, const BnFin& f, int t, float* ext = nullptr, bool publish = true) {
-  const int c = t & 31;
-  const bool live = c < f.C, lo = t < 32;
-  const bool pub = blockIdx.x == 0 && publish;
-  double s = 0.0;
-#pragma unroll
-  for (int sh = 0; sh < AVA_ACC_SHARDS; ++sh) s += ((double)r.v0[sh] + (double)r.v1[sh] * 0x1p32 + (double)r.v2[sh] * 0x1p64) * 0x1p-48;
-  const double mine = live ? (r.bad ? __builtin_nan("") : s) : 0.0;
-  const double upper = __shfl(mine, c + 32, 64);          // value 32 + c
-  const float p0 = r.p0, p1 = r.p1, p2 = r.p2, r0 = r.r0, r1 = r.r1;
-  if (lo) {
-    float k0 = 0.f, k1 = 0.f, k2 = 0.f;
-    if (live) {
-      if (!f.backward) {
-        const double mean = mine / f.n;
-        double var = upper / f.n - mean * mean;          // biased variance
-        if (var < 0.0) var = 0.0;
-        const float meanf = (float)mean;
-        const float invstd = (float)(1.0 / sqrt(var + AVA_BN_EPS_D));
-        const float sc = p0 * invstd;
-        k0 = sc;
-        k1 = p1 - meanf * sc;
-        if (ext != nullptr) { ext[c] = meanf; ext[32 + c] = invstd; }
-        if (pub) {
-          f.save[c] = meanf; f.save[32 + c] = invstd; f.save[64 + c] = k0; f.save[96 + c] = k1;
-          if (f.running_mean != nullptr) {
-            const double unb = f.n > 1.0 ? var * (f.n / (f.n - 1.0)) : var;
-            f.running_mean[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)r0 + AVA_BN_MOM_D * mean);
-            f.running_var[c] = (float)((1.0 - AVA_BN_MOM_D) * (double)r1 + AVA_BN_MOM_D * unb);
-          }
-        }
-      } else {
-        const double dB = mine, dG = upper;
-        const double is = (double)p1, gm = (double)p0, mu = (double)p2;
-        const double a = gm * is;
-        const double b = f.eval ? 0.0 : -gm * is * is * dG / f.n;
-        k0 = (float)a;
-        k1 = (float)b;
-        k2 = f.eval ? 0.f : (float)(-a * dB / f.n - b * mu);
-        if (pub) {
-          f.dgamma[c] = (float)dG; f.dbeta[c] = (float)dB;
-          f.abc[c] = k0; f.abc[32 + c] = k1; f.abc[64 + c] = k2;
-        }
-      }
-    }
-    coef[c] = k0; coef[32 + c] = k1; coef[64 + c] = k2;
-    if (ext != nullptr && !live) { ext[c] = 0.f; ext[32 + c] = 0.f; }
-    if (c == 0 && pub && !f.backward && f.num_batches != nullptr) *f.num_batches += 1;
-  }
-}
-
 // Consumer prologue, called by ALL threads of the workgroup (>= 64 threads; contains a barrier): fills coef[3][32]
 // (LDS) with {scale, shift, 0} (forward) or {A, Bc, Cc} (backward), zero beyond C, exactly as bn_finalize_kernel /
 // bn_finalize_bwd_kernel compute them; workgroup 0 also publishes what later kernels read from global memory.

@@ -13,9 +13,6 @@
 // needed between writing it and reading it back (LDS operations of one wave execute in order).
 #pragma once
 #include "conv_common.h"
-#ifndef AVA_DU_BATCH
-#define AVA_DU_BATCH 0          // DU1to8Stager::store_limb: all units of a wave as one straight-line block (lab A/B)
-#endif
 #include "conv_mfma.h"
 
 // RAWI: also keep the raw (un-normalised) y1 of the window's interior [RI x CI at (ROFF, COFF)] in a second LDS tile
@@ -282,53 +279,6 @@ struct DU1to8Stager {
     core.stage(xs_all, [](float v) { return v; });               // PRO_ID on the seed
     const float* ca = coef + 4 * ((core.lane >> 4) & 1);
     const avaf4 kA = {ca[0], ca[1], ca[2], ca[3]}, kB = {ca[32], ca[33], ca[34], ca[35]}, kC = {ca[64], ca[65], ca[66], ca[67]};
-#if AVA_DU_BATCH
-    // All units of the wave as ONE straight-line block (round 5): the B operands of every unit are requested together, the
-    // 3 x NUW MFMAs run as NUW independent chains, then the prologues / splits / stores.  Unit by unit -- with the wave-uniform
-    // `continue` of the units a wave does not have -- every unit was its own scheduling region: LDS read, wait, three dependent
-    // MFMAs, wait, store, one after the other (17 waits per tile in the ISA).  A wave without a fourth unit computes it on a
-    // clamped column group and drops the result.
-    float bv[Core::NUW][3];
-    int row[Core::NUW], col[Core::NUW];
-    bool val[Core::NUW];
-    const int quad = (core.lane >> 4) & 1;
-#pragma unroll
-    for (int u = 0; u < Core::NUW; ++u) {
-      int q_, pb, g;
-      val[u] = core.unit(u, row[u], col[u], q_, pb, g);
-      const int gc = g < Core::NG ? g : Core::NG - 1;
-      const float* p = xs_all + core.wave * Core::XS_F + (pb + (core.lane >> 4)) * Core::XCP + 16 * gc + (core.lane & 15);
-      bv[u][0] = p[0]; bv[u][1] = p[1]; bv[u][2] = p[2];
-    }
-    f32x4 acc[Core::NUW];
-#pragma unroll
-    for (int u = 0; u < Core::NUW; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int u = 0; u < Core::NUW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(core.wA[c], bv[u][c], acc[u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < Core::NUW; ++u) {
-      const bool in = (yin >> u) & 1u;
-      avaf4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float y = y2[u][r];
-        const float du = fmaf(kA[r], acc[u][r], fmaf(kB[r], y, kC[r]));
-        o[r] = (in && y > 0.f) ? du : 0.f;
-      }
-      ava_u32x2 p0, p1, p2;
-      uint32_t a, b, c;
-      ava_limb_split2(o[0], o[1], a, b, c); p0[0] = a; p1[0] = b; p2[0] = c;
-      ava_limb_split2(o[2], o[3], a, b, c); p0[1] = a; p1[1] = b; p2[1] = c;
-      unsigned char* d = lds + (row[u] * C + col[u]) * 16 + quad * 8;
-      if (val[u]) {
-        *reinterpret_cast<ava_u32x2*>(d) = p0;
-        *reinterpret_cast<ava_u32x2*>(d + PLANE_BYTES) = p1;
-        *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
-      }
-    }
-#else
 #pragma unroll
     for (int u = 0; u < Core::NUW; ++u) {
       int row, col, quad, pb, g;
@@ -354,7 +304,6 @@ struct DU1to8Stager {
         *reinterpret_cast<ava_u32x2*>(d + 2 * PLANE_BYTES) = p2;
       }
     }
-#endif
   }
 };
 

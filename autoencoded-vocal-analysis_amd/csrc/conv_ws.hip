@@ -49,9 +49,6 @@ static unsigned long long* ava_lab_next_stamps() {
 }
 #endif
 
-#ifndef AVA_EARLY_INIT
-#define AVA_EARLY_INIT 0              // 1 (lab): the staging waves finalise the coefficients, the matrix-core waves build their fragments from the kernel's entry on
-#endif
 
 static bool conv_limb_on(int Cin, int Cout, int mode, int pro) {
   static const int sel = [] { const char* e = ava_env("AVA_CONV_LIMB"); return e ? atoi(e) : 1; }();
@@ -138,16 +135,6 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
   // stride-2 gathers hold the most staging registers: keeping their first tile in flight across the prologue raised
   // conv2's forward from 70 to 112 VGPRs (3 -> 2 resident workgroups per CU, 42 -> 50 us); they load after it instead
   constexpr bool HOIST = MODE != MODE_DOWN || DEEP;
-  // EARLY (lab, -DAVA_EARLY_INIT=1; round 5, stamps of tools/lab/conv_stamps.py): as shipped, the first matrix-core wave finalises
-  // the BatchNorm coefficients (ready 2.5-3.4 us after the kernel's entry) and only then do the matrix-core waves build their
-  // weight fragments (barrier A at 4.4-7.7 us).  EARLY lets the staging waves finalise the coefficients -- each for itself,
-  // identical values into the same LDS words, no workgroup barrier; counter loads requested in front of the first tile -- and the
-  // matrix-core waves build their fragments from the entry on.  Measured: barrier A moves by -0.8 ... +0.8 us and the step gets
-  // 15 us SLOWER (with or without a pre-split weight table): without the touch-then-barrier the weight loads are first-touch
-  // HBM misses that every workgroup takes at once, and the staging waves carry 50 more registers through the prologue.
-  constexpr bool EARLY = AVA_EARLY_INIT != 0 && PRO == PRO_BN;      // (the forward launches: what the model runs through this kernel)
-  BnAccRegs accr;
-  if (EARLY && stager && a.fin.acc != nullptr) bn_acc_issue(accr, a.fin, lane, wave8 == 0);     // every staging wave, for itself
   if (stager) {
     if constexpr (RECOMP) stg.init(a.rc, xs); else stg.init();
     if constexpr (DEEP) stg2.init();
@@ -173,25 +160,18 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
     }
   }
   if (a.fin.acc != nullptr) {
-    // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h): by staging wave 0 (EARLY), or by the first
-    // matrix-core wave under the staging waves' first tile load
-    if constexpr (EARLY) { if (stager) bn_coef_finish(coef, accr, a.fin, lane, nullptr, wave8 == 0); }
-    else bn_coef_from_acc(coef, accvals, a.fin, 256);
-  } else if (EARLY) {
-    if (stager)
-      for (int i = lane; i < 96; i += 64) {
-        const int which = i >> 5, c = i & 31;
-        const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
-        coef[i] = (src != nullptr && c < CIN) ? src[c] : 0.f;
-      }
+    // BatchNorm finalised here from the producer's accumulated sums (bn_acc.h), by the first matrix-core wave under the
+    // staging waves' first tile load.  (The staging waves finalising them for themselves, without the barrier below, so that
+    // the matrix-core waves build their fragments from the entry on: 15 us per step slower, tools/lab/early_init.patch,
+    // profiles/NOTES.md item 40.)
+    bn_coef_from_acc(coef, accvals, a.fin, 256);
   } else if (t < 96) {
     const int which = t >> 5, c = t & 31;
     const float* src = which == 0 ? a.pa : (which == 1 ? a.pb : a.pc);
     coef[t] = (src != nullptr && c < CIN) ? src[c] : 0.f;
   }
-  // (EARLY: no workgroup barrier -- a staging wave reads back coefficient words it has written itself, in program order)
-  if (!EARLY) __syncthreads();              // coef[] visible
-  if (!EARLY && !stager) asm volatile("" ::"v"(wpf));
+  __syncthreads();                          // coef[] visible
+  if (!stager) asm volatile("" ::"v"(wpf));
   AVA_STAMP(1, t == 0);
 
   if (stager) {
@@ -323,7 +303,6 @@ __global__ __launch_bounds__(512) void conv3x3_mfma_ws_kernel(const ConvArgs a) 
       }
   };
   if (EPI == EPI_BWD && walk.valid()) load_ex(walk.cur);
-  if constexpr (EARLY) asm volatile("" ::"v"(wpf));
   AVA_STAMP(3, t == 256);
   __syncthreads();                                              // (A)
   AVA_STAMP(4, t == 256);

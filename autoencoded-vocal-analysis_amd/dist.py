@@ -8,6 +8,7 @@ not a mean, because the reference loss is a sum over the batch (vae.py:316-323).
 
 Nothing here is needed (or touched) when torch.distributed is not initialised.
 """
+import contextlib
 import math
 
 import torch
@@ -81,13 +82,86 @@ def shard_of(offset, count):
     return offset + rank() * part, part
 
 
+# ---- several ranks on ONE GPU (the two-rank tests on a 1-GPU box) ------------------------------------------------------
+# Two PROCESSES with kernels on the chip at the same time are not bit-reproducible on this pool: in one run out of ten a few
+# workgroups of a kernel with long-lived register accumulators (convt7's forward, which also forms its weight gradient) come
+# back with a handful of those accumulators perturbed -- the same two processes taking turns, or running without the other,
+# or one process with several streams never show it (tools/lab/share_probe.py, profiles/NOTES.md item 43: the signature of
+# the driver's wave save / restore between processes, nothing a kernel can order).  Ranks that share a device therefore
+# take turns: a test installs a lock shared by its ranks (``gpu_turn``), holds it while it computes, and the blocking
+# host-side collectives below give it up for their duration (``_off_gpu``).  Never set outside such tests.
+_gpu_turn = None
+
+
+@contextlib.contextmanager
+def gpu_turn(lock):
+    """Hold ``lock`` (shared by the ranks that share this GPU) for the body, except inside this module's collectives."""
+    global _gpu_turn
+    if lock is None:
+        yield
+        return
+    _gpu_turn = lock
+    lock.acquire()
+    try:
+        yield
+    finally:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        lock.release()
+        _gpu_turn = None
+
+
+@contextlib.contextmanager
+def _off_gpu():
+    """Around a blocking host-side collective: this rank's kernels are done, the other rank may have the GPU meanwhile."""
+    lock = _gpu_turn
+    if lock is None:
+        yield
+        return
+    torch.cuda.synchronize()
+    lock.release()
+    try:
+        yield
+    finally:
+        lock.acquire()
+
+
+off_gpu = _off_gpu          # for test code that calls torch.distributed itself while it holds the turn
+
+
+class _Done:
+    """Handle of a collective that is complete already."""
+    def wait(self):
+        return True
+
+
+def _through_host(t):
+    """A device tensor on a backend other than RCCL (gloo: the two-rank tests, two processes on ONE GPU) goes through the
+    host by plain synchronous copies, so that gloo only ever sees CPU tensors (the path tests/test_cpu_dist.py runs) and the
+    copies happen while this rank holds its turn on the GPU (``gpu_turn``): torch's gloo path for device tensors copies on
+    worker threads and pool streams at times of its own choosing, i.e. while the OTHER rank computes.  The bookkeeping of
+    the deferred path (pending handles, per-bucket Adam) is exercised unchanged, its overlap is not -- that is RCCL's to
+    show."""
+    return t.is_cuda and td.get_backend() != "nccl"
+
+
+def _all_reduce_async(t, op):
+    if _through_host(t):
+        host = t.detach().cpu()                    # waits for the kernels that produce t (current stream)
+        with _off_gpu():
+            td.all_reduce(host, op=op)
+        t.copy_(host)
+        return _Done()
+    return td.all_reduce(t, op=op, async_op=True)
+
+
 def reduce_scatter_bucket_async(flat_grads, offset, count):
     """SUM of one gradient bucket over the ranks, delivered to its owner slices only (in place: rank r's slice of the
     bucket receives the reduced values).  RCCL: reduce_scatter_tensor; gloo has no reduce-scatter: all-reduce."""
     bucket = flat_grads[offset:offset + count]
     sh = shard_of(offset, count)
     if sh is None or td.get_backend() != "nccl":
-        return td.all_reduce(bucket, op=td.ReduceOp.SUM, async_op=True)
+        return _all_reduce_async(bucket, td.ReduceOp.SUM)
     return td.reduce_scatter_tensor(flat_grads[sh[0]:sh[0] + sh[1]], bucket, op=td.ReduceOp.SUM, async_op=True)
 
 
@@ -95,6 +169,13 @@ def all_gather_bucket_async(flat, offset, count):
     """Every rank's slice of flat[offset:offset+count] to every rank (in place)."""
     sh = shard_of(offset, count)
     bucket = flat[offset:offset + count]
+    if _through_host(bucket):
+        mine = flat[sh[0]:sh[0] + sh[1]].detach().cpu()
+        parts = [torch.empty_like(mine) for _ in range(world_size())]
+        with _off_gpu():
+            td.all_gather(parts, mine)
+        bucket.copy_(torch.cat(parts))
+        return _Done()
     try:
         return td.all_gather_into_tensor(bucket, flat[sh[0]:sh[0] + sh[1]].clone(), async_op=True)
     except (RuntimeError, NotImplementedError):
@@ -105,7 +186,7 @@ def all_gather_bucket_async(flat, offset, count):
 def allreduce_gradients(flat_grads):
     """In-place SUM over ranks of the flat gradient arena (backend 'nccl' is RCCL on ROCm)."""
     if active():
-        td.all_reduce(flat_grads, op=td.ReduceOp.SUM)
+        _all_reduce_async(flat_grads, td.ReduceOp.SUM).wait()
     return flat_grads
 
 
@@ -115,7 +196,7 @@ def allreduce_gradients_async(flat_slice):
     compute enqueued afterwards overlaps with it."""
     if not active():
         return None
-    return td.all_reduce(flat_slice, op=td.ReduceOp.SUM, async_op=True)
+    return _all_reduce_async(flat_slice, td.ReduceOp.SUM)
 
 
 def wait_all(handles):
@@ -134,7 +215,7 @@ def wait_all(handles):
 def allreduce_max_(t):
     """In-place MAX over ranks (status words)."""
     if active():
-        td.all_reduce(t, op=td.ReduceOp.MAX)
+        _all_reduce_async(t, td.ReduceOp.MAX).wait()
     return t
 
 
@@ -142,14 +223,20 @@ def allreduce_max_async(t):
     """MAX over ranks enqueued like a gradient bucket (status words); returns the work handle."""
     if not active():
         return None
-    return td.all_reduce(t, op=td.ReduceOp.MAX, async_op=True)
+    return _all_reduce_async(t, td.ReduceOp.MAX)
 
 
 def broadcast_parameters(model, src=0):
     """Identical weights / BatchNorm buffers / Adam state on every rank."""
     if active():
         for t in (model._params, model._exp_avg, model._exp_avg_sq, model._bn_running, model._bn_batches):
-            td.broadcast(t, src=src)
+            if _through_host(t):
+                host = t.detach().cpu()
+                with _off_gpu():
+                    td.broadcast(host, src=src)
+                t.copy_(host)
+            else:
+                td.broadcast(t, src=src)
 
 
 def per_call_constants(z_dim, model_precision, x_dim=X_DIM):
@@ -164,7 +251,10 @@ def global_loss(local_sum, z_dim, model_precision, num_batches, x_dim=X_DIM):
     if not active():
         return float(local_sum.item())
     t = local_sum.detach().clone().double().reshape(1)
-    td.all_reduce(t, op=td.ReduceOp.SUM)
+    if _through_host(t):
+        t = t.cpu()
+    with _off_gpu():
+        td.all_reduce(t, op=td.ReduceOp.SUM)
     n = world_size()
     return float(t.item()) - (n - 1) * num_batches * per_call_constants(z_dim, model_precision, x_dim)
 
@@ -176,5 +266,6 @@ def global_dataset_len(local_len):
     t = torch.tensor([float(local_len)], dtype=torch.float64)
     if td.get_backend() == "nccl":
         t = t.cuda()
-    td.all_reduce(t, op=td.ReduceOp.SUM)
+    with _off_gpu():
+        td.all_reduce(t, op=td.ReduceOp.SUM)
     return int(round(float(t.item())))

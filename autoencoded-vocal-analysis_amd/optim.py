@@ -75,9 +75,7 @@ class FlatAdam(torch.optim.Adam):
             # Sharded form (dist.sharded_adam): this rank's slice of every bucket, then the parameters to everyone.
             sharded = m._sharded_adam()
             pending = {b: h for b, h in m._take_pending_comm()}
-            # every work handle stays alive until the step is complete (a handle owns the staging buffers of its collective;
-            # torch's gloo path -- the CPU-side test backend -- gave run-to-run different sums at the SECOND step when the
-            # handles were dropped one by one while later collectives were still in flight)
+            # every work handle stays alive until the step is complete (a handle owns the staging buffers of its collective)
             alive = list(pending.values())
             if None in pending:
                 _dist.wait_all([pending.pop(None)])       # the status word's MAX: the kernel's guard reads it

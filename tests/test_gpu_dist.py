@@ -1,7 +1,8 @@
 """The data-parallel path of VAE on the GPU with TWO processes: backward in parts, every gradient bucket all-reduced
 (SUM) asynchronously as its part completes, global loss, Adam on the reduced gradient.  The gpurun boxes have one
 GPU, so both ranks share cuda:0 and the collective runs over gloo (which stages device tensors through the host);
-RCCL itself is exercised by `bench.py --gpus N` on a multi-GPU node.  Pinned by the reference-generated two-shard
+RCCL itself is exercised by `bench.py --gpus N` on a multi-GPU node.  The two ranks take turns on the GPU (`_take_turns`): two processes with
+kernels on the chip at the same time are not bit-reproducible on this pool (profiles/NOTES.md item 43).  Pinned by the reference-generated two-shard
 golden (tests/golden/ddp2.npz): each shard run separately from identical weights, gradients summed."""
 import os
 import sys
@@ -16,7 +17,31 @@ from conftest import load_golden, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _take_turns(turn):
+    """First thing in a worker: this rank holds the lock `turn` (shared by the ranks of the test, which share ONE GPU) from
+    init_process_group to destroy_process_group, except inside ava_amd.dist's blocking collectives -- two processes with
+    kernels on the chip at the same time are not bit-reproducible on this pool (ava_amd/dist.py: gpu_turn)."""
+    if turn is None:
+        return
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    from ava_amd import dist as adist
+    cm = adist.gpu_turn(turn)
+    init, destroy = td.init_process_group, td.destroy_process_group
+
+    def init_then_take(*a, **k):
+        r = init(*a, **k)
+        cm.__enter__()
+        return r
+
+    def give_then_destroy(*a, **k):
+        cm.__exit__(None, None, None)
+        return destroy(*a, **k)
+    td.init_process_group, td.destroy_process_group = init_then_take, give_then_destroy
+
+
+def _worker(rank, world, port, q, turn=None):
+    _take_turns(turn)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -56,7 +81,8 @@ def test_two_rank_step_on_gpu():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    turn = ctx.Lock()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q), kwargs={"turn": turn}) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -79,7 +105,8 @@ def test_two_rank_step_on_gpu():
     assert res[0][2] == res[1][2] and res[0][5] == res[1][5]   # identical reduced gradients and updated parameters
 
 
-def _nan_worker(rank, world, port, q):
+def _nan_worker(rank, world, port, q, turn=None):
+    _take_turns(turn)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -110,7 +137,8 @@ def _nan_worker(rank, world, port, q):
         same = (model._params == before) | (torch.isnan(model._params) & torch.isnan(before))
         # a collective after the raise: hangs (test time-out) unless BOTH ranks left the epoch at the same step
         t = torch.ones(1)
-        td.all_reduce(t)
+        with adist.off_gpu():
+            td.all_reduce(t)
         q.put((rank, raised, len(steps), bool(same.all()), int(model.optimizer._step_count_flat), float(t.item())))
     finally:
         td.destroy_process_group()
@@ -123,7 +151,8 @@ def test_invalid_posterior_on_one_rank_stops_every_rank_at_the_same_step():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, q)) for r in range(2)]
+    turn = ctx.Lock()
+    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, q), kwargs={"turn": turn}) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in procs)
@@ -138,7 +167,8 @@ def test_invalid_posterior_on_one_rank_stops_every_rank_at_the_same_step():
     assert t0 == 2.0 and t1 == 2.0
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, turn=None):
+    _take_turns(turn)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -182,7 +212,8 @@ def test_sharded_adam_equals_allreduce_adam():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    turn = ctx.Lock()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q), kwargs={"turn": turn}) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in procs)
@@ -193,7 +224,8 @@ def test_sharded_adam_equals_allreduce_adam():
     assert res[0][2] == res[1][2]
 
 
-def _bucket_adam_worker(rank, world, port, q, backend="gloo"):
+def _bucket_adam_worker(rank, world, port, q, backend="gloo", turn=None):
+    _take_turns(turn)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -244,7 +276,8 @@ def _run_two(worker, port_base, *extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = port_base + (os.getpid() % 2000)
-    procs = [ctx.Process(target=worker, args=(r, 2, port, q) + extra) for r in range(2)]
+    kw = {} if worker is _nccl_worker else {"turn": ctx.Lock()}       # ranks that share ONE GPU take turns on it
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q) + extra, kwargs=kw) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in procs)
@@ -268,7 +301,8 @@ def test_per_bucket_adam_behind_its_own_allreduce_equals_flat_adam():
     assert res[0][2] == res[1][2]
 
 
-def _test_epoch_worker(rank, world, port, q):
+def _test_epoch_worker(rank, world, port, q, turn=None):
+    _take_turns(turn)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -288,8 +322,11 @@ def _test_epoch_worker(rank, world, port, q):
         # identical again: eval mode must then be a pure function of the weights and the data
         shard = DataLoader(Subset(ds, list(range(rank * n // 2, (rank + 1) * n // 2))), batch_size=B, shuffle=False)
         model.train_epoch(shard)
-        td.broadcast(model._bn_running, src=0)
-        td.broadcast(model._bn_batches, src=0)
+        for t in (model._bn_running, model._bn_batches):    # through the host: gloo only sees CPU tensors (dist._through_host)
+            host = t.cpu()
+            with adist.off_gpu():
+                td.broadcast(host, src=0)
+            t.copy_(host)
         # test_epoch samples z like the reference (vae.py:313 inside forward): zero noise makes the loss a function of the data
         model.noise_source = lambda b, zz: (np.zeros(b, np.float32), np.zeros((b, zz), np.float32))
         got = model.test_epoch(shard)                       # this rank's half; returns the GLOBAL mean

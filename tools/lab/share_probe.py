@@ -22,13 +22,15 @@ def worker(rank, q, parts, barrier, lock=None):
     snaps = []
     ws = []; regions = []
     barrier.wait()
+    whole = os.environ.get("SHARE_PROBE_WHOLE_RUN_TURNS") == "1"     # the lock is held for a whole run (model set-up + both steps)
     for run in range(6):
+        if whole and lock is not None: lock.acquire()
         model = build_model(z)
         model.noise_source = lambda b, zz: (ew[sl], ed[sl])
         s = []
         for step in (1, 2):
-            barrier.wait()                              # lock-step with the other process, as blocking collectives would force
-            if lock is not None: lock.acquire()         # ... but only one process at a time has kernels on the GPU
+            if not whole: barrier.wait()                # lock-step with the other process, as blocking collectives would force
+            if lock is not None and not whole: lock.acquire()         # ... but only one process at a time has kernels on the GPU
             model.optimizer.zero_grad()
             model._forward_device(x, need_grad=True)
             fwd = (model._loss_buf.clone(), model._workspace_tensor("xrec", (B, 128, 128)).clone())
@@ -42,7 +44,7 @@ def worker(rank, q, parts, barrier, lock=None):
                 model._backward_device(x)
             model.optimizer.step()
             torch.cuda.synchronize()
-            if lock is not None: lock.release()
+            if lock is not None and not whole: lock.release()
             s.append((model._grads.clone(), model._params.clone(), fwd[0], fwd[1]))
             if step == 1:
                 ws.append((ws_f, model._workspace.clone(), model._workspace.data_ptr()))
@@ -55,6 +57,7 @@ def worker(rank, q, parts, barrier, lock=None):
                         ptr = C.ava_debug_buffer(model._handle, nm.encode(), ctypes.byref(n))
                         if ptr: regions.append(((ptr - model._workspace.data_ptr()) // 4, n.value, nm))
         snaps.append(s)
+        if whole and lock is not None: lock.release()
     out = []
     for step in (0, 1):
         for what in (0, 1, 2, 3):
@@ -74,7 +77,8 @@ def worker(rank, q, parts, barrier, lock=None):
     reg = {nm: (o, n) for o, n, nm in regions}
     wg13 = reg["dF8"][0] - 74752                       # wg_part[13]: 1024 rows x 73 floats in front of dF8 (model.hip: carve)
     slot27 = reg["bn_bwd"][0] + reg["bn_bwd"][1] + 27 * 3200      # bn_acc slot 27 (1600 int64): what the fold adds bn14's backward sums to
-    for r in range(1, len(ws)):
+    fold_on = os.environ.get("AVA_FOLD13", "1") != "0"       # (lab build: with the fold off the forward leaves these regions unwritten)
+    for r in range(1, len(ws) if fold_on else 0):
         a = ws[0][0].view(torch.float32); b = ws[r][0].view(torch.float32)
         wa = a[wg13:wg13 + 128 * 73].view(128, 73); wb = b[wg13:wg13 + 128 * 73].view(128, 73)
         if not torch.equal(wa, wb):
@@ -88,6 +92,14 @@ def worker(rank, q, parts, barrier, lock=None):
         if not torch.equal(la, lb):
             ii = (la != lb).nonzero().flatten().tolist()
             out.append("after forward, run %d: bn_acc slot 27 words that differ: %s" % (r, ["%d: %d / %d" % (k, int(la[k]), int(lb[k])) for k in ii[:16]]))
+    cls = []
+    for r in range(len(snaps)):
+        for k, rep in enumerate(cls):
+            if torch.equal(snaps[rep][0][0], snaps[r][0][0]): break
+        else:
+            cls.append(r)
+    if len(cls) > 1:
+        out.append("step-1 gradients: %d distinct results over %d runs (first run of each: %s)" % (len(cls), len(snaps), cls))
     # which parameters' gradients differ at step 1 (backward order: convt7 ... convt1, fc8 ... fc1, conv7 ... conv1)
     from ava_amd import layout
     offs, total = layout.arena_offsets(z)

@@ -8,7 +8,6 @@ not a mean, because the reference loss is a sum over the batch (vae.py:316-323).
 
 Nothing here is needed (or touched) when torch.distributed is not initialised.
 """
-import contextlib
 import math
 
 import torch
@@ -82,77 +81,28 @@ def shard_of(offset, count):
     return offset + rank() * part, part
 
 
-# ---- several ranks on ONE GPU (the two-rank tests on a 1-GPU box) ------------------------------------------------------
-# Two PROCESSES with kernels on the chip at the same time are not bit-reproducible on this pool: in one run out of ten a few
-# workgroups of a kernel with long-lived register accumulators (convt7's forward, which also forms its weight gradient) come
-# back with a handful of those accumulators perturbed -- the same two processes taking turns, or running without the other,
-# or one process with several streams never show it (tools/lab/share_probe.py, profiles/NOTES.md item 43: the signature of
-# the driver's wave save / restore between processes, nothing a kernel can order).  Ranks that share a device therefore
-# take turns: a test installs a lock shared by its ranks (``gpu_turn``), holds it while it computes, and the blocking
-# host-side collectives below give it up for their duration (``_off_gpu``).  Never set outside such tests.
-_gpu_turn = None
+# ---- the three collective primitives everything below goes through -------------------------------------------------------
+# (one seam: tests that put two ranks on ONE GPU replace these three with host-staged, turn-taking forms of their own --
+# tests/gpu_util.py: take_turns -- the product module carries no test code)
+def _all_reduce(t, op, async_op=False):
+    """td.all_reduce; with ``async_op`` the work handle (RCCL: ordered on the compute stream by ``wait()``)."""
+    return td.all_reduce(t, op=op, async_op=async_op)
 
 
-@contextlib.contextmanager
-def gpu_turn(lock):
-    """Hold ``lock`` (shared by the ranks that share this GPU) for the body, except inside this module's collectives."""
-    global _gpu_turn
-    if lock is None:
-        yield
-        return
-    _gpu_turn = lock
-    lock.acquire()
+def _all_gather_into(bucket, mine):
+    """Every rank's ``mine`` (equal sizes) into ``bucket``, asynchronously; returns the work handle."""
     try:
-        yield
-    finally:
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        lock.release()
-        _gpu_turn = None
+        return td.all_gather_into_tensor(bucket, mine, async_op=True)
+    except (RuntimeError, NotImplementedError):
+        return td.all_gather(list(bucket.chunk(world_size())), mine, async_op=True)
 
 
-@contextlib.contextmanager
-def _off_gpu():
-    """Around a blocking host-side collective: this rank's kernels are done, the other rank may have the GPU meanwhile."""
-    lock = _gpu_turn
-    if lock is None:
-        yield
-        return
-    torch.cuda.synchronize()
-    lock.release()
-    try:
-        yield
-    finally:
-        lock.acquire()
-
-
-off_gpu = _off_gpu          # for test code that calls torch.distributed itself while it holds the turn
-
-
-class _Done:
-    """Handle of a collective that is complete already."""
-    def wait(self):
-        return True
-
-
-def _through_host(t):
-    """A device tensor on a backend other than RCCL (gloo: the two-rank tests, two processes on ONE GPU) goes through the
-    host by plain synchronous copies, so that gloo only ever sees CPU tensors (the path tests/test_cpu_dist.py runs) and the
-    copies happen while this rank holds its turn on the GPU (``gpu_turn``): torch's gloo path for device tensors copies on
-    worker threads and pool streams at times of its own choosing, i.e. while the OTHER rank computes.  The bookkeeping of
-    the deferred path (pending handles, per-bucket Adam) is exercised unchanged, its overlap is not -- that is RCCL's to
-    show."""
-    return t.is_cuda and td.get_backend() != "nccl"
+def _broadcast(t, src):
+    td.broadcast(t, src=src)
 
 
 def _all_reduce_async(t, op):
-    if _through_host(t):
-        host = t.detach().cpu()                    # waits for the kernels that produce t (current stream)
-        with _off_gpu():
-            td.all_reduce(host, op=op)
-        t.copy_(host)
-        return _Done()
-    return td.all_reduce(t, op=op, async_op=True)
+    return _all_reduce(t, op, async_op=True)
 
 
 def reduce_scatter_bucket_async(flat_grads, offset, count):
@@ -168,25 +118,13 @@ def reduce_scatter_bucket_async(flat_grads, offset, count):
 def all_gather_bucket_async(flat, offset, count):
     """Every rank's slice of flat[offset:offset+count] to every rank (in place)."""
     sh = shard_of(offset, count)
-    bucket = flat[offset:offset + count]
-    if _through_host(bucket):
-        mine = flat[sh[0]:sh[0] + sh[1]].detach().cpu()
-        parts = [torch.empty_like(mine) for _ in range(world_size())]
-        with _off_gpu():
-            td.all_gather(parts, mine)
-        bucket.copy_(torch.cat(parts))
-        return _Done()
-    try:
-        return td.all_gather_into_tensor(bucket, flat[sh[0]:sh[0] + sh[1]].clone(), async_op=True)
-    except (RuntimeError, NotImplementedError):
-        parts = list(bucket.chunk(world_size()))
-        return td.all_gather(parts, flat[sh[0]:sh[0] + sh[1]].clone(), async_op=True)
+    return _all_gather_into(flat[offset:offset + count], flat[sh[0]:sh[0] + sh[1]].clone())
 
 
 def allreduce_gradients(flat_grads):
     """In-place SUM over ranks of the flat gradient arena (backend 'nccl' is RCCL on ROCm)."""
     if active():
-        _all_reduce_async(flat_grads, td.ReduceOp.SUM).wait()
+        _all_reduce(flat_grads, td.ReduceOp.SUM)
     return flat_grads
 
 
@@ -215,7 +153,7 @@ def wait_all(handles):
 def allreduce_max_(t):
     """In-place MAX over ranks (status words)."""
     if active():
-        _all_reduce_async(t, td.ReduceOp.MAX).wait()
+        _all_reduce(t, td.ReduceOp.MAX)
     return t
 
 
@@ -230,13 +168,7 @@ def broadcast_parameters(model, src=0):
     """Identical weights / BatchNorm buffers / Adam state on every rank."""
     if active():
         for t in (model._params, model._exp_avg, model._exp_avg_sq, model._bn_running, model._bn_batches):
-            if _through_host(t):
-                host = t.detach().cpu()
-                with _off_gpu():
-                    td.broadcast(host, src=src)
-                t.copy_(host)
-            else:
-                td.broadcast(t, src=src)
+            _broadcast(t, src)
 
 
 def per_call_constants(z_dim, model_precision, x_dim=X_DIM):
@@ -251,12 +183,28 @@ def global_loss(local_sum, z_dim, model_precision, num_batches, x_dim=X_DIM):
     if not active():
         return float(local_sum.item())
     t = local_sum.detach().clone().double().reshape(1)
-    if _through_host(t):
-        t = t.cpu()
-    with _off_gpu():
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+    _all_reduce(t, td.ReduceOp.SUM)
     n = world_size()
     return float(t.item()) - (n - 1) * num_batches * per_call_constants(z_dim, model_precision, x_dim)
+
+
+def check_equal_batches(num_batches, what="epoch"):
+    """Every rank must run the SAME number of steps per epoch: each step holds collectives (the gradient buckets, the
+    status word's MAX), and ``global_loss`` removes ``(N-1) * num_batches`` copies of the per-call constants -- with ragged
+    shards the ranks would deadlock in mismatched collectives or report different losses.  One MAX all-reduce of
+    ``[n, -n]`` before the first step; raises ``ValueError`` on every rank when the counts differ (shard with
+    ``DistributedSampler(drop_last=True)`` or pad the shorter shard)."""
+    if not active():
+        return num_batches
+    t = torch.tensor([float(num_batches), -float(num_batches)], dtype=torch.float64)
+    if td.get_backend() == "nccl":
+        t = t.cuda()
+    _all_reduce(t, td.ReduceOp.MAX)
+    hi, lo = int(round(float(t[0].item()))), int(round(-float(t[1].item())))
+    if hi != lo:
+        raise ValueError("data parallel %s: the ranks' loaders have different numbers of batches (%d..%d, this rank %d); "
+                         "every rank must run the same number of steps" % (what, lo, hi, num_batches))
+    return num_batches
 
 
 def global_dataset_len(local_len):
@@ -266,6 +214,5 @@ def global_dataset_len(local_len):
     t = torch.tensor([float(local_len)], dtype=torch.float64)
     if td.get_backend() == "nccl":
         t = t.cuda()
-    with _off_gpu():
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+    _all_reduce(t, td.ReduceOp.SUM)
     return int(round(float(t.item())))

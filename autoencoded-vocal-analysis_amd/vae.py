@@ -574,6 +574,7 @@ class VAE(nn.Module):
         self.train()
         self._loss_acc.zero_()
         batch_idx = -1
+        self._check_equal_shards(train_loader, "train_epoch")
         for batch_idx, data in enumerate(self._feed(train_loader)):
             self.optimizer.zero_grad()
             data = self._prep_x(data)
@@ -583,17 +584,41 @@ class VAE(nn.Module):
             self._poll_status()
         self._check_status()
         train_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, batch_idx + 1, self.x_dim)
-        train_loss /= _dist.global_dataset_len(len(train_loader.dataset))
+        train_loss /= self._global_len(train_loader)
         if _dist.rank() == 0:
             print('Epoch: {} Average loss: {:.4f}'.format(self.epoch, train_loss))
         self.epoch += 1
         return train_loss
+
+    def _global_len(self, loader):
+        """len(loader.dataset) over all ranks (single process: the local length, as the reference divides by,
+        vae.py:355,383).  A collective under data parallelism, so it is computed once per dataset and remembered."""
+        n = len(loader.dataset)
+        if not _dist.active():
+            return n
+        cache = self.__dict__.setdefault("_global_len_cache", {})
+        key = (id(loader.dataset), n)
+        if key not in cache:
+            cache[key] = _dist.global_dataset_len(n)
+        return cache[key]
+
+    def _check_equal_shards(self, loader, what):
+        """Data parallel: every rank must run the same number of steps (dist.check_equal_batches: one 16-byte MAX
+        all-reduce at the start of every epoch, entered by every rank)."""
+        if not _dist.active():
+            return
+        try:
+            nb = len(loader)
+        except TypeError:
+            nb = -1                                     # an iterable without a length: still enter the collective
+        _dist.check_equal_batches(nb, what)
 
     def test_epoch(self, test_loader):
         """Mean -ELBO per sample with BatchNorm on running statistics (vae.py:361-385)."""
         self.eval()
         self._loss_acc.zero_()
         i = -1
+        self._check_equal_shards(test_loader, "test_epoch")
         with torch.no_grad():
             for i, data in enumerate(self._feed(test_loader)):
                 data = self._prep_x(data)
@@ -603,7 +628,7 @@ class VAE(nn.Module):
         # like train_epoch's (eval mode has no per-rank BatchNorm statistics, so it equals the single-process value on the
         # concatenated data up to summation order).  Single process: the reference's expression unchanged.
         test_loss = _dist.global_loss(self._loss_acc, self.z_dim, self.model_precision, i + 1, self.x_dim)
-        test_loss /= _dist.global_dataset_len(len(test_loader.dataset))
+        test_loss /= self._global_len(test_loader)
         if _dist.rank() == 0:
             print('Test loss: {:.4f}'.format(test_loss))
         return test_loss
@@ -613,12 +638,12 @@ class VAE(nn.Module):
         if _dist.rank() == 0:               # data parallel: one banner, one PDF (rank 0's shard); single process: as the reference
             print("=" * 40)
             print("Training: epochs", self.epoch, "to", self.epoch + epochs - 1)
-            print("Training set:", _dist.global_dataset_len(len(loaders['train'].dataset)) if _dist.active() else len(loaders['train'].dataset))
-            print("Test set:", _dist.global_dataset_len(len(loaders['test'].dataset)) if _dist.active() else len(loaders['test'].dataset))
+            print("Training set:", self._global_len(loaders['train']))
+            print("Test set:", self._global_len(loaders['test']))
             print("=" * 40)
-        elif _dist.active():                # (the two dataset lengths are collectives: every rank enters them)
-            _dist.global_dataset_len(len(loaders['train'].dataset))
-            _dist.global_dataset_len(len(loaders['test'].dataset))
+        elif _dist.active():                # (the two dataset lengths are collectives: every rank enters them, once per loader)
+            self._global_len(loaders['train'])
+            self._global_len(loaders['test'])
         for epoch in range(self.epoch, self.epoch + epochs):
             loss = self.train_epoch(loaders['train'])
             self.loss['train'][epoch] = loss

@@ -1,8 +1,9 @@
 """The data-parallel path of VAE on the GPU with TWO processes: backward in parts, every gradient bucket all-reduced
 (SUM) asynchronously as its part completes, global loss, Adam on the reduced gradient.  The gpurun boxes have one
 GPU, so both ranks share cuda:0 and the collective runs over gloo (which stages device tensors through the host);
-RCCL itself is exercised by `bench.py --gpus N` on a multi-GPU node.  The two ranks take turns on the GPU (`_take_turns`): two processes with
-kernels on the chip at the same time are not bit-reproducible on this pool (profiles/NOTES.md item 43).  Pinned by the reference-generated two-shard
+RCCL itself is exercised by `bench.py --gpus N` on a multi-GPU node.  The two ranks take turns on the GPU (tests/turns.py): two processes with
+kernels on the chip at the same time are not bit-reproducible on this pool (profiles/NOTES.md items 43, 44); one test runs them
+concurrently on the product's own asynchronous path and tracks how often that shows.  Pinned by the reference-generated two-shard
 golden (tests/golden/ddp2.npz): each shard run separately from identical weights, gradients summed."""
 import os
 import sys
@@ -13,31 +14,9 @@ import torch
 import torch.multiprocessing as mp
 
 from conftest import load_golden, ROOT
+from turns import take_turns as _take_turns, off_gpu as _off_gpu
 
 pytestmark = pytest.mark.gpu
-
-
-def _take_turns(turn):
-    """First thing in a worker: this rank holds the lock `turn` (shared by the ranks of the test, which share ONE GPU) from
-    init_process_group to destroy_process_group, except inside ava_amd.dist's blocking collectives -- two processes with
-    kernels on the chip at the same time are not bit-reproducible on this pool (ava_amd/dist.py: gpu_turn)."""
-    if turn is None:
-        return
-    sys.path.insert(0, ROOT)
-    import torch.distributed as td
-    from ava_amd import dist as adist
-    cm = adist.gpu_turn(turn)
-    init, destroy = td.init_process_group, td.destroy_process_group
-
-    def init_then_take(*a, **k):
-        r = init(*a, **k)
-        cm.__enter__()
-        return r
-
-    def give_then_destroy(*a, **k):
-        cm.__exit__(None, None, None)
-        return destroy(*a, **k)
-    td.init_process_group, td.destroy_process_group = init_then_take, give_then_destroy
 
 
 def _worker(rank, world, port, q, turn=None):
@@ -137,7 +116,7 @@ def _nan_worker(rank, world, port, q, turn=None):
         same = (model._params == before) | (torch.isnan(model._params) & torch.isnan(before))
         # a collective after the raise: hangs (test time-out) unless BOTH ranks left the epoch at the same step
         t = torch.ones(1)
-        with adist.off_gpu():
+        with _off_gpu():
             td.all_reduce(t)
         q.put((rank, raised, len(steps), bool(same.all()), int(model.optimizer._step_count_flat), float(t.item())))
     finally:
@@ -301,6 +280,38 @@ def test_per_bucket_adam_behind_its_own_allreduce_equals_flat_adam():
     assert res[0][2] == res[1][2]
 
 
+def test_per_bucket_adam_with_concurrent_ranks_and_asynchronous_handles(record_property):
+    """The same comparison with the two ranks running CONCURRENTLY on the one GPU and nothing replaced in ava_amd.dist:
+    the gradient buckets are genuine `async_op=True` gloo work handles of device tensors, left in flight by the backward and
+    consumed one by one by FlatAdam.step.  Two processes with kernels on the chip at once are not bit-reproducible on this
+    pool (profiles/NOTES.md items 43, 44: about one run in ten, relative 1e-3 on a few weight-gradient partial sums of
+    convt7), so bit-identity is RECORDED here (property `bit_identical`, a warning when it fails) and the assertion is a
+    tolerance: everything the deferred path hands to Adam is the flat path's to 1e-2 of the largest entry per bucket, and
+    the bookkeeping (pending handles consumed, buckets tile the arena) is exact."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_adam_worker, args=(r, 2, port, q)) for r in range(2)]      # turn=None: concurrent
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exact = all(all(same) for _, same, _, _, _, _ in res)
+    record_property("bit_identical", exact)
+    if not exact:
+        import warnings
+        warnings.warn("two concurrent processes on one GPU: deferred != flat bit for bit this time (NOTES item 43/44): %s"
+                      % [d for *_, d in res])
+    for rank, same, psum, bk, total, diffs in res:
+        assert len(bk) == 4 and sum(c for _, c in bk) == total
+        gdiff, pdiff = diffs[0], diffs[1]
+        assert max(gdiff) < 1e-2 * 50.0, diffs            # gradients: entries are O(1..50) at B = 8
+        assert max(pdiff) <= 2.1e-3, diffs                # parameters after two Adam steps of lr 1e-3: never more than 2 lr apart
+    assert abs(res[0][2] - res[1][2]) <= 1e-6 * abs(res[0][2])
+
+
 def _test_epoch_worker(rank, world, port, q, turn=None):
     _take_turns(turn)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -322,9 +333,9 @@ def _test_epoch_worker(rank, world, port, q, turn=None):
         # identical again: eval mode must then be a pure function of the weights and the data
         shard = DataLoader(Subset(ds, list(range(rank * n // 2, (rank + 1) * n // 2))), batch_size=B, shuffle=False)
         model.train_epoch(shard)
-        for t in (model._bn_running, model._bn_batches):    # through the host: gloo only sees CPU tensors (dist._through_host)
+        for t in (model._bn_running, model._bn_batches):    # through the host: gloo only sees CPU tensors (tests/turns.py)
             host = t.cpu()
-            with adist.off_gpu():
+            with _off_gpu():
                 td.broadcast(host, src=0)
             t.copy_(host)
         # test_epoch samples z like the reference (vae.py:313 inside forward): zero noise makes the loss a function of the data

@@ -236,6 +236,14 @@ static int conv3x3_thin_w(const ConvArgs& a0, int grid, int Cin, int Cout, int p
         if (a.epi_x == nullptr || a.out2 == nullptr || (a.fin.acc == nullptr && (a.fold.mean == nullptr || a.fold.invstd == nullptr)) ||
             (a.fold.acc_out == nullptr && a.fold.bn_partials == nullptr))
           return AVA_EINVAL;
+        // one resident wave of THIS kernel (more registers and LDS than the plain forward: two workgroups per CU at W = 128,
+        // one at W = 256; the smaller of the two activation types' answers so that both partition the tiles alike)
+        static const int fold_resident = [] {
+          const int rf = thin_resident(&thin_8to1_direct_fold_kernel<W, float>, W, 0);
+          const int rb = thin_resident(&thin_8to1_direct_fold_kernel<W, ava_bf16>, W, 0);
+          return rf < rb ? rf : rb;
+        }();
+        if (g > ava_scale_grid(fold_resident)) g = ava_scale_grid(fold_resident);
         if (a.act_bf16) hipLaunchKernelGGL((thin_8to1_direct_fold_kernel<W, ava_bf16>), dim3(g), block, 0, st, a);
         else hipLaunchKernelGGL((thin_8to1_direct_fold_kernel<W, float>), dim3(g), block, 0, st, a);
       }

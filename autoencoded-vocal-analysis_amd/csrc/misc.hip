@@ -7,6 +7,7 @@
 //  * adam_flat is torch.optim.Adam's single-tensor update (torch/optim/adam.py:414-547) over the
 //    whole flat parameter arena in one launch.
 #include "common.h"
+#include "bn_acc.h"
 
 #define LOG_2PI 1.8378770664093453
 
@@ -166,22 +167,60 @@ int ava_latent_bwd_scaled(const float* z, const float* dz_dec, const float* u, c
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }
-// v[i] *= scale[0] (the seed gradient of a backward whose root is not the loss itself)
-__global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ v, int64_t n4, const float* __restrict__ scale) {
+// A backward whose root is not the loss itself (d(result)/d(loss) = scale[0] != 1, ava_set_backward_scale): everything the
+// forward left behind for the backward is LINEAR in the seed prec * (xhat - x), so it is scaled in place, in one launch --
+//   * the seed itself (convt6's fused backward gathers convt7's data gradient from it),
+//   * convt7's weight / bias gradient partial rows formed by its training forward (conv_thin_kernels.h: FOLD), and
+//   * the two BatchNorm-backward sums of bn14 the same forward added to its accumulator slot (bn_acc.h): read in the
+//     consumer's fixed order, multiplied in fp64, the slot cleared and the products written back as exact limbs of shard 0.
+// scale[0] == 1 (loss.backward() with the loss as the root: autograd hands over a tensor of ones) returns at once without
+// touching memory: that path is bit-identical to ava_backward without a scale.
+__global__ __launch_bounds__(256) void scale_backward_roots_kernel(float* __restrict__ seed, int64_t n4, int seed_blocks,
+                                                                   float* __restrict__ wg, int64_t nwg,
+                                                                   long long* __restrict__ slot, const float* __restrict__ scale) {
   const float sc = scale[0];
-  float4* v4 = reinterpret_cast<float4*>(v);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float4 t = v4[i];
-    t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc;
-    v4[i] = t;
+  if (sc == 1.f) return;
+  if ((int)blockIdx.x < seed_blocks) {
+    float4* v4 = reinterpret_cast<float4*>(seed);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)seed_blocks * 256) {
+      float4 t = v4[i];
+      t.x *= sc; t.y *= sc; t.z *= sc; t.w *= sc;
+      v4[i] = t;
+    }
+    return;
+  }
+  const int wb = (int)blockIdx.x - seed_blocks, nwb = (int)gridDim.x - seed_blocks;
+  if (wg != nullptr)
+    for (int64_t i = (int64_t)wb * 256 + threadIdx.x; i < nwg; i += (int64_t)nwb * 256) wg[i] *= sc;
+  if (wb == 0 && slot != nullptr) {
+    const int t = threadIdx.x;
+    double v = 0.0;
+    if (t < 64) v = bn_acc_read(slot, t) * (double)sc;          // NaN when the slot is poisoned: re-poisoned below
+    __syncthreads();
+    for (int i = t; i < AVA_ACC_SLOT_LL; i += 256) slot[i] = 0;
+    __syncthreads();
+    if (t < 64) {
+      const double ad = fabs(v) * 0x1p48;
+      if (!(ad < 0x1p95)) slot[192] = 1;
+      else {
+        const double l2 = floor(ad * 0x1p-64), r1 = ad - l2 * 0x1p64;
+        const double l1 = floor(r1 * 0x1p-32), l0 = floor(r1 - l1 * 0x1p32);
+        const long long sg = v < 0.0 ? -1 : 1;
+        slot[t] = sg * (long long)l0; slot[64 + t] = sg * (long long)l1; slot[128 + t] = sg * (long long)l2;
+      }
+    }
   }
 }
-int ava_scale_inplace(float* v, int64_t n, const float* scale, hipStream_t st) {
-  if (v == nullptr || scale == nullptr || n % 4 != 0) return AVA_EINVAL;
-  int64_t n4 = n / 4;
-  int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(scale_inplace_kernel, dim3(blocks), dim3(256), 0, st, v, n4, scale);
+int ava_scale_backward_roots(float* seed, int64_t n, float* wg, int64_t nwg, long long* slot, const float* scale, hipStream_t st) {
+  if (seed == nullptr || scale == nullptr || n % 4 != 0) return AVA_EINVAL;
+  const int64_t n4 = n / 4;
+  int seed_blocks = (int)((n4 + 255) / 256);
+  if (seed_blocks > 2048) seed_blocks = 2048;
+  int wg_blocks = (wg != nullptr || slot != nullptr) ? (int)((nwg + 255) / 256) : 0;
+  if (wg_blocks > 256) wg_blocks = 256;
+  if ((wg != nullptr || slot != nullptr) && wg_blocks < 1) wg_blocks = 1;
+  hipLaunchKernelGGL(scale_backward_roots_kernel, dim3(seed_blocks + wg_blocks), dim3(256), 0, st, seed, n4, seed_blocks, wg, nwg,
+                     slot, scale);
   AVA_CHECK_LAUNCH();
   return AVA_OK;
 }

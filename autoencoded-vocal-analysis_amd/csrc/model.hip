@@ -36,7 +36,7 @@ int ava_bn_finalize_bwd_ex(const float* partials, int nparts, int64_t n, int C, 
 int ava_latent_bwd_scaled(const float* z, const float* dz_dec, const float* u, const float* d, const float* eps_w,
                           const float* eps_d, float* dmu, float* du, float* dlogd, int B, int zdim, const float* scale,
                           hipStream_t st);
-int ava_scale_inplace(float* v, int64_t n, const float* scale, hipStream_t st);
+int ava_scale_backward_roots(float* seed, int64_t n, float* wg, int64_t nwg, long long* slot, const float* scale, hipStream_t st);
 int ava_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                           double eps, int step, const int* skip_if_set, hipStream_t st);
 int ava_elbo_finalize_strided(const float* latent_sums, int B, const float* sse_partials, int nparts, int stride,
@@ -454,6 +454,7 @@ extern "C" int ava_model_create_ex(ava_model** out, int z_dim, int H, int W, int
   m->dbg["xrec"] = {m->xrec, (int64_t)B * XD}; m->dbg["seed"] = {m->seed, (int64_t)B * XD};
   m->dbg["bn_save"] = {m->bn_save, NCONV * 4 * 32}; m->dbg["bn_bwd"] = {m->bn_bwd, NCONV * 3 * 32};
   m->dbg["dz"] = {m->dz, (int64_t)B * z_dim}; m->dbg["dF8"] = {m->dF8, (int64_t)B * F};
+  m->dbg["wg13"] = {m->wg_part[NCONV - 1], (int64_t)wgrad_part_floats(m, (int)B, NCONV - 1)};   // convt7's weight-gradient partial rows
   // (no "dy7" entry: fc1's data gradient usually stays as two split-K slabs in dy7_ws, summed by the encoder's first kernel)
   *out = m;
   return AVA_OK;
@@ -1068,10 +1069,10 @@ static int conv_layer_backward(ava_model* m, int l, const float* x0, const float
   const int fgrid = fused_grid(m, l, B);
   if (l == 13) {
     // convt7: the training forward has already left this layer's weight-gradient partials and BatchNorm-backward sums behind
-    // (FOLD) and convt6's kernel forms its data gradient itself -- nothing to launch.  They are those of loss scale 1: with
-    // another scale (ava_set_backward_scale) the layer's accumulator slot is cleared and the separate kernel runs on the
-    // scaled seed, as it does after a forward that did not fold.
-    if (m->fold13 && m->bwd_scale == nullptr && dd6_fused(m)) return AVA_OK;
+    // (FOLD) and convt6's kernel forms its data gradient itself -- nothing to launch.  They are those of loss scale 1; both are
+    // linear in the seed, so a backward with another scale (ava_set_backward_scale) has had them multiplied in place together
+    // with the seed (backward_part0: ava_scale_backward_roots).  After a forward that did not fold the separate kernel runs.
+    if (m->fold13 && dd6_fused(m)) return AVA_OK;
     if (m->fold13) {
       if (hipMemsetAsync(acc_slot(m, 14 + l), 0, (size_t)AVA_ACC_SLOT_LL * sizeof(long long), st) != hipSuccess) return AVA_ELAUNCH;
       m->fold13 = 0;
@@ -1214,8 +1215,11 @@ static int backward_part0(ava_model* m, const float* x, int B, hipStream_t st, b
   float* gcur = m->gA;
   float* gnext = m->gB;
   mark(m, -1, st);
-  if (m->bwd_scale != nullptr) {       // d(result)/d(loss) != 1: scale the two roots of the backward (here and latent_bwd)
-    TRY(ava_scale_inplace(m->seed, (int64_t)B * m->H * m->W, m->bwd_scale, st));
+  if (m->bwd_scale != nullptr) {       // d(result)/d(loss) may differ from 1: scale the roots of the backward (here and latent_bwd)
+    const bool folded = m->fold13 && dd6_fused(m);          // ... and what convt7's forward left behind for this backward
+    // (a lab build without the fused gather reruns the separate kernel on the scaled seed instead: conv_layer_backward)
+    TRY(ava_scale_backward_roots(m->seed, (int64_t)B * m->H * m->W, folded ? m->wg_part[13] : nullptr,
+                                 folded ? (int64_t)m->wg13_rows * 73 : 0, folded ? acc_slot(m, 14 + 13) : nullptr, m->bwd_scale, st));
     mark(m, CAT_LAYOUT, st);
   }
   TRY(conv_layer_backward(m, 13, x, m->seed, nullptr, nullptr, nullptr, nullptr, PRO_ID, gcur, B, st));

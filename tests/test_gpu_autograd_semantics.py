@@ -78,6 +78,41 @@ def test_grad_output_scale_is_applied_on_the_device():
     assert err < 1e-6, err
 
 
+@pytest.mark.parametrize("shape,act,B", [((128, 128), "float32", 5), ((128, 128), "float32", 64), ((128, 128), "bfloat16", 7),
+                                         ((256, 256), "float32", 3), ((256, 256), "bfloat16", 8)])
+def test_loss_backward_and_the_epoch_loops_backward_are_the_same_path(shape, act, B):
+    """`loss.backward()` (the reference idiom, what every oracle-backed gradient test drives) always
+    hands a scale tensor to the device, which used to discard what convt7's training forward had left behind (its weight
+    gradient partials and bn14's backward sums: FOLD) and rerun the separate kernel -- so no oracle comparison ever saw
+    the fold's results, which are what `train_epoch` / bench.py (`_backward_device`, no scale) use.  Now a scale of exactly
+    1 leaves everything untouched on the device: both entry points must produce the SAME bits, per tensor, for both
+    activation types, both image widths and odd batch sizes; and a scale != 1 multiplies the fold's results in place."""
+    from ava_amd.vae import VAE
+    z = 32 if shape == (128, 128) else 128
+    torch.manual_seed(11)
+    model = VAE(z_dim=z, device_name="cuda", x_shape=shape, act_dtype=act)
+    model.train()
+    x = torch.from_numpy(syn.spectrograms(B, shape=shape)).cuda()
+    _fixed(model, B, z)
+    model.optimizer.zero_grad()
+    model.forward(x).backward()                               # scale tensor of ones -> fold kept
+    g_autograd = model._grads.clone()
+    model.optimizer.zero_grad()
+    model._forward_device(x, need_grad=True)
+    model._backward_device(x)                                 # the epoch loop's call: no scale at all
+    g_loop = model._grads.clone()
+    assert torch.equal(g_autograd, g_loop)
+    model.optimizer.zero_grad()
+    (model.forward(x) * 0.5).backward()                       # the fold's partial rows and bn14's sums scaled in place
+    g_half = model._grads.clone()
+    named = dict(model.named_parameters())
+    offs = model._arena_views
+    for name in named:
+        o, n, _ = offs[name]
+        a, b = g_half[o:o + n].double(), 0.5 * g_loop[o:o + n].double()
+        assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-30, name
+
+
 def test_backward_accumulates_until_zero_grad():
     B, z = 4, 32
     model = build_model(z)

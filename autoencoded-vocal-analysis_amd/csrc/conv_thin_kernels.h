@@ -67,6 +67,17 @@ struct ThinWeights {
 // not fit beside the kernel's other scalars and hipcc spills them to VGPR lanes (125 v_readlane + 89 v_writelane per tile
 // in the first version); the empty asm keeps hipcc from re-reading them from memory inside the tile loop.
 typedef float avaf2 __attribute__((ext_vector_type(2)));
+// A scalar that is BROADCAST into both halves of a packed-FMA operand must not be the ODD register of a wider value (the second
+// dword of a ds_read2_b32, element 1 or 3 of a 16-byte load): hipcc then selects it with op_sel (v_pk_fma_f32 ... op_sel:[0,1,0]),
+// and on gfx950 that form returns a WRONG low-half result in lanes 48..63 while a wave of another kernel that interleaves
+// v_mfma_f32_16x16x32_bf16 with vector instructions shares the SIMD -- a second stream or a second process; never within one
+// stream (tools/lab/two_proc_repro.hip: a stand-alone reproducer with no code of this library; profiles/NOTES.md item 44).
+// Passing the scalar through an empty asm makes it a register of its own: the broadcast then reads the LOW register of an aligned
+// pair (op_sel_hi:[1,0,1]), which is not affected.  tools/lab/op_sel_scan.py checks the built code objects for the bad form.
+__device__ __forceinline__ float ava_pin(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 struct ThinPairWeights {
   avaf2 w[9][4];                                        // [tap][channel pair]
   __device__ __forceinline__ explicit ThinPairWeights(const float* __restrict__ G) {
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(2 * W, W == 128 ? 4 : 2) void thin_1to8_kernel(cons
     for (int kx = 0; kx < 3; ++kx) {
       float in[THIN_IR];
 #pragma unroll
-      for (int j = 0; j < THIN_IR; ++j) in[j] = tile[j * THIN_IC + x + kx];
+      for (int j = 0; j < THIN_IR; ++j) in[j] = ava_pin(tile[j * THIN_IC + x + kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -618,7 +629,7 @@ __device__ __forceinline__ void thin_8to1_direct_body(const ConvArgs& a) {
       for (int kx = 0; kx < 3; ++kx) {
         float d[THIN_TH];
 #pragma unroll
-        for (int r = 0; r < THIN_TH; ++r) d[r] = dUt[r * THIN_IC + x + 2 - kx];
+        for (int r = 0; r < THIN_TH; ++r) d[r] = ava_pin(dUt[r * THIN_IC + x + 2 - kx]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -765,7 +776,7 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_1to8_kernel(const WgradArgs 
     for (int kx = 0; kx < 3; ++kx) {
       float in[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) in[j] = tile[(ty0 + j) * THIN_IC + x + kx];
+      for (int j = 0; j < 6; ++j) in[j] = ava_pin(tile[(ty0 + j) * THIN_IC + x + kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
       for (int kx = 0; kx < 3; ++kx) {
         float inn[THIN_IR];
 #pragma unroll
-        for (int j = 0; j < THIN_IR; ++j) inn[j] = tile_n[j * THIN_IC + x + kx];
+        for (int j = 0; j < THIN_IR; ++j) inn[j] = ava_pin(tile_n[j * THIN_IC + x + kx]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const avaf4 wq = *reinterpret_cast<const avaf4*>(w1s + (ky * 3 + kx) * 8 + hoff);
@@ -999,7 +1010,7 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
     for (int kx = 0; kx < 3; ++kx) {
       float in[THIN_IR];
 #pragma unroll
-      for (int j = 0; j < THIN_IR; ++j) in[j] = tile[j * THIN_IC + x + kx];
+      for (int j = 0; j < THIN_IR; ++j) in[j] = ava_pin(tile[j * THIN_IC + x + kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1140,7 +1151,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
     Cc += edge_col ? strip : 0.f;
     avaf2 dd[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) dd[p] = avaf2{du[p], du[p]};
+    for (int p = 0; p < 4; ++p) { const float dp = ava_pin(du[p]); dd[p] = avaf2{dp, dp}; }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -1276,7 +1287,7 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(con
     for (int kx = 0; kx < 3; ++kx) {
       float d[THIN_IR];
 #pragma unroll
-      for (int j = 0; j < THIN_IR; ++j) d[j] = tile[j * THIN_IC + x + 2 - kx];
+      for (int j = 0; j < THIN_IR; ++j) d[j] = ava_pin(tile[j * THIN_IC + x + 2 - kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1424,7 +1435,8 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
                     w2a = {w2[0], w2[1]}, w2b = {w2[2], w2[3]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const avaf2 x0 = {xn[r][ci], xn[r][ci]}, x1 = {xn[r + 1][ci], xn[r + 1][ci]};
+          const float xr0 = ava_pin(xn[r][ci]), xr1 = ava_pin(xn[r + 1][ci]);      // (see ava_pin)
+          const avaf2 x0 = {xr0, xr0}, x1 = {xr1, xr1};
           acc[2 * r][0] = __builtin_elementwise_fma(x0, w1a, acc[2 * r][0]);
           acc[2 * r][1] = __builtin_elementwise_fma(x0, w1b, acc[2 * r][1]);
           acc[2 * r + 1][0] = __builtin_elementwise_fma(x0, w2a, acc[2 * r + 1][0]);

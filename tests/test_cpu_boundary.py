@@ -175,3 +175,21 @@ def test_unsupported_sizes_are_refused():
             VAE(device_name="cpu", x_shape=bad)
         assert lib.ava_arena_floats_hw(32, bad[0], bad[1]) == -1 and lib.ava_workspace_bytes_hw(32, bad[0], bad[1], 8) == 0
     assert lib.ava_arena_floats_hw(32, 128, 128) == lib.ava_arena_floats(32)
+
+
+def test_no_packed_fma_selects_a_high_register_for_its_low_lane():
+    """profiles/NOTES.md item 44: on gfx950 `v_pk_fma_f32 ... op_sel:[0,1,0]` (the broadcast scalar sits in the odd register of
+    a pair) returns a wrong low half in lanes 48..63 while a bf16-MFMA wave of another kernel shares the SIMD.  The packed-FMA
+    kernels pin their broadcast scalars (`conv_thin_kernels.h: ava_pin`); this scans the BUILT code objects so that a later
+    edit cannot silently bring the form back.  Skipped where the objects or the llvm tools are not at hand."""
+    import glob
+    import subprocess
+    import sys
+    import pytest
+    objs = glob.glob(os.path.join(ROOT, "autoencoded-vocal-analysis_amd", "csrc", "*.o"))
+    if not objs or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no built objects / llvm-objdump")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lab", "op_sel_scan.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "packed fp32 instructions scanned, 0 with" in res.stdout

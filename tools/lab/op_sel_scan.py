@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Scan the built gfx950 code objects for the packed-fp32 instruction form that gfx950 executes wrongly beside a co-resident
+bf16-MFMA wave of another kernel (profiles/NOTES.md item 44, tools/lab/two_proc_repro.hip): v_pk_{fma,mul,add}_f32 whose
+op_sel selects the HIGH register of a source pair for the LOW result lane (any 1 in `op_sel:[...]`).  The low-register
+broadcast (`op_sel_hi:[..0..]`) is not affected and is not reported.
+usage: python tools/lab/op_sel_scan.py [object files ...]   (default: every .o under autoencoded-vocal-analysis_amd/csrc)
+exit status 1 when an instance is found."""
+import glob, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def disassemble(obj, tmp):
+    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "co.elf")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+    if os.path.getsize(fat) == 0:
+        return ""
+    subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    "--input=" + fat, "--output=" + co], check=True, stderr=subprocess.DEVNULL)
+    return subprocess.run([LLVM + "/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+
+
+def main():
+    objs = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "autoencoded-vocal-analysis_amd", "csrc", "*.o")))
+    bad = {}
+    total = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj in objs:
+            kern = None
+            for line in disassemble(obj, tmp).splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+                if m:
+                    kern = m.group(1)
+                    continue
+                if re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+                    total += 1
+                    m = re.search(r"op_sel:\[([01,]+)\]", line)
+                    if m and "1" in m.group(1):
+                        bad[(os.path.basename(obj), kern)] = bad.get((os.path.basename(obj), kern), 0) + 1
+    for (obj, kern), n in sorted(bad.items(), key=lambda kv: -kv[1]):
+        print("%5d  %s  %s" % (n, obj, kern))
+    print("%d packed fp32 instructions scanned, %d with a high-register select for the low lane, in %d kernels" % (total, sum(bad.values()), len(bad)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

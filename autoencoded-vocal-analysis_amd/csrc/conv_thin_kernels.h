@@ -67,15 +67,25 @@ struct ThinWeights {
 // not fit beside the kernel's other scalars and hipcc spills them to VGPR lanes (125 v_readlane + 89 v_writelane per tile
 // in the first version); the empty asm keeps hipcc from re-reading them from memory inside the tile loop.
 typedef float avaf2 __attribute__((ext_vector_type(2)));
-// A scalar that is BROADCAST into both halves of a packed-FMA operand must not be the ODD register of a wider value (the second
-// dword of a ds_read2_b32, element 1 or 3 of a 16-byte load): hipcc then selects it with op_sel (v_pk_fma_f32 ... op_sel:[0,1,0]),
-// and on gfx950 that form returns a WRONG low-half result in lanes 48..63 while a wave of another kernel that interleaves
-// v_mfma_f32_16x16x32_bf16 with vector instructions shares the SIMD -- a second stream or a second process; never within one
-// stream (tools/lab/two_proc_repro.hip: a stand-alone reproducer with no code of this library; profiles/NOTES.md item 44).
-// Passing the scalar through an empty asm makes it a register of its own: the broadcast then reads the LOW register of an aligned
-// pair (op_sel_hi:[1,0,1]), which is not affected.  tools/lab/op_sel_scan.py checks the built code objects for the bad form.
+// A scalar that is BROADCAST into both halves of a packed operand must not reach the instruction as "src1, high register for both
+// lanes": `v_pk_fma_f32 vD, vA, vB, vC op_sel:[0,1,0]` (and v_pk_mul_f32 ... op_sel:[0,1]) -- what hipcc emits when the scalar is the
+// second dword of a ds_read2_b32 or element 1 / 3 of a 16-byte load and it sits in the src1 slot.  On gfx950 that form returns a
+// WRONG low half in lanes 48..63 while a wave of another kernel that issues v_mfma_f32_16x16x32_bf16 shares the SIMD -- a second
+// stream or a second process; never within one stream.  The same select on src0 or src2, every op_sel_hi form and the swapped-halves
+// form are executed correctly (tools/lab/op_sel_forms.hip: an 80-line probe; tools/lab/two_proc_repro.hip; profiles/NOTES.md
+// item 44).  Passing the scalar through an empty asm makes it a register of its own, and the broadcast then reads the LOW register
+// of an aligned pair (op_sel_hi:[1,0,1]) -- at the price of the odd partner register and a move (convt7's forward: + 1.9 us).  The
+// two kernels in which hipcc produced the bad form (convt7's forward + fold and its weight-gradient kernel: the seed of the thread's
+// own column, second dword of a ds_read2_b32) now pass the broadcast as the FIRST multiplicand instead: hipcc keeps the order, the
+// select lands on src0, no register and no instruction is spent, results are bit-identical (a * b is commutative).  The compiler is
+// free to change its mind, so tools/lab/op_sel_scan.py scans the BUILT code objects for the bad form and tests/test_cpu_boundary.py
+// runs the scan; AVA_PIN_MASK (one bit per site below) is the fallback that does not depend on operand order.
+#ifndef AVA_PIN_MASK
+#define AVA_PIN_MASK 0
+#endif
+template <int SITE>
 __device__ __forceinline__ float ava_pin(float v) {
-  asm volatile("" : "+v"(v));
+  if constexpr ((AVA_PIN_MASK >> SITE) & 1) asm volatile("" : "+v"(v));
   return v;
 }
 struct ThinPairWeights {
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(2 * W, W == 128 ? 4 : 2) void thin_1to8_kernel(cons
     for (int kx = 0; kx < 3; ++kx) {
       float in[THIN_IR];
 #pragma unroll
-      for (int j = 0; j < THIN_IR; ++j) in[j] = ava_pin(tile[j * THIN_IC + x + kx]);
+      for (int j = 0; j < THIN_IR; ++j) in[j] = ava_pin<0>(tile[j * THIN_IC + x + kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -629,14 +639,14 @@ __device__ __forceinline__ void thin_8to1_direct_body(const ConvArgs& a) {
       for (int kx = 0; kx < 3; ++kx) {
         float d[THIN_TH];
 #pragma unroll
-        for (int r = 0; r < THIN_TH; ++r) d[r] = ava_pin(dUt[r * THIN_IC + x + 2 - kx]);
+        for (int r = 0; r < THIN_TH; ++r) d[r] = ava_pin<1>(dUt[r * THIN_IC + x + 2 - kx]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < THIN_TH; ++r) {
             const avaf2 dv = {d[r], d[r]};
 #pragma unroll
-            for (int q = 0; q < 2; ++q) facc[ky * 3 + kx][q] = __builtin_elementwise_fma(xh[r + ky][q], dv, facc[ky * 3 + kx][q]);
+            for (int q = 0; q < 2; ++q) facc[ky * 3 + kx][q] = __builtin_elementwise_fma(dv, xh[r + ky][q], facc[ky * 3 + kx][q]);
           }
       }
     }
@@ -776,7 +786,7 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_1to8_kernel(const WgradArgs 
     for (int kx = 0; kx < 3; ++kx) {
       float in[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) in[j] = ava_pin(tile[(ty0 + j) * THIN_IC + x + kx]);
+      for (int j = 0; j < 6; ++j) in[j] = ava_pin<7>(tile[(ty0 + j) * THIN_IC + x + kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -947,7 +957,7 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
       for (int kx = 0; kx < 3; ++kx) {
         float inn[THIN_IR];
 #pragma unroll
-        for (int j = 0; j < THIN_IR; ++j) inn[j] = ava_pin(tile_n[j * THIN_IC + x + kx]);
+        for (int j = 0; j < THIN_IR; ++j) inn[j] = ava_pin<2>(tile_n[j * THIN_IC + x + kx]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const avaf4 wq = *reinterpret_cast<const avaf4*>(w1s + (ky * 3 + kx) * 8 + hoff);
@@ -1010,7 +1020,7 @@ __global__ __launch_bounds__(2 * W) void thin_bwd_fused_1to8_kernel(const FusedA
     for (int kx = 0; kx < 3; ++kx) {
       float in[THIN_IR];
 #pragma unroll
-      for (int j = 0; j < THIN_IR; ++j) in[j] = ava_pin(tile[j * THIN_IC + x + kx]);
+      for (int j = 0; j < THIN_IR; ++j) in[j] = ava_pin<3>(tile[j * THIN_IC + x + kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1151,7 +1161,7 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stats_8to1_kernel(const Fus
     Cc += edge_col ? strip : 0.f;
     avaf2 dd[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { const float dp = ava_pin(du[p]); dd[p] = avaf2{dp, dp}; }
+    for (int p = 0; p < 4; ++p) { const float dp = ava_pin<4>(du[p]); dd[p] = avaf2{dp, dp}; }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -1287,14 +1297,14 @@ __global__ __launch_bounds__(2 * W) void thin_wgrad_stats_8to1_direct_kernel(con
     for (int kx = 0; kx < 3; ++kx) {
       float d[THIN_IR];
 #pragma unroll
-      for (int j = 0; j < THIN_IR; ++j) d[j] = ava_pin(tile[j * THIN_IC + x + 2 - kx]);
+      for (int j = 0; j < THIN_IR; ++j) d[j] = ava_pin<5>(tile[j * THIN_IC + x + 2 - kx]);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int r = 0; r < THIN_TH; ++r) {
           const avaf2 dv = {d[r + 2 - ky], d[r + 2 - ky]};
 #pragma unroll
-          for (int q = 0; q < 2; ++q) acc[ky * 3 + kx][q] = __builtin_elementwise_fma(xh[r][q], dv, acc[ky * 3 + kx][q]);
+          for (int q = 0; q < 2; ++q) acc[ky * 3 + kx][q] = __builtin_elementwise_fma(dv, xh[r][q], acc[ky * 3 + kx][q]);
         }
     }
   }
@@ -1435,7 +1445,7 @@ __global__ __launch_bounds__(256, 3) void up88_direct_kernel(const ConvArgs a) {
                     w2a = {w2[0], w2[1]}, w2b = {w2[2], w2[3]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float xr0 = ava_pin(xn[r][ci]), xr1 = ava_pin(xn[r + 1][ci]);      // (see ava_pin)
+          const float xr0 = ava_pin<6>(xn[r][ci]), xr1 = ava_pin<6>(xn[r + 1][ci]);      // (see ava_pin)
           const avaf2 x0 = {xr0, xr0}, x1 = {xr1, xr1};
           acc[2 * r][0] = __builtin_elementwise_fma(x0, w1a, acc[2 * r][0]);
           acc[2 * r][1] = __builtin_elementwise_fma(x0, w1b, acc[2 * r][1]);

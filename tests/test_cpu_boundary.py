@@ -178,10 +178,10 @@ def test_unsupported_sizes_are_refused():
 
 
 def test_no_packed_fma_selects_a_high_register_for_its_low_lane():
-    """profiles/NOTES.md item 44: on gfx950 `v_pk_fma_f32 ... op_sel:[0,1,0]` (the broadcast scalar sits in the odd register of
-    a pair) returns a wrong low half in lanes 48..63 while a bf16-MFMA wave of another kernel shares the SIMD.  The packed-FMA
-    kernels pin their broadcast scalars (`conv_thin_kernels.h: ava_pin`); this scans the BUILT code objects so that a later
-    edit cannot silently bring the form back.  Skipped where the objects or the llvm tools are not at hand."""
+    """profiles/NOTES.md item 44: on gfx950 `v_pk_fma_f32 ... op_sel:[0,1,0]` (src1 read from the odd register of a pair by both
+    lanes) returns a wrong low half in lanes 48..63 while a bf16-MFMA wave of another kernel shares the SIMD.  The two kernels
+    in which hipcc produces that form pin their broadcast scalars (`conv_thin_kernels.h: ava_pin`); this scans the BUILT code
+    objects so that a later edit -- or another operand order chosen by the compiler -- cannot silently bring the form back.  Skipped where the objects or the llvm tools are not at hand."""
     import glob
     import subprocess
     import sys
@@ -192,4 +192,4 @@ def test_no_packed_fma_selects_a_high_register_for_its_low_lane():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lab", "op_sel_scan.py")], capture_output=True, text=True,
                          timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    assert "packed fp32 instructions scanned, 0 with" in res.stdout
+    assert "packed fp32 instructions scanned, 0 with" in res.stdout, res.stdout[-500:]

@@ -31,7 +31,7 @@ from oracle import vae_oracle as O
 # 5e-5: against the fp32 goldens the bound is therefore the goldens' own distance from fp64 -- 1e-4 at B=8 outside
 # conv1/bn1 (whose B=8 golden carries one ReLU flip: 9e-3), 1e-2 at B=64 (same values as tests/test_oracle_golden.py).
 FLIP_TOL = 2e-2
-GTOL = {8: 1e-4}          # (B = 64: no gradient comparison against the flip-carrying golden any more, see the test)
+GTOL = {8: 1e-4, 64: 1e-2}   # B = 64: the golden's own distance from fp64 (its gradients carry the reference's ReLU flips)
 
 
 def _oracle_grads(fp, x, ew, ed, dtype):
@@ -140,12 +140,11 @@ def test_train_step_matches_reference_golden(B, z):
         assert rel(1.0 / bn_save[i - 1, 1, :c] ** 2 - 1e-5, G["s1.bn%d.var" % i]) < 1e-4
     loss.backward()
     named = dict(model.named_parameters())
-    # Gradients, B = 64: this golden's gradients carry ReLU flips of the reference's own fp32
-    # evaluation (it is 1e-2 away from fp64), so a comparison against them could only be held to 1e-2 -- no evidence
-    # beyond what test_flip_free_reference_golden[64] (the REAL reference at B = 64, 1e-4 per tensor, nothing masked) and
-    # the mask-imposed fp64 suite assert.  The gradient / Adam-moment part therefore runs at B = 8 only; at B = 64 the
-    # forward quantities above, the running statistics and the size of the first Adam step below are what is checked.
-    check_grads = B == 8
+    # Gradients.  B = 8: 1e-4 per tensor (FLIP_TOL on conv1 / bn1, whose golden carries one flip).  B = 64: this golden's gradients
+    # carry the ReLU flips of the reference's own fp32 evaluation (it is 1e-2 away from fp64), so 1e-2 is all it can assert
+    # (kept as a coarse check rather than dropped); the tight B = 64 evidence is
+    # test_flip_free_reference_golden[64] (the REAL reference, 1e-4 per tensor, nothing masked) and the mask-imposed fp64 suite.
+    check_grads = True
     for s in (param_specs(z) if check_grads else ()):
         g = named[s.name].grad.cpu().numpy().ravel()
         sens = s.layer in ("conv1", "bn1")

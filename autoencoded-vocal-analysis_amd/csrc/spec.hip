@@ -79,13 +79,17 @@ __global__ __launch_bounds__(AVA_SPEC_PREP_T) void spec_prep_kernel(const SpecAr
   __shared__ double red[AVA_SPEC_PREP_T];
   __shared__ double tlo[64], thi[64];
   const int w = blockIdx.x, t = threadIdx.x;
-  if (w == 0)
-    for (int k = t; k < a.nperseg / 2; k += AVA_SPEC_PREP_T) {
+  if (w == 0) {
+    // power of two: exp(-2 pi i k / N) for k < N / 2 (k / N is exact); any other length: the whole circle, k < N, for the direct
+    // transform (spec_dft_kernel), whose index (k n) mod N is exact -- only the quotient k / N is rounded, 1e-16 of the angle
+    const int ntw = (a.nperseg & (a.nperseg - 1)) == 0 ? a.nperseg / 2 : a.nperseg;
+    for (int k = t; k < ntw; k += AVA_SPEC_PREP_T) {
       double sn, cs;
-      sincospi(-2.0 * (double)k / (double)a.nperseg, &sn, &cs);      // k / nperseg is exact (power of two)
+      sincospi(-2.0 * (double)k / (double)a.nperseg, &sn, &cs);
       a.twiddle[2 * k] = cs;
       a.twiddle[2 * k + 1] = sn;
     }
+  }
   if (w == 0 && t < 64) {                                       // bins the target frequencies lie between (+- 2 of slack)
     double mnf = 1e300, mxf = -1e300;
     for (int i = t; i < a.F; i += 64) {
@@ -305,6 +309,50 @@ __global__ __launch_bounds__(256) void spec_stft_kernel(const SpecArgs a) {
 
 #undef PD
 
+// The same for a segment length that is NOT a power of two (the reference hands any nperseg to scipy.signal.stft,
+// ava/preprocessing/utils.py:66-68; scipy's pocketfft takes any length): the one-sided spectrum by direct summation in fp64,
+//   X_k = sum_n v_n exp(-2 pi i (k n mod N) / N),   v = (x - mean) * window,
+// for the bins k0 .. k1 the interpolation can touch only.  The frame and the N twiddles live in LDS; a thread owns a bin and walks
+// n with the table index advanced by k modulo N (exact integer arithmetic: no argument reduction error).  N^2 work instead of
+// N log N -- 0.3 ms for a batch of 256 windows at N = 400 -- on a path whose power-of-two lengths (every example script of the
+// reference uses 512 or 1024) keep the radix-2 kernel above.  Error of a direct sum: <= N eps sum |v|, as pocketfft's to a factor.
+#define AVA_SPEC_DFT_MAXN 2048
+__global__ __launch_bounds__(256) void spec_dft_kernel(const SpecArgs a) {
+  __shared__ double v[AVA_SPEC_DFT_MAXN];
+  __shared__ double twr[AVA_SPEC_DFT_MAXN], twi[AVA_SPEC_DFT_MAXN];
+  const int w = blockIdx.y, t = threadIdx.x, N = a.nperseg, K1 = N / 2;
+  const SpecMeta m = a.meta[w];
+  if (m.nframes <= 0 || m.j0 + (int)blockIdx.x > m.j1) return;
+  for (int k = t; k < N; k += 256) {
+    twr[k] = a.twiddle[2 * k];
+    twi[k] = a.twiddle[2 * k + 1];
+  }
+  const int k0 = a.krange[0], k1 = a.krange[1];
+  for (int j = m.j0 + blockIdx.x; j <= m.j1; j += gridDim.x) {
+    __syncthreads();                                       // twiddles ready / previous frame's reads retired
+    for (int i = t; i < N; i += 256) {
+      const long long idx = (long long)j * a.nstep + i - N / 2;              // position in the slice (zeros outside)
+      const bool in = idx >= 0 && idx < m.n;
+      const double x = audio_at(a.audio, a.dtype, m.lo + (in ? idx : 0));
+      v[i] = in ? __dmul_rn(x - m.mean, a.window[i]) : 0.0;
+    }
+    __syncthreads();
+    double* dst = a.logmag + ((size_t)w * a.maxframes + j) * (K1 + 1);
+    for (int k = k0 + t; k <= k1; k += 256) {
+      double xr = 0.0, xi = 0.0;
+      int q = 0;                                           // (k n) mod N
+      for (int n = 0; n < N; ++n) {
+        const double vn = v[n];
+        xr = fma(vn, twr[q], xr);
+        xi = fma(vn, twi[q], xi);
+        q += k;
+        if (q >= N) q -= N;
+      }
+      dst[k] = log(__dadd_rn(__dmul_rn(sqrt(xr * xr + xi * xi), a.scale), AVA_SPEC_EPS));
+    }
+  }
+}
+
 // utils.py:77-103.  Linear B-spline evaluation in FITPACK's order (fpbspl: h0 = f (t[l+1] - x), h1 = f (x - t[l]) with
 // f = 1 / (t[l+1] - t[l]); fpbisp: sum over x then y of (c * hx) * hy), then interp2d's out-of-bounds rule, then
 // normalisation and clip.  A workgroup owns AVA_SPEC_ROWS frequency rows of one window: the knot interval and the two
@@ -484,14 +532,14 @@ __global__ __launch_bounds__(AVA_SPEC_NORM_T) void spec_normalize_kernel(const S
 static int frames_for(int max_samples, int nstep) { return (max_samples + nstep - 1) / nstep + 1; }
 
 static bool spec_shape_ok(int nperseg, int noverlap) {
-  if (nperseg < 64 || nperseg > 2048 || (nperseg & (nperseg - 1)) != 0) return false;
+  if (nperseg < 64 || nperseg > 2048) return false;       // a power of two: radix-2 kernel; any other length: direct transform
   return noverlap >= 0 && noverlap < nperseg;
 }
 
 extern "C" size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap, int F, int T, int normalize) {
   if (n <= 0 || max_samples <= 0 || F <= 0 || T <= 0 || !spec_shape_ok(nperseg, noverlap)) return 0;
   const size_t frames = (size_t)frames_for(max_samples, nperseg - noverlap);
-  return 256 + 16 + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15) + (size_t)nperseg * sizeof(double) +
+  return 256 + 16 + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15) + (size_t)2 * nperseg * sizeof(double) +
          (size_t)n * frames * sizeof(double) + (size_t)n * frames * (size_t)(nperseg / 2 + 1) * sizeof(double) +
          (normalize ? (size_t)n * F * T * sizeof(double) : 0);
 }
@@ -520,7 +568,7 @@ extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int6
   base += 16;
   a.meta = reinterpret_cast<SpecMeta*>(base);
   a.twiddle = reinterpret_cast<double*>(base + (((size_t)n * sizeof(SpecMeta) + 15) & ~(size_t)15));
-  a.ftimes = a.twiddle + nperseg;
+  a.ftimes = a.twiddle + 2 * nperseg;                 // room for the whole circle (lengths that are not a power of two)
   a.logmag = a.ftimes + (size_t)n * frames_for(max_samples, nperseg - noverlap);
   a.vals = a.logmag + (size_t)n * frames_for(max_samples, nperseg - noverlap) * (size_t)(nperseg / 2 + 1);
   a.normalize = normalize ? 1 : 0; a.q_lo = q_lo; a.q_gamma = q_gamma;
@@ -533,7 +581,8 @@ extern "C" int ava_get_spec_batch(const void* audio, int audio_dtype, const int6
   hipLaunchKernelGGL(spec_prep_kernel, dim3(n), dim3(AVA_SPEC_PREP_T), 0, st, a);
   AVA_CHECK_LAUNCH();
   const dim3 fgrid(a.maxframes < 24 ? a.maxframes : 24, n);      // a workgroup strides over its window's needed frames
-  switch (nperseg) {
+  if ((nperseg & (nperseg - 1)) != 0) hipLaunchKernelGGL(spec_dft_kernel, fgrid, dim3(256), 0, st, a);
+  else switch (nperseg) {
     case 64: hipLaunchKernelGGL(spec_stft_kernel<6>, fgrid, dim3(256), 0, st, a); break;
     case 128: hipLaunchKernelGGL(spec_stft_kernel<7>, fgrid, dim3(256), 0, st, a); break;
     case 256: hipLaunchKernelGGL(spec_stft_kernel<8>, fgrid, dim3(256), 0, st, a); break;

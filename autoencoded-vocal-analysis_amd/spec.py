@@ -13,8 +13,9 @@ order, so that a seeded call picks the very windows the reference picks), and th
 produced by three launches (``csrc/spec.hip``) straight into the fp32 ``[batch, freq, time]`` tensor the VAE step
 consumes: no CPU workers, no host-to-device copy of spectrograms.
 
-Not covered: ``nperseg`` must be a power of two in 64..2048, at most 512 target times per window
-(``NotImplementedError`` otherwise).  There is no CPU
+``nperseg`` may be any length in 64..2048: powers of two (every example script of the reference) run a radix-2 transform, other
+lengths a direct fp64 transform of the bins the target grid can touch.  Not covered: ``nperseg`` outside 64..2048, more than 512
+target times per window (``NotImplementedError`` otherwise).  There is no CPU
 fallback.
 """
 import warnings
@@ -152,8 +153,8 @@ def get_spec_batch(audio, file_idx, t1, t2, p, fs, target_times, target_freqs=No
     s1, s2 = np.rint(t1 * fs), np.rint(t2 * fs)                                     # int(round(.)): half to even
     assert (s1 < s2).all(), "s1 >= s2 for window %d" % int(np.argmin(s2 - s1))     # utils.py:60-61
     nperseg, noverlap = int(p['nperseg']), int(p['noverlap'])
-    if nperseg < 64 or nperseg > 2048 or nperseg & (nperseg - 1) or not 0 <= noverlap < nperseg:
-        raise NotImplementedError("device get_spec needs nperseg a power of two in 64..2048 and 0 <= noverlap < nperseg")
+    if nperseg < 64 or nperseg > 2048 or not 0 <= noverlap < nperseg:
+        raise NotImplementedError("device get_spec needs 64 <= nperseg <= 2048 and 0 <= noverlap < nperseg")
     if T > 512:
         raise NotImplementedError("device get_spec handles at most 512 target times per window")
     max_samples = int((s2 - s1).max())

@@ -310,7 +310,8 @@ int ava_pair_sqdist(const double* latent, int z, const int64_t* a, const int64_t
  *   normalize, q_lo,      p['within_syll_normalize'] (utils.py:104-108): subtract np.quantile(spec, p['normalize_quantile']),
  *   q_gamma               floor at 0, divide by max + 1e-12; the quantile is a[q_lo] + (a[q_lo+1] - a[q_lo]) * q_gamma over the
  *                         sorted F*T values (numpy's 'linear' method: q_lo and q_gamma as numpy derives them from q and F*T)
- * nperseg: a power of two in 64..2048, 0 <= noverlap < nperseg; T <= 512.
+ * nperseg: 64..2048 (a power of two: radix-2 transform; any other length: direct fp64 transform of the needed bins, as
+ * scipy.signal.stft takes any length, ava/preprocessing/utils.py:66-68), 0 <= noverlap < nperseg; T <= 512.
  * All arithmetic is fp64.  Windows the reference answers with zeros (utils.py:68-69) come out as zeros. */
 size_t ava_spec_workspace_bytes(int n, int max_samples, int nperseg, int noverlap, int F, int T, int normalize);
 int ava_get_spec_batch(const void* audio, int audio_dtype, const int64_t* file_off, const int64_t* file_len,

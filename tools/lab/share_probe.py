@@ -52,7 +52,7 @@ def worker(rank, q, parts, barrier, lock=None):
                     import ctypes
                     C = ctypes.CDLL(_lib.LIB_PATH)
                     C.ava_debug_buffer.restype = ctypes.c_void_p
-                    for nm in ("y2","y3","y4","y5","y6","y7","y7t","h1","h2","h3","mu","z","h5","h6","h7","f8","f8t","d1","d2","d3","d4","d5","d6","xrec","seed","bn_save","bn_bwd","dz","dF8"):
+                    for nm in ("y2","y3","y4","y5","y6","y7","y7t","h1","h2","h3","mu","z","h5","h6","h7","f8","f8t","d1","d2","d3","d4","d5","d6","xrec","seed","bn_save","bn_bwd","dz","dF8","wg13"):
                         n = ctypes.c_int64()
                         ptr = C.ava_debug_buffer(model._handle, nm.encode(), ctypes.byref(n))
                         if ptr: regions.append(((ptr - model._workspace.data_ptr()) // 4, n.value, nm))
@@ -75,7 +75,7 @@ def worker(rank, q, parts, barrier, lock=None):
         o, n, nm = best
         return ("%s+%d" % (nm, off - o)) if off < o + n else ("%d floats behind the end of %s" % (off - o - n, nm))
     reg = {nm: (o, n) for o, n, nm in regions}
-    wg13 = reg["dF8"][0] - 74752                       # wg_part[13]: 1024 rows x 73 floats in front of dF8 (model.hip: carve)
+    wg13 = reg["wg13"][0]                              # convt7's weight-gradient partial rows (model.hip: debug buffer "wg13", round 6)
     slot27 = reg["bn_bwd"][0] + reg["bn_bwd"][1] + 27 * 3200      # bn_acc slot 27 (1600 int64): what the fold adds bn14's backward sums to
     fold_on = os.environ.get("AVA_FOLD13", "1") != "0"       # (lab build: with the fold off the forward leaves these regions unwritten)
     for r in range(1, len(ws) if fold_on else 0):

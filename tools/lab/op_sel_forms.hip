@@ -1,4 +1,5 @@
-// Which operand-select forms of the packed fp32 instructions are executed wrongly on gfx950 while a wave of ANOTHER kernel that
+// Which operand-select forms of the packed fp32 instructions are executed wrongly on gfx950 while a wave of ANOTHER kernel (eight
+// neighbour kinds: one matrix instruction type each) that
 // alternates v_mfma_f32_16x16x32_bf16 with vector-ALU instructions shares the SIMD?  (profiles/NOTES.md item 44; the effect was
 // found as op_sel:[0,1,0] on v_pk_fma_f32 in tools/lab/two_proc_repro.hip.)  One process, two streams: the victim kernel runs
 // every form in a long loop on known operands and compares with the scalar result computed by plain v_fma_f32 in the same lane;
@@ -75,18 +76,35 @@ __global__ __launch_bounds__(256, 2) void victim_kernel(unsigned* bad, int iters
   for (int f = 0; f < NFORM; ++f) bad[(size_t)g * NFORM + f] = nbad[f];
 }
 
-// neighbour: v_mfma_f32_16x16x32_bf16 alternating with one plain vector instruction (kind 1), or the matrix instruction alone (0)
+// neighbours: one matrix instruction type each, back to back (the loop counter is scalar); kind 1 adds one plain vector instruction per
+// matrix instruction
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f16acc __attribute__((ext_vector_type(16)));
+static const char* kNeigh[] = {"v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x32_bf16 + v_add_f32", "v_mfma_f32_16x16x4_f32", "v_mfma_f32_16x16x32_f16",
+                               "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x16_bf16 (the 8-pass bf16 form)", "no matrix instruction: v_fma_f32 only"};
+constexpr int NNEIGH = 8;
 __global__ __launch_bounds__(512, 2) void neighbour_kernel(float* out, int iters, int kind) {
   const int t = threadIdx.x;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
+  f16acc acc16 = {};
   bf16x8 a, b;
-  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (t + i)); b[i] = (__bf16)(0.002f * (t - i)); }
+  f16x8 ha, hb;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 a4, b4;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (t + i)); b[i] = (__bf16)(0.002f * (t - i)); ha[i] = (_Float16)(0.001f * (t + i)); hb[i] = (_Float16)(0.002f * (t - i)); }
+  for (int i = 0; i < 4; ++i) { a4[i] = a[i]; b4[i] = b[i]; }
   float x = 0.001f * t;
   for (int i = 0; i < iters; ++i) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    if (kind <= 1) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    else if (kind == 2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, 0.5f, acc, 0, 0, 0);
+    else if (kind == 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc, 0, 0, 0);
+    else if (kind == 4) acc16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc16, 0, 0, 0);
+    else if (kind == 5) acc16 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, 0.5f, acc16, 0, 0, 0);
+    else if (kind == 6) acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, b4, acc, 0, 0, 0);
+    else asm volatile("v_fma_f32 %0, %0, 1.0, 1.0" : "+v"(x));
     if (kind == 1) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
   }
-  out[(size_t)blockIdx.x * 512 + t] = acc[0] + acc[3] + x;
+  out[(size_t)blockIdx.x * 512 + t] = acc[0] + acc[3] + x + acc16[0] + acc16[15];
 }
 
 int main(int argc, char** argv) {
@@ -97,7 +115,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dbad, (size_t)grid * 256 * NFORM * 4)); CK(hipMalloc(&nout, 512 * 512 * 4));
   hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
   std::vector<unsigned> h((size_t)grid * 256 * NFORM);
-  for (int nk = -1; nk <= 1; ++nk) {
+  for (int nk = -1; nk < NNEIGH; ++nk) {
     unsigned long lo[NFORM] = {0}, hi[NFORM] = {0}; unsigned lanes[NFORM][4] = {{0}};
     for (int l = 0; l < launches; ++l) {
       if (nk >= 0) neighbour_kernel<<<256, 512, 0, s2>>>(nout, 6000, nk);
@@ -110,7 +128,7 @@ int main(int argc, char** argv) {
           if (v) { lo[f] += v & 0xffff; hi[f] += v >> 16; lanes[f][(g & 63) >> 4] += 1; }
         }
     }
-    printf("neighbour: %s\n", nk < 0 ? "none" : (nk == 0 ? "bf16 MFMA alone" : "bf16 MFMA alternating with v_add_f32"));
+    printf("neighbour: %s\n", nk < 0 ? "none" : kNeigh[nk]);
     for (int f = 0; f < NFORM; ++f)
       printf("  %-52s wrong low halves %8lu, wrong high halves %8lu   (threads hit, by lane quarter 0-15 / 16-31 / 32-47 / 48-63: %u %u %u %u)\n",
              kForm[f], lo[f], hi[f], lanes[f][0], lanes[f][1], lanes[f][2], lanes[f][3]);

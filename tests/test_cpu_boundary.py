@@ -193,3 +193,25 @@ def test_no_packed_fma_selects_a_high_register_for_its_low_lane():
                          timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "packed fp32 instructions scanned, 0 with" in res.stdout, res.stdout[-500:]
+
+
+def test_op_sel_scanner_flags_exactly_the_form_the_probe_found_wrong():
+    """the scanner's rule on disassembly lines of every form tools/lab/op_sel_forms.hip measured (profiles/NOTES.md item 44 h)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("op_sel_scan", os.path.join(ROOT, "tools", "lab", "op_sel_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = ["\tv_pk_fma_f32 v[86:87], v[142:143], v[46:47], v[86:87] op_sel:[0,1,0]// 0000: D3B0",
+           "\tv_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[0,1]",
+           "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[0:1] op_sel:[1,1,0]",
+           "\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]"]                      # (add: not probed on src1, flagged conservatively)
+    good = ["\tv_pk_fma_f32 v[4:5], v[24:25], v[24:25], v[4:5]",
+            "\tv_pk_fma_f32 v[8:9], v[6:7], v[46:47], v[8:9] op_sel:[1,0,0]",
+            "\tv_pk_fma_f32 v[8:9], v[6:7], v[46:47], v[8:9] op_sel:[0,0,1]",
+            "\tv_pk_fma_f32 v[126:127], v[142:143], v[186:187], v[126:127] op_sel_hi:[1,0,1]",
+            "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[0:1] op_sel_hi:[0,1,1]",
+            "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[0:1] op_sel:[1,1,0] op_sel_hi:[0,0,1]",
+            "\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]",
+            "\tv_pk_mul_lo_u16 v4, v4, 60 op_sel_hi:[1,0]",
+            "\tv_fma_f32 v0, v1, v2, v3"]
+    assert all(mod.is_bad(l) for l in bad) and not any(mod.is_bad(l) for l in good)

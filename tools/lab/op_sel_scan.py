@@ -22,6 +22,17 @@ def disassemble(obj, tmp):
     return subprocess.run([LLVM + "/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
 
 
+def is_bad(line):
+    """True for a packed fp32 multiply / FMA / add whose src1 is read from the HIGH register by BOTH result lanes"""
+    if not re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+        return False
+    m = re.search(r"op_sel:\[([01,]+)\]", line)
+    mh = re.search(r"op_sel_hi:\[([01,]+)\]", line)
+    sel = m.group(1).split(",") if m else []
+    sel_hi = mh.group(1).split(",") if mh else []
+    return len(sel) > 1 and sel[1] == "1" and not (len(sel_hi) > 1 and sel_hi[1] == "0")
+
+
 def main():
     objs = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "autoencoded-vocal-analysis_amd", "csrc", "*.o")))
     bad = {}
@@ -36,11 +47,7 @@ def main():
                     continue
                 if re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
                     total += 1
-                    m = re.search(r"op_sel:\[([01,]+)\]", line)
-                    mh = re.search(r"op_sel_hi:\[([01,]+)\]", line)
-                    sel = m.group(1).split(",") if m else []
-                    sel_hi = mh.group(1).split(",") if mh else []
-                    if len(sel) > 1 and sel[1] == "1" and not (len(sel_hi) > 1 and sel_hi[1] == "0"):
+                    if is_bad(line):
                         bad[(os.path.basename(obj), kern)] = bad.get((os.path.basename(obj), kern), 0) + 1
     for (obj, kern), n in sorted(bad.items(), key=lambda kv: -kv[1]):
         print("%5d  %s  %s" % (n, obj, kern))
